@@ -1,0 +1,240 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python oracle/gen_golden.py
+Needs /root/reference (absent on the GPU box -- the committed .npz/.json files
+are what travels).  The reference's Python is imported, never copied.
+
+Missing third-party modules are stubbed in ``sys.modules``:
+* ``torchvision.models.resnet.resnet34``: a plain-torch ResNet34 with
+  torchvision's attribute / parameter names (public architecture: BasicBlock
+  [3,4,6,3], conv1 7x7 s2, maxpool 3x3 s2).  The reference code under test is
+  ``UNetResNet34`` + ``Net2DSeg`` which wrap it.
+* ``sparseconvnet``: empty module (the 3D path cannot be imported; its oracle
+  stays "parity unpinned").
+Weights come from oracle.params.det_tensor(name) so only I/O is stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- stubs
+def _install_stubs():
+    class BasicBlock(nn.Module):
+        def __init__(self, cin, c, stride):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, c, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(c)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(c)
+            self.downsample = None
+            if stride != 1 or cin != c:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, c, 1, stride, bias=False), nn.BatchNorm2d(c))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.bn2(self.conv2(y))
+            return self.relu(y + idt)
+
+    class ResNet34(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            cin = 64
+            for i, (c, n, s) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+                blocks = [BasicBlock(cin, c, s)] + [BasicBlock(c, c, 1) for _ in range(n - 1)]
+                setattr(self, f"layer{i}", nn.Sequential(*blocks))
+                cin = c
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvr.resnet34 = lambda pretrained=False: ResNet34()
+    tv.models, tvm.resnet = tvm, tvr
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr,
+                        "sparseconvnet": types.ModuleType("sparseconvnet"),
+                        "openpyxl": types.ModuleType("openpyxl")})  # metric_logger.py:11 (xlsx export, unused here)
+    sys.path.insert(0, REF)
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------- G1
+def gen_g1():
+    from mopa.models.xmuda_arch import Net2DSeg  # reference
+    from oracle.params import det_tensor
+
+    def build(C=5):
+        net = Net2DSeg(num_classes=C, dual_head=True, backbone_2d="UNetResNet34",
+                       backbone_2d_kwargs={"pretrained": False}, output_all=True)
+        sd = net.state_dict()
+        net.load_state_dict({k: det_tensor(k, v.shape) for k, v in sd.items()})
+        return net
+
+    cases = {"pad_eval": ((2, 3, 30, 46), False), "nopad_eval": ((1, 3, 32, 48), False),
+             "pad_train": ((2, 3, 30, 46), True)}
+    for name, (shape, train) in cases.items():
+        rng = np.random.Generator(np.random.PCG64(len(name)))
+        img = torch.from_numpy(rng.random(shape, dtype=np.float32))
+        idx = [np.stack([rng.integers(0, shape[2], 200), rng.integers(0, shape[3], 200)], 1).astype(np.int64)
+               for _ in range(shape[0])]
+        net = build()
+        net.train(train)
+        net.net_2d.dropout.p = 0.0  # train-mode parity without RNG (hard part 5)
+        img.requires_grad_(True)
+        out = net({"img": img, "img_indices": idx})
+        save = {"img": img, **{f"idx{i}": a for i, a in enumerate(idx)}}
+        save.update({"out_" + k: v for k, v in out.items()})
+        if train:
+            g = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
+            save.update({"gin_" + k: v for k, v in g.items()})
+            sum((out[k] * g[k]).sum() for k in out).backward()
+            save["grad_img"] = img.grad
+            norms = {}
+            for k, p in net.named_parameters():
+                norms[k] = [float(p.grad.double().sum()), float(p.grad.double().norm())]
+            for k in ("net_2d.conv1.weight", "linear.weight", "linear2.bias", "net_2d.dec_conv_stage1.bias",
+                      "net_2d.layer2.0.downsample.0.weight", "net_2d.dec_t_conv_stage2.0.weight",
+                      "net_2d.layer4.2.bn2.weight", "net_2d.bn1.bias"):
+                save["pgrad_" + k] = dict(net.named_parameters())[k].grad
+            for k in ("net_2d.bn1.running_mean", "net_2d.bn1.running_var", "net_2d.layer3.5.bn2.running_var",
+                      "net_2d.dec_conv_stage2.1.running_mean"):
+                save["buf_" + k] = net.state_dict()[k]
+            with open(os.path.join(OUT, f"g1_net2dseg_{name}_gradnorms.json"), "w") as f:
+                json.dump(norms, f, indent=0)
+        np.savez_compressed(os.path.join(OUT, f"g1_net2dseg_{name}.npz"), **_np(save))
+        print("G1", name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+# ----------------------------------------------------------------------------- G2
+def gen_g2():
+    from mopa.common.utils.loss import mask_cons_loss  # reference
+
+    rng = np.random.Generator(np.random.PCG64(22))
+    B, H, W, C = 3, 30, 46, 5
+    logits = torch.from_numpy(rng.standard_normal((B, H, W, C), dtype=np.float32) * 2).requires_grad_(True)
+    masks = []
+    for b in range(B):
+        m = rng.integers(0, 7, (H, W)).astype(np.int32)
+        m[:10] = -100
+        m[rng.random((H, W)) < 0.1] = -100
+        if b == 2:
+            m[:] = -100  # an image with no valid id still counts in the mean (loss.py:278-281)
+        masks.append(torch.from_numpy(m))
+    probs = F.softmax(logits, dim=3)  # caller: train_xmuda_mopa.py:473
+    loss = mask_cons_loss(probs, masks, True)
+    loss.backward()
+    loss_noent = mask_cons_loss(F.softmax(logits.detach(), dim=3), masks, False)
+    np.savez_compressed(os.path.join(OUT, "g2_mask_cons.npz"), logits=logits.detach().numpy(),
+                        masks=np.stack([m.numpy() for m in masks]), loss=loss.detach().numpy(),
+                        loss_noent=np.asarray(float(loss_noent)), grad_logits=logits.grad.numpy())
+    print("G2", float(loss), float(loss_noent))
+
+
+# ----------------------------------------------------------------------------- G3
+def gen_g3():
+    rng = np.random.Generator(np.random.PCG64(33))
+    N, C = 400, 5
+    a = torch.from_numpy(rng.standard_normal((N, C), dtype=np.float32) * 3).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal((N, C), dtype=np.float32) * 3)
+    lab = torch.from_numpy(rng.integers(0, C, N).astype(np.int64))
+    lab[rng.random(N) < 0.15] = -100
+    w = torch.tensor([2.68678412, 4.36182969, 5.47896839, 3.89026883, 1.0])
+    # same expressions as train_xmuda_mopa.py:389-393 and :354-358
+    kl = F.kl_div(F.log_softmax(a, dim=1), F.softmax(b.detach(), dim=1), reduction="none").sum(1).mean()
+    ga_kl, = torch.autograd.grad(kl, a)
+    ce = F.cross_entropy(a, lab, weight=w)
+    ga_ce, = torch.autograd.grad(ce, a)
+    ce_now = F.cross_entropy(a, lab)
+    ga_ce_now, = torch.autograd.grad(ce_now, a)
+    np.savez_compressed(os.path.join(OUT, "g3_kl_ce.npz"), a=a.detach().numpy(), b=b.numpy(), label=lab.numpy(),
+                        weight=w.numpy(), kl=kl.detach().numpy(), grad_kl=ga_kl.numpy(), ce=ce.detach().numpy(),
+                        grad_ce=ga_ce.numpy(), ce_noweight=ce_now.detach().numpy(), grad_ce_noweight=ga_ce_now.numpy())
+    print("G3", float(kl), float(ce))
+
+
+# ----------------------------------------------------------------------------- G4
+def gen_g4():
+    from mopa.data.utils.augmentation_3d import augment_and_scale_3d  # reference
+
+    save = {}
+    for k in range(3):
+        rng = np.random.Generator(np.random.PCG64(40 + k))
+        pts = (rng.standard_normal((500, 3)) * np.array([20, 20, 1.5])).astype(np.float32)
+        np.random.seed(k)
+        coords, _ = augment_and_scale_3d(pts, 20, 4096, noisy_rot=0.1 * (k > 0), flip_y=0.5 * (k > 0),
+                                         rot_z=6.2831 * (k > 1), transl=k > 0)
+        ci = coords.astype(np.int64)  # nuscenes_dataloader.py:419
+        keep = (ci.min(1) >= 0) & (ci.max(1) < 4096)  # :422-424
+        save[f"points{k}"], save[f"coords{k}"], save[f"keep{k}"] = pts, ci, keep
+    np.savez_compressed(os.path.join(OUT, "g4_voxelize.npz"), **save)
+    print("G4 ok")
+
+
+# ----------------------------------------------------------------------------- G5
+def gen_g5():
+    from mopa.data.utils.refine_pseudo_labels import refine_pseudo_labels  # reference
+    from mopa.models.losses import prob_2_entropy  # reference
+    from mopa.models.metric import SegIoU  # reference
+
+    rng = np.random.Generator(np.random.PCG64(55))
+    N, C = 300, 5
+    logit = torch.from_numpy(rng.standard_normal((N, C), dtype=np.float32) * 2)
+    prob = F.softmax(logit, 1)
+    maxp, lab = prob.max(1)
+    refined = refine_pseudo_labels(maxp.numpy().copy(), lab.numpy().copy())
+    ent = prob_2_entropy(prob)
+    gt = torch.from_numpy(rng.integers(0, C, N).astype(np.int64))
+    gt[rng.random(N) < 0.2] = -100
+    m = SegIoU(C, name="iou")
+    m.update_dict({"seg_logit": logit}, {"seg_label": gt})
+    m.update_dict({"seg_logit": logit.flip(0)}, {"seg_label": gt})
+    np.savez_compressed(os.path.join(OUT, "g5_misc.npz"), logit=logit.numpy(), refined=refined, entropy=ent.numpy(),
+                        gt=gt.numpy(), iou_mat=m.mat.numpy(), iou=m.iou.numpy())
+    print("G5 ok")
+
+
+# ----------------------------------------------------------------------------- G7
+def gen_g7():
+    """Integer pins of the synthetic scan (our own generator; not reference-derived)."""
+    from mopa_amd import synth
+    from oracle import scn3d
+
+    pins = {}
+    for seed in (0, 1):
+        s = synth.make_scan(seed)
+        c = np.concatenate([s["coords"], np.zeros((len(s["coords"]), 1), np.int64)], 1)
+        g = scn3d.Geometry(c)
+        pins[str(seed)] = {"n_points": int(c.shape[0]), "extent": s["coords"].max(0).tolist(),
+                           "active": g.num_active, "rules": g.num_rules}
+    with open(os.path.join(OUT, "g7_synth_pins.json"), "w") as f:
+        json.dump(pins, f, indent=1)
+    print("G7", pins["0"])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _install_stubs()
+    gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g7()
