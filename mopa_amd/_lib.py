@@ -1,0 +1,118 @@
+"""ctypes binding of libmopa_hip.so (the C-ABI declared in include/mopa_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+returns a non-zero code, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmopa_hip.so")
+
+_P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+_T = {"p": _P, "i": _I, "l": _L, "z": _Z, "f": _F}
+
+# name -> (restype, argtypes) ; 'p' pointer, 'i' int32, 'l' int64, 'z' size_t, 'f' float
+SIGNATURES = {
+    # ---- geometry (hash3d.hip)
+    "mopa_voxel_hash_workspace_bytes": ("z", "l"),
+    "mopa_voxel_hash_build": ("i", "plpplpppppzp"),
+    "mopa_coarsen_workspace_bytes": ("z", "l"),
+    "mopa_coarsen_build": ("i", "pippplppppzp"),
+    "mopa_rulebook_subm": ("i", "pipplipp"),
+    "mopa_rulebook_updown": ("i", "ppiippp"),
+    "mopa_points_csr_workspace_bytes": ("z", "l"),
+    "mopa_points_csr": ("i", "piipppzp"),
+    # ---- sparse conv (spconv.hip)
+    "mopa_spconv_fwd": ("i", "piipiipiipip"),
+    "mopa_spconv_transpose_weight": ("i", "piiipp"),
+    "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
+    "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
+    # ---- row ops (rows.hip)
+    "mopa_bnrelu_rows_workspace_bytes": ("z", "ii"),
+    "mopa_bnrelu_rows_fwd": ("i", "pipiiippppfffippzp"),
+    "mopa_bnrelu_rows_bwd_workspace_bytes": ("z", "ii"),
+    "mopa_bnrelu_rows_bwd": ("i", "pipipiiipfippiipzp"),
+    "mopa_input_layer_fwd": ("i", "pippipip"),
+    "mopa_input_layer_bwd": ("i", "pippiipp"),
+    "mopa_output_layer_heads_fwd": ("i", "pipiiipppppppp"),
+    "mopa_output_layer_heads_bwd_workspace_bytes": ("z", "iii"),
+    "mopa_output_layer_heads_bwd": ("i", "ppppppppiiiipippppipzp"),
+    # ---- losses (losses.hip)
+    "mopa_loss_workspace_bytes": ("z", "l"),
+    "mopa_softmax_kl_fwd": ("i", "ppiippzp"),
+    "mopa_softmax_kl_bwd": ("i", "ppiippp"),
+    "mopa_wce_fwd": ("i", "pppiilppppzp"),
+    "mopa_wce_bwd": ("i", "pppiilpppp"),
+    "mopa_softmax_fwd": ("i", "plipp"),
+    "mopa_softmax_bwd": ("i", "pplipp"),
+    "mopa_mask_cons_workspace_bytes": ("z", "iii"),
+    "mopa_mask_cons_state_floats": ("z", "ii"),
+    "mopa_mask_cons_fwd": ("i", "ppiiiiipppzp"),
+    "mopa_mask_cons_bwd": ("i", "ppiiiiipppp"),
+    # ---- optimiser (optim.hip)
+    "mopa_adam_flat": ("i", "pppplffffffffp"),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP extension; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"mopa_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mopa_amd/csrc`). There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = _T[res]
+        fn.argtypes = [_T[a] for a in args]
+    _lib = lib
+    return lib
+
+
+def ptr(t, col: int = 0):
+    """Device pointer of a tensor (optionally offset by `col` elements), or NULL."""
+    if t is None:
+        return None
+    return t.data_ptr() + col * t.element_size()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))
+
+
+class _Workspace:
+    """One growing scratch buffer per device; kernels on a stream run in order, so it is shared."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+workspace = _Workspace()

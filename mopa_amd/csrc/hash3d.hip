@@ -1,0 +1,382 @@
+// Voxel hash, active-set construction and rule tables on the GPU.
+//
+// Replaces the host-side hash / rulebook construction of sparseconvnet that the
+// reference reaches through mopa/models/scn_unet.py:26-28 (InputLayer mode 4,
+// SubmanifoldConvolution, scn.UNet's Convolution/Deconvolution) -- SURVEY.md
+// Appendix A.2/A.4/A.5.  Integer work only: results must be bit-exact with
+// oracle/scn3d.py (Geometry).
+//
+// Canonical row order: level-0 rows in first-seen point order (A.2); level l+1
+// rows in first-seen order of the parents of the level-l rows.  It is obtained
+// without sorting: open-addressing insert with atomicMin(first item index) per
+// slot, a flag "I am my voxel's first item", and an exclusive scan of the flags.
+#include "common.h"
+
+#define KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define SCAN_ITEMS 1024  // items per scan block (256 threads x 4)
+
+__device__ __forceinline__ uint64_t mix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+__device__ __forceinline__ int resolve_n(int n_host, const int* n_dev) { return n_dev ? *n_dev : n_host; }
+
+// ---------------------------------------------------------------- key packing
+// key = b<<36 | x<<24 | y<<12 | z  (x,y,z < 4096; collate.py:183-185 gives [x,y,z,b]).
+__global__ void k_pack_keys(const int64_t* __restrict__ coords, int n, uint64_t* __restrict__ keys,
+                            int* __restrict__ status) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int64_t x = coords[4 * (int64_t)i + 0], y = coords[4 * (int64_t)i + 1];
+    int64_t z = coords[4 * (int64_t)i + 2], b = coords[4 * (int64_t)i + 3];
+    if ((uint64_t)x >= 4096 || (uint64_t)y >= 4096 || (uint64_t)z >= 4096 || (uint64_t)b >= (1u << 27)) {
+      atomicOr(status, 1);
+      x &= 4095; y &= 4095; z &= 4095; b &= (1 << 27) - 1;
+    }
+    keys[i] = ((uint64_t)b << 36) | ((uint64_t)x << 24) | ((uint64_t)y << 12) | (uint64_t)z;
+  }
+}
+
+__global__ void k_coarse_keys(const uint64_t* __restrict__ fine, int n_host, const int* n_dev,
+                              uint64_t* __restrict__ coarse) {
+  int n = resolve_n(n_host, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint64_t k = fine[i];
+    // halve x,y,z: clear the low bit of each 12-bit field, then shift the fields right by one.
+    uint64_t xyz = (k & 0xFFFFFFFFFull & ~0x001001001ull) >> 1;
+    coarse[i] = (k & ~0xFFFFFFFFFull) | xyz;
+  }
+}
+
+// ---------------------------------------------------------------- hash insert
+__global__ void k_table_clear(uint64_t* __restrict__ tk, int* __restrict__ tv, int64_t cap) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+    tk[i] = KEY_EMPTY;
+    tv[i] = 0x7FFFFFFF;
+  }
+}
+
+__global__ void k_insert(const uint64_t* __restrict__ keys, int n_host, const int* n_dev,
+                         uint64_t* __restrict__ tk, int* __restrict__ tv, uint32_t mask,
+                         int* __restrict__ slot_of) {
+  int n = resolve_n(n_host, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint64_t key = keys[i];
+    uint32_t s = (uint32_t)mix64(key) & mask;
+    while (true) {
+      unsigned long long prev = atomicCAS((unsigned long long*)&tk[s], (unsigned long long)KEY_EMPTY,
+                                          (unsigned long long)key);
+      if (prev == KEY_EMPTY || prev == key) break;
+      s = (s + 1) & mask;
+    }
+    atomicMin(&tv[s], i);
+    slot_of[i] = (int)s;
+  }
+}
+
+__global__ void k_first_flags(const int* __restrict__ slot_of, const int* __restrict__ tv, int n_host,
+                              const int* n_dev, int* __restrict__ flags) {
+  int n = resolve_n(n_host, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    flags[i] = (tv[slot_of[i]] == i) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- exclusive scan (int32)
+// Three launches: per-block sums, one-block scan of the sums, per-block local scan + offset.
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds /*>=8 ints*/, int* block_total) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int s = lds[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *block_total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const int* __restrict__ in, int n_host, const int* n_dev,
+                                                          int* __restrict__ sums) {
+  int n = resolve_n(n_host, n_dev);
+  int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) s += in[base + k];
+  s = wave_sum_i(s);
+  __shared__ int l[4];
+  if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = l[0] + l[1] + l[2] + l[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_sums(int* __restrict__ sums, int nblocks_cap, int n_host,
+                                                    const int* n_dev, int* __restrict__ total) {
+  int n = resolve_n(n_host, n_dev);
+  int nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+  if (nb > nblocks_cap) nb = nblocks_cap;
+  __shared__ int l[8];
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    int i = b0 + threadIdx.x;
+    int v = i < nb ? sums[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan_256(v, l, &tot);
+    if (i < nb) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_final(const int* __restrict__ in, int n_host, const int* n_dev,
+                                                     const int* __restrict__ sums, int* __restrict__ out) {
+  int n = resolve_n(n_host, n_dev);
+  int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  if (blockIdx.x * SCAN_ITEMS >= n) return;
+  int v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+  }
+  __shared__ int l[8];
+  int tot;
+  int ex = block_exclusive_scan_256(s, l, &tot) + sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+}
+
+static int scan_exclusive(const int* in, int* out, int n_cap, const int* n_dev, int* sums, int* total,
+                          hipStream_t st) {
+  int nb = (int)cdiv64(n_cap > 0 ? n_cap : 1, SCAN_ITEMS);
+  k_scan_block_sums<<<nb, 256, 0, st>>>(in, n_cap, n_dev, sums);
+  k_scan_sums<<<1, 256, 0, st>>>(sums, nb, n_cap, n_dev, total);
+  k_scan_final<<<nb, 256, 0, st>>>(in, n_cap, n_dev, sums, out);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- row assignment
+__global__ void k_assign_rows(const uint64_t* __restrict__ keys, const int* __restrict__ flags,
+                              const int* __restrict__ scan, const int* __restrict__ slot_of, int n_host,
+                              const int* n_dev, int* __restrict__ tv, uint64_t* __restrict__ row_keys) {
+  int n = resolve_n(n_host, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (flags[i]) {
+      int r = scan[i];
+      tv[slot_of[i]] = r;
+      row_keys[r] = keys[i];
+    }
+}
+
+__global__ void k_item_rows(const int* __restrict__ slot_of, const int* __restrict__ tv, int n_host,
+                            const int* n_dev, int* __restrict__ item_row) {
+  int n = resolve_n(n_host, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    item_row[i] = tv[slot_of[i]];
+}
+
+// Shared driver: unique keys in first-seen order.
+//   keys[n] -> table (key -> row), item_row[n], row_keys[num_rows], *num_rows
+// ws layout (ints): slot_of[n_cap] | flags[n_cap] | scan[n_cap] | sums[ceil(n_cap/1024)]
+static size_t unique_ws_bytes(int64_t n_cap) {
+  return align_up((size_t)(3 * n_cap + cdiv64(n_cap, SCAN_ITEMS) + 16) * sizeof(int), 256);
+}
+
+static int unique_first_seen(const uint64_t* keys, int n_cap, const int* n_dev, uint64_t* tk, int* tv,
+                             int64_t cap, int* item_row, uint64_t* row_keys, int* num_rows, void* ws,
+                             hipStream_t st) {
+  if (cap <= 0 || (cap & (cap - 1)) != 0 || cap < 2 * (int64_t)n_cap || cap > (1ll << 31)) return MOPA_ERR_ARG;
+  int* slot_of = (int*)ws;
+  int* flags = slot_of + n_cap;
+  int* scan = flags + n_cap;
+  int* sums = scan + n_cap;
+  int g = stream_grid(n_cap, 256);
+  k_table_clear<<<stream_grid(cap, 256), 256, 0, st>>>(tk, tv, cap);
+  k_insert<<<g, 256, 0, st>>>(keys, n_cap, n_dev, tk, tv, (uint32_t)(cap - 1), slot_of);
+  k_first_flags<<<g, 256, 0, st>>>(slot_of, tv, n_cap, n_dev, flags);
+  int rc = scan_exclusive(flags, scan, n_cap, n_dev, sums, num_rows, st);
+  if (rc) return rc;
+  k_assign_rows<<<g, 256, 0, st>>>(keys, flags, scan, slot_of, n_cap, n_dev, tv, row_keys);
+  k_item_rows<<<g, 256, 0, st>>>(slot_of, tv, n_cap, n_dev, item_row);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ---------------------------------------------------------------- C-ABI: level 0
+MOPA_API size_t mopa_voxel_hash_workspace_bytes(int64_t n_points) {
+  return align_up((size_t)n_points * sizeof(uint64_t), 256) + unique_ws_bytes(n_points);
+}
+
+// coords [N,4] int64 (x,y,z,batch) on the device.  status: bit0 set if a coordinate was out of range.
+MOPA_API int mopa_voxel_hash_build(const int64_t* coords, int64_t n_points, uint64_t* table_keys,
+                                   int32_t* table_vals, int64_t table_cap, int32_t* point_row,
+                                   uint64_t* row_keys, int32_t* num_rows, int32_t* status, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  if (n_points <= 0 || n_points > (1 << 30)) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_voxel_hash_workspace_bytes(n_points)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t* keys = (uint64_t*)ws;
+  void* uws = (char*)ws + align_up((size_t)n_points * sizeof(uint64_t), 256);
+  k_pack_keys<<<stream_grid(n_points, 256), 256, 0, st>>>(coords, (int)n_points, keys, status);
+  return unique_first_seen(keys, (int)n_points, nullptr, table_keys, table_vals, table_cap, point_row, row_keys,
+                           num_rows, uws, st);
+}
+
+// ---------------------------------------------------------------- C-ABI: level l -> l+1
+MOPA_API size_t mopa_coarsen_workspace_bytes(int64_t n_fine_cap) { return mopa_voxel_hash_workspace_bytes(n_fine_cap); }
+
+// fine_keys[*n_fine] -> coarse table, parent[*n_fine], coarse_keys[*num_coarse].  n_fine is read on the device
+// so that all levels can be chained without a host sync; n_fine_cap bounds it (grid + buffer sizes).
+MOPA_API int mopa_coarsen_build(const uint64_t* fine_keys, int32_t n_fine_cap, const int32_t* n_fine_dev,
+                                uint64_t* table_keys, int32_t* table_vals, int64_t table_cap, int32_t* parent,
+                                uint64_t* coarse_keys, int32_t* num_coarse, void* ws, size_t ws_bytes,
+                                void* stream) {
+  if (n_fine_cap <= 0) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_coarsen_workspace_bytes(n_fine_cap)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t* keys = (uint64_t*)ws;
+  void* uws = (char*)ws + align_up((size_t)n_fine_cap * sizeof(uint64_t), 256);
+  k_coarse_keys<<<stream_grid(n_fine_cap, 256), 256, 0, st>>>(fine_keys, n_fine_cap, n_fine_dev, keys);
+  return unique_first_seen(keys, n_fine_cap, n_fine_dev, table_keys, table_vals, table_cap, parent, coarse_keys,
+                           num_coarse, uws, st);
+}
+
+// ---------------------------------------------------------------- rule tables
+__device__ __forceinline__ int table_lookup(const uint64_t* __restrict__ tk, const int* __restrict__ tv,
+                                            uint32_t mask, uint64_t key) {
+  uint32_t s = (uint32_t)mix64(key) & mask;
+  while (true) {
+    uint64_t k = tk[s];
+    if (k == key) return tv[s];
+    if (k == KEY_EMPTY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// nbr[o][i] = row of voxel at pos(i) + off(o), o = (dx+1)*9 + (dy+1)*3 + (dz+1)  (A.4), or -1.
+__global__ __launch_bounds__(256) void k_rulebook_subm(const uint64_t* __restrict__ row_keys, int A,
+                                                        const uint64_t* __restrict__ tk, const int* __restrict__ tv,
+                                                        uint32_t mask, int size, int* __restrict__ nbr) {
+  int64_t total = (int64_t)A * 27;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int o = (int)(t / A), i = (int)(t - (int64_t)o * A);
+    int r;
+    if (o == 13) {
+      r = i;
+    } else {
+      uint64_t k = row_keys[i];
+      int x = (int)((k >> 24) & 4095) + o / 9 - 1;
+      int y = (int)((k >> 12) & 4095) + (o / 3) % 3 - 1;
+      int z = (int)(k & 4095) + o % 3 - 1;
+      if ((unsigned)x >= (unsigned)size || (unsigned)y >= (unsigned)size || (unsigned)z >= (unsigned)size) {
+        r = -1;
+      } else {
+        uint64_t q = (k & ~0xFFFFFFFFFull) | ((uint64_t)x << 24) | ((uint64_t)y << 12) | (uint64_t)z;
+        r = table_lookup(tk, tv, mask, q);
+      }
+    }
+    nbr[t] = r;
+  }
+}
+
+MOPA_API int mopa_rulebook_subm(const uint64_t* row_keys, int32_t num_rows, const uint64_t* table_keys,
+                                const int32_t* table_vals, int64_t table_cap, int32_t spatial_size,
+                                int32_t* nbr /*[27][num_rows]*/, void* stream) {
+  if (num_rows <= 0 || (table_cap & (table_cap - 1)) != 0) return MOPA_ERR_ARG;
+  k_rulebook_subm<<<stream_grid((int64_t)num_rows * 27, 256), 256, 0, (hipStream_t)stream>>>(
+      row_keys, num_rows, table_keys, table_vals, (uint32_t)(table_cap - 1), spatial_size, nbr);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ch[o][q] = fine row that is child o of coarse row q (or -1); up[o][p] = parent(p) iff octant(p)==o else -1.
+// o = (x&1)*4 + (y&1)*2 + (z&1)  (A.5).
+__global__ void k_fill_i32(int* __restrict__ p, int64_t n, int v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_rulebook_updown(const uint64_t* __restrict__ fine_keys, const int* __restrict__ parent, int A_f,
+                                  int A_c, int* __restrict__ ch, int* __restrict__ up) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < A_f; p += gridDim.x * blockDim.x) {
+    uint64_t k = fine_keys[p];
+    int o = (int)(((k >> 24) & 1) * 4 + ((k >> 12) & 1) * 2 + (k & 1));
+    int q = parent[p];
+    ch[(int64_t)o * A_c + q] = p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) up[(int64_t)j * A_f + p] = (j == o) ? q : -1;
+  }
+}
+
+MOPA_API int mopa_rulebook_updown(const uint64_t* fine_keys, const int32_t* parent, int32_t num_fine,
+                                  int32_t num_coarse, int32_t* ch /*[8][num_coarse]*/,
+                                  int32_t* up /*[8][num_fine]*/, void* stream) {
+  if (num_fine <= 0 || num_coarse <= 0) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  k_fill_i32<<<stream_grid((int64_t)num_coarse * 8, 256), 256, 0, st>>>(ch, (int64_t)num_coarse * 8, -1);
+  k_rulebook_updown<<<stream_grid(num_fine, 256), 256, 0, st>>>(fine_keys, parent, num_fine, num_coarse, ch, up);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ---------------------------------------------------------------- CSR of points per voxel row
+// row_start[A+1], row_points[N]: points of each row in increasing point index (deterministic sums).
+__global__ void k_count_rows(const int* __restrict__ item_row, int n, int* __restrict__ cnt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&cnt[item_row[i]], 1);
+}
+__global__ void k_fill_rows(const int* __restrict__ item_row, int n, const int* __restrict__ row_start,
+                            int* __restrict__ cursor, int* __restrict__ row_items) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int r = item_row[i];
+    row_items[row_start[r] + atomicAdd(&cursor[r], 1)] = i;
+  }
+}
+__global__ void k_sort_rows(const int* __restrict__ row_start, int A, int n, int* __restrict__ row_items) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < A; r += gridDim.x * blockDim.x) {
+    int s = row_start[r], e = (r + 1 < A) ? row_start[r + 1] : n;
+    for (int a = s + 1; a < e; ++a) {  // insertion sort: rows hold a handful of points
+      int v = row_items[a], b = a - 1;
+      while (b >= s && row_items[b] > v) { row_items[b + 1] = row_items[b]; --b; }
+      row_items[b + 1] = v;
+    }
+  }
+}
+__global__ void k_set_last(int* row_start, int A, int n) { row_start[A] = n; }
+
+MOPA_API size_t mopa_points_csr_workspace_bytes(int64_t num_rows) {
+  return align_up((size_t)(2 * num_rows + cdiv64(num_rows, SCAN_ITEMS) + 32) * sizeof(int), 256);
+}
+
+MOPA_API int mopa_points_csr(const int32_t* point_row, int32_t n_points, int32_t num_rows,
+                             int32_t* row_start /*[num_rows+1]*/, int32_t* row_points /*[n_points]*/, void* ws,
+                             size_t ws_bytes, void* stream) {
+  if (n_points <= 0 || num_rows <= 0) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_points_csr_workspace_bytes(num_rows)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = (int*)ws;
+  int* cursor = cnt + num_rows;
+  int* sums = cursor + num_rows;
+  int* total = sums + cdiv64(num_rows, SCAN_ITEMS) + 8;
+  if (hipMemsetAsync(cnt, 0, (size_t)2 * num_rows * sizeof(int), st) != hipSuccess) return MOPA_ERR_LAUNCH;
+  int g = stream_grid(n_points, 256);
+  k_count_rows<<<g, 256, 0, st>>>(point_row, n_points, cnt);
+  int rc = scan_exclusive(cnt, row_start, num_rows, nullptr, sums, total, st);
+  if (rc) return rc;
+  k_set_last<<<1, 1, 0, st>>>(row_start, num_rows, n_points);
+  k_fill_rows<<<g, 256, 0, st>>>(point_row, n_points, row_start, cursor, row_points);
+  k_sort_rows<<<stream_grid(num_rows, 256), 256, 0, st>>>(row_start, num_rows, n_points, row_points);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

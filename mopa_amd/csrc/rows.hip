@@ -1,0 +1,423 @@
+// Row-wise ops of the sparse 3D branch: BatchNorm(+Leaky)ReLU over active rows, InputLayer (mode 4),
+// OutputLayer fused with the two linear heads.  HBM-bound elementwise / reduction kernels: float4 access,
+// wave-shuffle + LDS reductions, two-stage (partials -> finalize) so results are deterministic.
+//
+// Reference call sites: mopa/models/scn_unet.py:26 (InputLayer), :28-29 (BatchNormReLU inside scn.UNet and
+// after it), :30 (OutputLayer); mopa/models/xmuda_arch.py:102,107,116,124 (linear heads).
+// Semantics: SURVEY.md Appendix A.2, A.3, A.6; oracle: oracle/scn3d.py::{input_layer,output_layer,bn_relu}.
+#include "common.h"
+
+#define BN_ROWS_PER_BLOCK 1024
+
+// ------------------------------------------------------------------------------------------ BN statistics
+// partial[blk][0][c] = sum(x - x0), partial[blk][1][c] = sum((x - x0)^2) with x0 = first row (shifted sums keep
+// fp32 accurate when |mean| >> std).  C % 4 == 0.
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int ld, int A, int C,
+                                                           float* __restrict__ partial) {
+  extern __shared__ float lds[];  // [2][RL][C]
+  const int CQ = C >> 2;
+  const int RL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const int rbeg = blockIdx.x * BN_ROWS_PER_BLOCK, rend = min(A, rbeg + BN_ROWS_PER_BLOCK);
+  float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    const float4 k = *reinterpret_cast<const float4*>(x + cq * 4);
+    for (int row = rbeg + rl; row < rend; row += RL) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ld + cq * 4);
+      float d0 = v.x - k.x, d1 = v.y - k.y, d2 = v.z - k.z, d3 = v.w - k.w;
+      s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
+      ss[0] += d0 * d0; ss[1] += d1 * d1; ss[2] += d2 * d2; ss[3] += d3 * d3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lds[(0 * RL + rl) * C + cq * 4 + j] = s[j];
+      lds[(1 * RL + rl) * C + cq * 4 + j] = ss[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float t = 0.f;
+    for (int k = 0; k < RL; ++k) t += lds[(which * RL + k) * C + c];
+    partial[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// One block; thread per channel.  Writes scale/shift (y = x*scale + shift), mean, invstd; updates running stats.
+__global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, const float* __restrict__ x0, int A, int C,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                              float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
+                              float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mean, var;
+    if (training) {
+      double s = 0.0, ss = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[(int64_t)b * 2 * C + c];
+        ss += (double)partial[(int64_t)b * 2 * C + C + c];
+      }
+      const double m = s / A;
+      double v = ss / A - m * m;
+      if (v < 0) v = 0;
+      mean = (float)((double)x0[c] + m);
+      var = (float)v;
+      const float unbiased = (float)(v * ((double)A / (double)(A > 1 ? A - 1 : 1)));
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                        int ldy, int A, int C, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float leak) {
+  const int CQ = C >> 2;
+  const int64_t total = (int64_t)A * CQ;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
+    const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    o.x = o.x > 0.f ? o.x : o.x * leak; o.y = o.y > 0.f ? o.y : o.y * leak;
+    o.z = o.z > 0.f ? o.z : o.z * leak; o.w = o.w > 0.f ? o.w : o.w * leak;
+    *reinterpret_cast<float4*>(y + (int64_t)row * ldy + cq * 4) = o;
+  }
+}
+
+MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
+  return align_up((size_t)cdiv64(num_rows, BN_ROWS_PER_BLOCK) * 2 * C * sizeof(float), 256);
+}
+
+// y = leaky_relu(batchnorm(x)).  stats[4][C] receives scale, shift, mean, invstd (saved for backward).
+MOPA_API int mopa_bnrelu_rows_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, float leak, int32_t training, float* stats, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
+  float* partial = (float*)ws;
+  if (training) {
+    if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+    const int RL = 256 / (C >> 2);
+    if (RL < 1) return MOPA_ERR_ARG;
+    k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, partial);
+  }
+  k_bn_finalize<<<1, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
+                                   eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
+  k_bn_relu_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
+                                                                                  stats + C, leak);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ BN backward
+// dz = dy * (y > 0 ? 1 : leak) with y recomputed from x; partial sums of dz and dz*xhat.
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, int ld_dy,
+                                                         const float* __restrict__ x, int ldx, int A, int C,
+                                                         const float* __restrict__ stats, float leak,
+                                                         float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int CQ = C >> 2;
+  const int RL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const int rbeg = blockIdx.x * BN_ROWS_PER_BLOCK, rend = min(A, rbeg + BN_ROWS_PER_BLOCK);
+  float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = stats[cq * 4 + j]; sh[j] = stats[C + cq * 4 + j];
+      mu[j] = stats[2 * C + cq * 4 + j]; is[j] = stats[3 * C + cq * 4 + j];
+    }
+    for (int row = rbeg + rl; row < rend; row += RL) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
+      const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float yv = fmaf(xs[j], sc[j], sh[j]);
+        const float dz = yv > 0.f ? gs[j] : gs[j] * leak;
+        s[j] += dz;
+        ss[j] += dz * ((xs[j] - mu[j]) * is[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lds[(0 * RL + rl) * C + cq * 4 + j] = s[j];
+      lds[(1 * RL + rl) * C + cq * 4 + j] = ss[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float t = 0.f;
+    for (int k = 0; k < RL; ++k) t += lds[(which * RL + k) * C + c];
+    partial[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// dgamma/dbeta (+= if accumulate) and the two per-channel means used by the apply pass (coef[2][C]).
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int A, int C, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s += (double)partial[(int64_t)b * 2 * C + c];
+      ss += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+    coef[c] = (float)(s / A);
+    coef[C + c] = (float)(ss / A);
+  }
+}
+
+// training: dx = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = scale * dz.   dx (+)= if acc_dx.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x,
+                                                       int ldx, float* __restrict__ dx, int ld_dx, int A, int C,
+                                                       const float* __restrict__ stats, const float* __restrict__ coef,
+                                                       float leak, int training, int acc_dx) {
+  const int CQ = C >> 2;
+  const int64_t total = (int64_t)A * CQ;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
+    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cq * 4 + j;
+      const float sc = stats[c], sh = stats[C + c];
+      const float yv = fmaf(xs[j], sc, sh);
+      const float dz = yv > 0.f ? gs[j] : gs[j] * leak;
+      if (training) {
+        const float xhat = (xs[j] - stats[2 * C + c]) * stats[3 * C + c];
+        o[j] = sc * (dz - coef[c] - xhat * coef[C + c]);
+      } else {
+        o[j] = sc * dz;
+      }
+    }
+    float4* dp = reinterpret_cast<float4*>(dx + (int64_t)row * ld_dx + cq * 4);
+    if (acc_dx) {
+      const float4 p = *dp;
+      o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
+    }
+    *dp = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+MOPA_API int mopa_bnrelu_rows_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
+                                  int32_t num_rows, int32_t C, const float* stats, float leak, int32_t training,
+                                  float* dgamma, float* dbeta, int32_t accumulate_param_grads, int32_t accumulate_dx,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3))
+    return MOPA_ERR_ARG;
+  const size_t need = mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
+  if (ws_bytes < need) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
+  float* partial = (float*)ws;
+  float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
+  const int RL = 256 / (C >> 2);
+  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, partial);
+  k_bn_bwd_finalize<<<1, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
+  k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C,
+                                                                                 stats, coef, leak, training, accumulate_dx);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+MOPA_API size_t mopa_bnrelu_rows_bwd_workspace_bytes(int32_t num_rows, int32_t C) {
+  return mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+// ------------------------------------------------------------------------------------------ InputLayer mode 4
+// out[row][c] = mean over the row's points (increasing point index) of feats[p][c]; columns [cin, ld) zero-filled.
+__global__ void k_input_layer_fwd(const float* __restrict__ feats, int cin, const int* __restrict__ row_start,
+                                  const int* __restrict__ row_points, int A, float* __restrict__ out, int ld) {
+  const int64_t total = (int64_t)A * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / ld), c = (int)(i - (int64_t)row * ld);
+    float v = 0.f;
+    if (c < cin) {
+      const int s = row_start[row], e = row_start[row + 1];
+      for (int k = s; k < e; ++k) v += feats[(int64_t)row_points[k] * cin + c];
+      v /= (float)(e - s);
+    }
+    out[i] = v;
+  }
+}
+
+MOPA_API int mopa_input_layer_fwd(const float* feats, int32_t cin, const int32_t* row_start, const int32_t* row_points,
+                                  int32_t num_rows, float* out, int32_t ld_out, void* stream) {
+  if (cin <= 0 || num_rows <= 0 || ld_out < cin) return MOPA_ERR_ARG;
+  k_input_layer_fwd<<<stream_grid((int64_t)num_rows * ld_out, 256), 256, 0, (hipStream_t)stream>>>(
+      feats, cin, row_start, row_points, num_rows, out, ld_out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// dfeats[p][c] = dout[row(p)][c] / count(row(p))
+__global__ void k_input_layer_bwd(const float* __restrict__ dout, int ld, const int* __restrict__ point_row,
+                                  const int* __restrict__ row_start, int N, int cin, float* __restrict__ dfeats) {
+  const int64_t total = (int64_t)N * cin;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / cin), c = (int)(i - (int64_t)p * cin);
+    const int row = point_row[p];
+    dfeats[i] = dout[(int64_t)row * ld + c] / (float)(row_start[row + 1] - row_start[row]);
+  }
+}
+
+MOPA_API int mopa_input_layer_bwd(const float* dout, int32_t ld_dout, const int32_t* point_row, const int32_t* row_start,
+                                  int32_t n_points, int32_t cin, float* dfeats, void* stream) {
+  if (cin <= 0 || n_points <= 0 || ld_dout < cin) return MOPA_ERR_ARG;
+  k_input_layer_bwd<<<stream_grid((int64_t)n_points * cin, 256), 256, 0, (hipStream_t)stream>>>(
+      dout, ld_dout, point_row, row_start, n_points, cin, dfeats);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ OutputLayer + heads
+// feats[p] = y[point_row[p]] (A.3);  logit_h[p] = feats[p] @ W_h^T + b_h for h = 1,2 (xmuda_arch.py:116,124).
+// 16 lanes per point (lane = feature channel group); M = feature width (multiple of 4, <= 64), NC <= 32 classes.
+__global__ __launch_bounds__(256) void k_output_heads_fwd(const float* __restrict__ y, int ld, const int* __restrict__ point_row,
+                                                           int N, int M, int NC, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, float* __restrict__ feats,
+                                                           float* __restrict__ logit1, float* __restrict__ logit2) {
+  extern __shared__ float lw[];  // w1[NC][M] | b1[NC] | w2[NC][M] | b2[NC]
+  const int nw = NC * M;
+  for (int i = threadIdx.x; i < nw; i += 256) { lw[i] = w1[i]; if (w2) lw[nw + NC + i] = w2[i]; }
+  for (int i = threadIdx.x; i < NC; i += 256) { lw[nw + i] = b1[i]; if (w2) lw[2 * nw + NC + i] = b2[i]; }
+  __syncthreads();
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+    const float* __restrict__ src = y + (int64_t)point_row[p] * ld;
+    for (int c = 0; c < M; c += 4)
+      *reinterpret_cast<float4*>(feats + (int64_t)p * M + c) = *reinterpret_cast<const float4*>(src + c);
+    for (int k = 0; k < NC; ++k) {
+      float a1 = lw[nw + k], a2 = w2 ? lw[2 * nw + NC + k] : 0.f;
+      for (int c = 0; c < M; ++c) {
+        const float fv = src[c];  // L1-resident row
+        a1 = fmaf(fv, lw[k * M + c], a1);
+        if (w2) a2 = fmaf(fv, lw[nw + NC + k * M + c], a2);
+      }
+      logit1[(int64_t)p * NC + k] = a1;
+      if (w2) logit2[(int64_t)p * NC + k] = a2;
+    }
+  }
+}
+
+MOPA_API int mopa_output_layer_heads_fwd(const float* y, int32_t ld_y, const int32_t* point_row, int32_t n_points,
+                                         int32_t M, int32_t num_classes, const float* w1, const float* b1,
+                                         const float* w2, const float* b2, float* feats, float* logit1, float* logit2,
+                                         void* stream) {
+  if (n_points <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > 64 || ld_y < M || (ld_y & 3))
+    return MOPA_ERR_ARG;
+  const size_t sh = (size_t)(2 * num_classes * M + 2 * num_classes) * sizeof(float);
+  k_output_heads_fwd<<<stream_grid(n_points, 256), 256, sh, (hipStream_t)stream>>>(
+      y, ld_y, point_row, n_points, M, num_classes, w1, b1, w2, b2, feats, logit1, logit2);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// Backward to the voxel rows: dy[row][c] = sum_{p in row} ( dfeats[p][c] + sum_k dl1[p][k] W1[k][c] + dl2[p][k] W2[k][c] ).
+// Any of dfeats / dl1 / dl2 may be null.  Deterministic: points of a row are visited in increasing index (CSR).
+__global__ __launch_bounds__(256) void k_output_heads_bwd_rows(const float* __restrict__ dfeats, const float* __restrict__ dl1,
+                                                                const float* __restrict__ dl2, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, const int* __restrict__ row_start,
+                                                                const int* __restrict__ row_points, int A, int M, int NC,
+                                                                float* __restrict__ dy, int ld) {
+  extern __shared__ float lw[];  // w1[NC][M] | w2[NC][M]
+  const int nw = NC * M;
+  for (int i = threadIdx.x; i < nw; i += 256) { lw[i] = w1[i]; lw[nw + i] = w2 ? w2[i] : 0.f; }
+  __syncthreads();
+  const int64_t total = (int64_t)A * M;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / M), c = (int)(i - (int64_t)row * M);
+    float acc = 0.f;
+    for (int k = row_start[row]; k < row_start[row + 1]; ++k) {
+      const int p = row_points[k];
+      float v = dfeats ? dfeats[(int64_t)p * M + c] : 0.f;
+      if (dl1) for (int j = 0; j < NC; ++j) v = fmaf(dl1[(int64_t)p * NC + j], lw[j * M + c], v);
+      if (dl2) for (int j = 0; j < NC; ++j) v = fmaf(dl2[(int64_t)p * NC + j], lw[nw + j * M + c], v);
+      acc += v;
+    }
+    dy[(int64_t)row * ld + c] = acc;
+  }
+}
+
+// Head parameter grads: dW[k][c] = sum_p dl[p][k] * feats[p][c], db[k] = sum_p dl[p][k]; block partials then reduce.
+#define HEAD_PTS_PER_BLOCK 2048
+__global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restrict__ dl, const float* __restrict__ feats, int N,
+                                                             int M, int NC, float* __restrict__ partial) {
+  // thread = (class k, channel c) pairs strided; each thread loops over the block's points (L1-friendly: all threads
+  // read the same point rows).
+  const int pbeg = blockIdx.x * HEAD_PTS_PER_BLOCK, pend = min(N, pbeg + HEAD_PTS_PER_BLOCK);
+  const int nout = NC * (M + 1);
+  for (int i = threadIdx.x; i < nout; i += 256) {
+    const int k = i / (M + 1), c = i - k * (M + 1);
+    float acc = 0.f;
+    if (c < M) {
+      for (int p = pbeg; p < pend; ++p) acc = fmaf(dl[(int64_t)p * NC + k], feats[(int64_t)p * M + c], acc);
+    } else {
+      for (int p = pbeg; p < pend; ++p) acc += dl[(int64_t)p * NC + k];
+    }
+    partial[(int64_t)blockIdx.x * nout + i] = acc;
+  }
+}
+__global__ void k_head_wgrad_reduce(const float* __restrict__ partial, int nblk, int M, int NC, float* __restrict__ dw,
+                                    float* __restrict__ db, int accumulate) {
+  const int nout = NC * (M + 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * nout + i];
+    const int k = i / (M + 1), c = i - k * (M + 1);
+    float* dst = (c < M) ? &dw[k * M + c] : &db[k];
+    *dst = (accumulate ? *dst : 0.f) + (float)s;
+  }
+}
+
+MOPA_API size_t mopa_output_layer_heads_bwd_workspace_bytes(int32_t n_points, int32_t M, int32_t num_classes) {
+  return align_up((size_t)cdiv64(n_points, HEAD_PTS_PER_BLOCK) * num_classes * (M + 1) * sizeof(float), 256);
+}
+
+// feats: the forward's per-point features (N,M).  dfeats/dl1/dl2 may be null (no upstream grad on that output).
+MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, const float* dl2, const float* feats,
+                                         const float* w1, const float* w2, const int32_t* row_start,
+                                         const int32_t* row_points, int32_t num_rows, int32_t n_points, int32_t M,
+                                         int32_t num_classes, float* dy, int32_t ld_dy, float* dw1, float* db1,
+                                         float* dw2, float* db2, int32_t accumulate, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || num_classes <= 0 || num_classes > 64 || ld_dy < M)
+    return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_output_layer_heads_bwd_workspace_bytes(n_points, M, num_classes)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  k_output_heads_bwd_rows<<<stream_grid((int64_t)num_rows * M, 256), 256, (size_t)2 * num_classes * M * sizeof(float), st>>>(
+      dfeats, dl1, dl2, w1, w2, row_start, row_points, num_rows, M, num_classes, dy, ld_dy);
+  const int nblk = (int)cdiv64(n_points, HEAD_PTS_PER_BLOCK);
+  float* partial = (float*)ws;
+  if (dl1 && dw1) {
+    k_head_wgrad_partial<<<nblk, 256, 0, st>>>(dl1, feats, n_points, M, num_classes, partial);
+    k_head_wgrad_reduce<<<1, 256, 0, st>>>(partial, nblk, M, num_classes, dw1, db1, accumulate);
+  }
+  if (dl2 && dw2) {
+    k_head_wgrad_partial<<<nblk, 256, 0, st>>>(dl2, feats, n_points, M, num_classes, partial);
+    k_head_wgrad_reduce<<<1, 256, 0, st>>>(partial, nblk, M, num_classes, dw2, db2, accumulate);
+  }
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

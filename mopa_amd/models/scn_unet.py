@@ -1,0 +1,86 @@
+"""UNetSCN: the SparseConvNet 3D backbone, MI355X-native.
+
+Drop-in for ``mopa/models/scn_unet.py:9-34`` (same constructor arguments and
+``out_channels`` attribute).  Parameters live in nested containers whose names
+reproduce scn.Sequential's index naming, e.g.
+``sparseModel.2.1.1.1.weight``, so ``state_dict()`` keys line up with checkpoints.
+Weights are ``(K, Cin, Cout)`` with K = 27 (submanifold) or 8 (stride-2 conv/deconv).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import sparse3d
+
+DIMENSION = 3
+
+
+class _Slot(nn.Module):
+    """Index-named container (stands in for scn.Sequential / ConcatTable nodes)."""
+
+    def put(self, idx, child):
+        self.add_module(str(idx), child)
+        return child
+
+
+class _SparseConvParams(nn.Module):
+    def __init__(self, K, n_in, n_out):
+        super().__init__()
+        # SCN init: normal(0, sqrt(2 / (nIn * filter_volume)))  (Appendix A.4/A.5)
+        self.weight = nn.Parameter(torch.randn(K, n_in, n_out) * math.sqrt(2.0 / (n_in * K)))
+
+
+class _BNParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+
+
+class UNetSCN(nn.Module):
+    def __init__(self, in_channels, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7,
+                 pretrained=False):
+        super().__init__()
+        if residual_blocks:
+            raise NotImplementedError("residual_blocks=True is not on the shipped hot path (config/xmuda.py:220)")
+        if m % 16 != 0:
+            raise NotImplementedError("m must be a multiple of 16 (MFMA tile width); the reference ships m=16")
+        self.in_channels, self.out_channels = in_channels, m
+        self.m, self.block_reps, self.full_scale, self.num_planes = m, block_reps, full_scale, num_planes
+        planes = [(i + 1) * m for i in range(num_planes)]
+        sm = self.sparseModel = _Slot()
+        sm.put(1, _SparseConvParams(27, in_channels, m))
+
+        def U(node, pl):
+            idx = 0
+            for _ in range(block_reps):
+                blk = node.put(idx, _Slot())
+                blk.put(0, _BNParams(pl[0]))
+                blk.put(1, _SparseConvParams(27, pl[0], pl[0]))
+                idx += 1
+            if len(pl) > 1:
+                seq = node.put(idx, _Slot()).put(1, _Slot())
+                seq.put(0, _BNParams(pl[0]))
+                seq.put(1, _SparseConvParams(8, pl[0], pl[1]))
+                U(seq.put(2, _Slot()), pl[1:])
+                seq.put(3, _BNParams(pl[1]))
+                seq.put(4, _SparseConvParams(8, pl[1], pl[0]))
+                idx += 2
+                for i in range(block_reps):
+                    a = pl[0] * (2 if i == 0 else 1)
+                    blk = node.put(idx, _Slot())
+                    blk.put(0, _BNParams(a))
+                    blk.put(1, _SparseConvParams(27, a, pl[0]))
+                    idx += 1
+
+        U(sm.put(2, _Slot()), planes)
+        sm.put(3, _BNParams(m))
+
+    def geometry(self, locs) -> sparse3d.Geometry3D:
+        dev = next(self.parameters()).device
+        return sparse3d.Geometry3D(locs, self.num_planes, self.full_scale, dev)

@@ -1,0 +1,351 @@
+"""Host side of the sparse 3D branch: device geometry (hash + rule tables) and the
+UNetSCN forward/backward schedule over the C-ABI kernels of libmopa_hip.so.
+
+What it replaces: the ``sparseconvnet`` calls behind ``mopa/models/scn_unet.py:25-34``
+(InputLayer -> SubMConv -> scn.UNet -> BatchNormReLU -> OutputLayer) plus the two
+``nn.Linear`` heads of ``mopa/models/xmuda_arch.py:114-126``.  Semantics: SURVEY.md
+Appendix A; oracle: ``oracle/scn3d.py``.
+
+PyTorch here is plumbing only (device buffers, streams, autograd hand-off): every
+arithmetic step is a HIP kernel.  The whole network is ONE autograd node so that
+JoinTable is free (layers write channel slices of a shared wide buffer) and no
+per-layer Python autograd overhead is paid.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, query, stream, workspace
+
+BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
+BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
+LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
+
+
+def _ws(nbytes, device):
+    return workspace.get(max(int(nbytes), 256), device)
+
+
+def _pow2_at_least(n):
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
+# --------------------------------------------------------------------------------------- geometry
+class Geometry3D:
+    """Active sets + rule tables of one batch on the device (bit-exact with oracle.scn3d.Geometry).
+
+    Built in two phases: (A) all levels' hashes/active sets chained on the device with
+    worst-case buffers, (B) ONE host sync to read the 7 row counts, then exact-size rule tables.
+    """
+
+    def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None):
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise RuntimeError(f"coords must be (N,4) [x,y,z,batch], got {tuple(coords.shape)}")
+        device = torch.device(device if device is not None else "cuda")
+        N = int(coords.shape[0])
+        if N == 0:
+            raise RuntimeError("empty point cloud")
+        coords = coords.to(torch.int64)
+        if coords.device.type == "cpu":
+            coords = coords.contiguous().pin_memory().to(device, non_blocking=True)
+        else:
+            coords = coords.to(device).contiguous()
+        self.device, self.n_points, self.num_levels = device, N, num_levels
+        L = num_levels
+        cap = _pow2_at_least(2 * N)
+        i64 = dict(dtype=torch.int64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        keys = [torch.empty(N, **i64) for _ in range(L)]
+        tk = [torch.empty(cap, **i64) for _ in range(L)]
+        tv = [torch.empty(cap, **i32) for _ in range(L)]
+        item_row = [torch.empty(N, **i32) for _ in range(L)]  # [0]: point->row0 ; [l>0]: parent of level l-1 rows
+        meta = torch.zeros(L + 1, **i32)                       # counts[0..L-1], status
+        wsb = query("mopa_voxel_hash_workspace_bytes", N)
+        ws = _ws(wsb, device)
+        st = stream()
+        call("mopa_voxel_hash_build", ptr(coords), N, ptr(tk[0]), ptr(tv[0]), cap, ptr(item_row[0]), ptr(keys[0]),
+             ptr(meta), ptr(meta, L), ptr(ws), ws.numel(), st)
+        for l in range(L - 1):
+            call("mopa_coarsen_build", ptr(keys[l]), N, ptr(meta, l), ptr(tk[l + 1]), ptr(tv[l + 1]), cap,
+                 ptr(item_row[l + 1]), ptr(keys[l + 1]), ptr(meta, l + 1), ptr(ws), ws.numel(), st)
+        m = meta.cpu().tolist()  # the one host sync of the geometry build
+        if m[L] != 0:
+            raise RuntimeError("voxel coordinates out of range: need 0 <= x,y,z < 4096 and batch >= 0")
+        self.num_active = m[:L]
+        A = self.num_active
+        self.point_row = item_row[0]
+        self.row_keys = [keys[l][:A[l]] for l in range(L)]
+        self.parent = [item_row[l + 1][:A[l]] for l in range(L - 1)]
+        self.nbr27, self.ch, self.up = [], [], []
+        for l in range(L):
+            nbr = torch.empty(27, A[l], **i32)
+            call("mopa_rulebook_subm", ptr(keys[l]), A[l], ptr(tk[l]), ptr(tv[l]), cap, full_scale >> l, ptr(nbr), st)
+            self.nbr27.append(nbr)
+        for l in range(L - 1):
+            ch = torch.empty(8, A[l + 1], **i32)
+            up = torch.empty(8, A[l], **i32)
+            call("mopa_rulebook_updown", ptr(keys[l]), ptr(item_row[l + 1]), A[l], A[l + 1], ptr(ch), ptr(up), st)
+            self.ch.append(ch)
+            self.up.append(up)
+        self.row_start = torch.empty(A[0] + 1, **i32)
+        self.row_points = torch.empty(N, **i32)
+        wsb = query("mopa_points_csr_workspace_bytes", A[0])
+        ws = _ws(wsb, device)
+        call("mopa_points_csr", ptr(self.point_row), N, A[0], ptr(self.row_start), ptr(self.row_points), ptr(ws),
+             ws.numel(), st)
+
+    @property
+    def num_rules(self):
+        return [int((n >= 0).sum().item()) for n in self.nbr27]
+
+
+# --------------------------------------------------------------------------------------- kernels (thin wrappers)
+class View:
+    """A [rows, C] fp32 activation living in columns [col, col+C) of a wider row-major buffer."""
+
+    __slots__ = ("t", "col", "C")
+
+    def __init__(self, t: torch.Tensor, col: int = 0, C: int | None = None):
+        self.t, self.col, self.C = t, col, (t.shape[1] - col if C is None else C)
+
+    @property
+    def rows(self):
+        return self.t.shape[0]
+
+    @property
+    def ld(self):
+        return self.t.shape[1]
+
+    @property
+    def p(self):
+        return ptr(self.t, self.col)
+
+    def dense(self):
+        return self.t[:, self.col:self.col + self.C]
+
+
+def new_view(rows, C, device, ld=None):
+    return View(torch.empty(rows, ld or C, dtype=torch.float32, device=device), 0, C)
+
+
+def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False):
+    K, A_out = nbr.shape
+    assert out.rows == A_out and w.shape == (K, x.C, out.C), (nbr.shape, x.C, out.C, w.shape)
+    call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, x.C, ptr(w), out.C, int(w_flip), out.p, out.ld, stream())
+
+
+def spconv_transpose_weight(w: torch.Tensor) -> torch.Tensor:
+    K, cin, cout = w.shape
+    wt = torch.empty(K, cout, cin, dtype=w.dtype, device=w.device)
+    call("mopa_spconv_transpose_weight", ptr(w), K, cin, cout, ptr(wt), stream())
+    return wt
+
+
+def spconv_bwd_weight(nbr: torch.Tensor, x: View, dout: View, dw: torch.Tensor, accumulate: bool = False):
+    K, A_out = nbr.shape
+    assert dw.shape == (K, x.C, dout.C) and dout.rows == A_out
+    wsb = query("mopa_spconv_wgrad_workspace_bytes", K, A_out, x.C, dout.C)
+    ws = _ws(wsb, dw.device)
+    call("mopa_spconv_bwd_weight", ptr(nbr), K, A_out, x.p, x.ld, x.C, dout.p, dout.ld, dout.C, ptr(dw),
+         int(accumulate), ptr(ws), ws.numel(), stream())
+
+
+def bnrelu_fwd(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats: torch.Tensor):
+    wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bnrelu_rows_fwd", x.p, x.ld, y.p, y.ld, x.rows, x.C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+         BN_MOMENTUM, BN_EPS, LEAK, int(training), ptr(stats), ptr(ws), ws.numel(), stream())
+
+
+def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool):
+    wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bnrelu_rows_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), LEAK, int(training),
+         ptr(dgamma), ptr(dbeta), 0, int(acc_dx), ptr(ws), ws.numel(), stream())
+
+
+# --------------------------------------------------------------------------------------- the network
+def unet_param_names(num_planes=7, block_reps=1, prefix="sparseModel."):
+    """Parameter/buffer names in scn.Sequential index naming, traversal order."""
+    convs, bns = [prefix + "1"], []
+
+    def U(pre, depth):
+        idx = 0
+        for _ in range(block_reps):
+            bns.append(f"{pre}{idx}.0"); convs.append(f"{pre}{idx}.1"); idx += 1
+        if depth < num_planes - 1:
+            p = f"{pre}{idx}.1."
+            bns.append(p + "0"); convs.append(p + "1")
+            U(p + "2.", depth + 1)
+            bns.append(p + "3"); convs.append(p + "4")
+            idx += 2
+            for _ in range(block_reps):
+                bns.append(f"{pre}{idx}.0"); convs.append(f"{pre}{idx}.1"); idx += 1
+
+    U(prefix + "2.", 0)
+    bns.append(prefix + "3")
+    return convs, bns
+
+
+class SCNNetFunction(torch.autograd.Function):
+    """InputLayer -> stem -> UNet -> BNReLU -> OutputLayer -> linear heads as one autograd node.
+
+    inputs : feats (N,cin), then flat params in `spec.order`
+    outputs: feats (N,m), seg_logit (N,C), seg_logit2 (N,C) (zeros-size if no dual head)
+    """
+
+    @staticmethod
+    def forward(ctx, spec, geom: Geometry3D, training: bool, feats, *flat):
+        dev = geom.device
+        P = dict(zip(spec.order, flat))
+        A, m, L, reps = geom.num_active, spec.m, spec.num_planes, spec.block_reps
+        planes = [(i + 1) * m for i in range(L)]
+        tape = []
+        pre = spec.prefix
+
+        def bn(name, x: View, y: View | None = None):
+            y = y or new_view(x.rows, x.C, dev)
+            stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
+            bnrelu_fwd(x, y, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                       P[name + ".running_var"], training, stats)
+            tape.append(("bn", name, x, y, stats))
+            return y
+
+        def conv(name, table, x: View, out: View, kind):
+            spconv_fwd(table, x, P[name + ".weight"], out)
+            tape.append(("conv", name, table, x, out, kind))
+            return out
+
+        def U(pfx, l, x: View) -> View:
+            idx = 0
+            has_down = l < L - 1
+            join = torch.empty(A[l], 2 * planes[l], dtype=torch.float32, device=dev) if has_down else None
+            for rep in range(reps):
+                last = rep == reps - 1
+                out = View(join, 0, planes[l]) if (has_down and last) else new_view(A[l], planes[l], dev)
+                x = conv(f"{pfx}{idx}.1", geom.nbr27[l], bn(f"{pfx}{idx}.0", x), out, ("subm", l))
+                idx += 1
+            if has_down:
+                p = f"{pfx}{idx}.1."
+                d = conv(p + "1", geom.ch[l], bn(p + "0", x), new_view(A[l + 1], planes[l + 1], dev), ("down", l))
+                d = U(p + "2.", l + 1, d)
+                conv(p + "4", geom.up[l], bn(p + "3", d), View(join, planes[l], planes[l]), ("up", l))
+                tape.append(("join", l, x, View(join, planes[l], planes[l])))
+                x = View(join, 0, 2 * planes[l])
+                idx += 2
+                for rep in range(reps):
+                    x = conv(f"{pfx}{idx}.1", geom.nbr27[l], bn(f"{pfx}{idx}.0", x), new_view(A[l], planes[l], dev),
+                             ("subm", l))
+                    idx += 1
+            return x
+
+        feats = feats.contiguous().float()
+        cin = spec.in_channels
+        if feats.shape[1] != cin or feats.shape[0] < geom.n_points:
+            raise RuntimeError(f"feats must be (>= {geom.n_points}, {cin}), got {tuple(feats.shape)}")
+        x0 = new_view(A[0], cin, dev)
+        call("mopa_input_layer_fwd", ptr(feats), cin, ptr(geom.row_start), ptr(geom.row_points), A[0], x0.p, x0.ld,
+             stream())
+        x = conv(pre + "1", geom.nbr27[0], x0, new_view(A[0], m, dev), ("subm", 0))
+        x = U(pre + "2.", 0, x)
+        y = bn(pre + "3", x)
+        N, C = geom.n_points, spec.num_classes
+        out_feats = torch.empty(N, m, dtype=torch.float32, device=dev)
+        l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
+        l2 = torch.empty(N, C if spec.dual_head else 0, dtype=torch.float32, device=dev)
+        w2 = P["linear2.weight"] if spec.dual_head else None
+        b2 = P["linear2.bias"] if spec.dual_head else None
+        call("mopa_output_layer_heads_fwd", y.p, y.ld, ptr(geom.point_row), N, m, C, ptr(P["linear.weight"]),
+             ptr(P["linear.bias"]), ptr(w2), ptr(b2), ptr(out_feats), ptr(l1), ptr(l2) if spec.dual_head else None,
+             stream())
+        ctx.spec, ctx.geom, ctx.training, ctx.tape = spec, geom, training, tape
+        ctx.P, ctx.y_final, ctx.out_feats = P, y, out_feats
+        ctx.feats_needs_grad = feats.requires_grad
+        ctx.x0 = x0
+        return out_feats, l1, l2
+
+    @staticmethod
+    def backward(ctx, dfeats, dl1, dl2):
+        spec, geom, P, tape = ctx.spec, ctx.geom, ctx.P, ctx.tape
+        dev = geom.device
+        N, m, C = geom.n_points, spec.m, spec.num_classes
+        A0 = geom.num_active[0]
+        grads = {k: None for k in spec.order}
+
+        def gbuf(name):
+            g = torch.empty_like(P[name])
+            grads[name] = g
+            return g
+
+        def cont(t):
+            return None if t is None else t.contiguous().float()
+
+        dfeats, dl1 = cont(dfeats), cont(dl1)
+        dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
+        dy = new_view(A0, m, dev)
+        wsb = query("mopa_output_layer_heads_bwd_workspace_bytes", N, m, C)
+        ws = _ws(wsb, dev)
+        dw1 = gbuf("linear.weight") if dl1 is not None else None
+        db1 = gbuf("linear.bias") if dl1 is not None else None
+        dw2 = gbuf("linear2.weight") if dl2 is not None else None
+        db2 = gbuf("linear2.bias") if dl2 is not None else None
+        call("mopa_output_layer_heads_bwd", ptr(dfeats), ptr(dl1), ptr(dl2), ptr(ctx.out_feats),
+             ptr(P["linear.weight"]), ptr(P["linear2.weight"]) if spec.dual_head else None, ptr(geom.row_start),
+             ptr(geom.row_points), A0, N, m, C, dy.p, dy.ld, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), 0, ptr(ws),
+             ws.numel(), stream())
+
+        # gradient w.r.t. activation buffers, keyed by (storage ptr, col, C)
+        gmap = {}
+
+        def key(v: View):
+            return (v.t.data_ptr(), v.col, v.C)
+
+        gmap[key(ctx.y_final)] = dy
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "bn":
+                _, name, x, y, stats = rec
+                dyv = gmap.pop(key(y))
+                k = key(x)
+                if k in gmap:  # skip half of a join buffer: accumulate into the existing gradient
+                    dx, acc = gmap[k], True
+                else:
+                    dx, acc = new_view(x.rows, x.C, dev), False
+                    gmap[k] = dx
+                bnrelu_bwd(dyv, x, dx, stats, ctx.training, gbuf(name + ".weight"), gbuf(name + ".bias"), acc)
+            elif kind == "conv":
+                _, name, table, x, out, ckind = rec
+                dout = gmap.pop(key(out))
+                w = P[name + ".weight"]
+                spconv_bwd_weight(table, x, dout, gbuf(name + ".weight"))
+                if name == spec.prefix + "1" and not ctx.feats_needs_grad:
+                    continue
+                wt = spconv_transpose_weight(w)
+                dx = new_view(x.rows, x.C, dev)
+                if ckind[0] == "subm":      # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
+                    spconv_fwd(table, dout, wt, dx, w_flip=True)
+                elif ckind[0] == "down":    # rules reversed = the up table of the same level
+                    spconv_fwd(geom.up[ckind[1]], dout, wt, dx)
+                else:                        # deconv: reversed rules = the children table
+                    spconv_fwd(geom.ch[ckind[1]], dout, wt, dx)
+                gmap[key(x)] = dx
+            elif kind == "join":
+                # dec-block BN produced d(join) for all 2P columns; expose its halves under the keys of the
+                # two producers (skip conv output / deconv output), which are column views of the same buffer.
+                _, l, skip, upv = rec
+                full = gmap.pop((skip.t.data_ptr(), 0, 2 * skip.C))
+                gmap[key(skip)] = View(full.t, 0, skip.C)
+                gmap[key(upv)] = View(full.t, skip.C, skip.C)
+        dfeat_in = None
+        if ctx.feats_needs_grad:
+            cin = spec.in_channels
+            dx0 = gmap[key(ctx.x0)]
+            dfeat_in = torch.zeros(N, cin, dtype=torch.float32, device=dev)
+            call("mopa_input_layer_bwd", dx0.p, dx0.ld, ptr(geom.point_row), ptr(geom.row_start), N, cin,
+                 ptr(dfeat_in), stream())
+        return (None, None, None, dfeat_in) + tuple(grads[k] for k in spec.order)

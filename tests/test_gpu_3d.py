@@ -1,0 +1,262 @@
+"""Parity of the HIP 3D path (through the C-ABI) against the CPU oracle.  Run with -m gpu on an MI355X.
+
+Integer work (hash, active sets, rule tables): bit-exact.  fp32 features: rtol 1e-4 / atol 1e-5 per layer,
+end-to-end logits atol 1e-3 (SURVEY.md 8c "Tolerances").
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scn3d
+from oracle.params import det_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(seed, n=3000, size=48, batch=3):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    # clustered points so that neighbourhoods are non-trivial and duplicates occur
+    centers = rng.integers(4, size - 4, (40, 3))
+    c = centers[rng.integers(0, 40, n)] + rng.integers(-3, 4, (n, 3))
+    c = np.clip(c, 0, size - 1)
+    b = rng.integers(0, batch, (n, 1))
+    return np.concatenate([c, b], 1).astype(np.int64)
+
+
+def _geoms(coords, levels, full_scale):
+    from mopa_amd.sparse3d import Geometry3D
+    g = Geometry3D(torch.from_numpy(coords), levels, full_scale, "cuda")
+    o = scn3d.Geometry(coords, levels, full_scale)
+    return g, o
+
+
+def _assert_geometry_equal(g, o):
+    assert g.num_active == o.num_active
+    assert np.array_equal(g.point_row.cpu().numpy(), o.point_row)
+    for l in range(o.num_levels):
+        assert np.array_equal(g.row_keys[l].cpu().numpy().astype(np.uint64), o.row_keys[l]), l
+        assert np.array_equal(g.nbr27[l].cpu().numpy(), o.nbr27[l]), l
+    for l in range(o.num_levels - 1):
+        assert np.array_equal(g.parent[l].cpu().numpy(), o.parent[l]), l
+        assert np.array_equal(g.ch[l].cpu().numpy(), o.ch[l]), l
+        assert np.array_equal(g.up[l].cpu().numpy(), o.up[l]), l
+    rs, rp = g.row_start.cpu().numpy(), g.row_points.cpu().numpy()
+    assert rs[0] == 0 and rs[-1] == o.n_points
+    for r in (0, 1, o.num_active[0] // 2, o.num_active[0] - 1):
+        assert np.array_equal(rp[rs[r]:rs[r + 1]], np.nonzero(o.point_row == r)[0])
+
+
+def test_geometry_bit_exact_random():
+    for seed, levels, fs in ((0, 4, 64), (1, 3, 4096), (2, 1, 64)):
+        c = _cloud(seed)
+        if fs == 4096:
+            c[:, :3] *= 60  # spread over the full 12-bit range
+            c[:, :3] += _cloud(seed + 10)[:, :3] // 8
+        g, o = _geoms(c, levels, fs)
+        _assert_geometry_equal(g, o)
+
+
+def test_geometry_bit_exact_synthetic_scan_and_pins(golden_dir):
+    import json, os
+    from mopa_amd import synth
+    b = synth.make_batch(2)
+    coords = b["x"][0].numpy()
+    g, o = _geoms(coords, 7, 4096)
+    _assert_geometry_equal(g, o)
+    pins = json.load(open(os.path.join(golden_dir, "g7_synth_pins.json")))
+    g0, _ = _geoms(coords[coords[:, 3] == 0], 7, 4096)
+    assert g0.num_active == pins["0"]["active"] and g0.num_rules == pins["0"]["rules"]
+
+
+def test_geometry_rejects_out_of_range():
+    from mopa_amd.sparse3d import Geometry3D
+    c = _cloud(3)
+    c[5, 1] = 4096
+    with pytest.raises(RuntimeError):
+        Geometry3D(torch.from_numpy(c), 2, 4096, "cuda")
+    with pytest.raises(RuntimeError):
+        Geometry3D(torch.zeros(0, 4, dtype=torch.int64), 2, 4096, "cuda")
+
+
+@pytest.mark.parametrize("cin,cout", [(1, 16), (16, 16), (32, 16), (48, 48), (64, 32), (80, 96), (192, 96), (96, 112),
+                                      (112, 112), (16, 1), (3, 20)])
+def test_spconv_fwd_wgrad_dgrad_vs_oracle(cin, cout):
+    from mopa_amd import sparse3d as s3
+    c = _cloud(4, n=5000)
+    g, o = _geoms(c, 2, 64)
+    dev = "cuda"
+    rng = np.random.Generator(np.random.PCG64(cin * 1000 + cout))
+    for table_name, tab_g, tab_o, A_in, flip_for_dgrad in (
+            ("subm", g.nbr27[0], o.nbr27[0], o.num_active[0], None),
+            ("down", g.ch[0], o.ch[0], o.num_active[0], g.up[0]),
+            ("up", g.up[0], o.up[0], o.num_active[1], g.ch[0])):
+        K, A_out = tab_o.shape
+        x = torch.from_numpy(rng.standard_normal((A_in, cin), dtype=np.float32))
+        w = torch.from_numpy(rng.standard_normal((K, cin, cout), dtype=np.float32) * 0.2)
+        gout = torch.from_numpy(rng.standard_normal((A_out, cout), dtype=np.float32))
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        ref = scn3d.sparse_conv(xr, tab_o, wr)
+        (ref * gout.double()).sum().backward()
+        # forward, reading x from / writing out to channel slices of wider buffers (JoinTable layout)
+        pad_in = 4 * ((cin + 3) // 4) + 8
+        xin = torch.zeros(A_in, pad_in, device=dev)
+        col = 4 if cin % 4 == 0 else 0
+        xin[:, col:col + cin] = x.to(dev)
+        outb = torch.full((A_out, cout + 8), 7.0, device=dev)
+        xv, ov = s3.View(xin, col, cin), s3.View(outb, 4 if cout % 4 == 0 else 0, cout)
+        s3.spconv_fwd(tab_g, xv, w.to(dev), ov)
+        got = ov.dense().cpu()
+        scale = max(1.0, float(ref.abs().max()))
+        np.testing.assert_allclose(got.numpy(), ref.detach().float().numpy(), rtol=1e-4, atol=2e-5 * scale)
+        assert (outb[:, ov.col + cout:] == 7.0).all()  # neighbours of the slice untouched
+        # backward-weight
+        dw = torch.empty(K, cin, cout, device=dev)
+        gv = s3.View(gout.to(dev).contiguous())
+        s3.spconv_bwd_weight(tab_g, xv, gv, dw)
+        sw = max(1.0, float(wr.grad.abs().max()))
+        np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.float().numpy(), rtol=2e-4, atol=5e-5 * sw)
+        # backward-data through the reversed rules
+        wt = s3.spconv_transpose_weight(w.to(dev))
+        dx = s3.new_view(A_in, cin, dev)
+        if table_name == "subm":
+            s3.spconv_fwd(tab_g, gv, wt, dx, w_flip=True)
+        else:
+            s3.spconv_fwd(flip_for_dgrad, gv, wt, dx)
+        sx = max(1.0, float(xr.grad.abs().max()))
+        np.testing.assert_allclose(dx.dense().cpu().numpy(), xr.grad.float().numpy(), rtol=1e-4, atol=2e-5 * sx)
+
+
+@pytest.mark.parametrize("C,rows", [(16, 5000), (48, 777), (192, 300), (32, 1)])
+def test_bnrelu_rows_fwd_bwd_vs_oracle(C, rows):
+    from mopa_amd import sparse3d as s3
+    rng = np.random.Generator(np.random.PCG64(C + rows))
+    x = torch.from_numpy(rng.standard_normal((rows, C), dtype=np.float32) * 3 + 5.0)
+    gam = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32))
+    bet = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((rows, C), dtype=np.float32))
+    for training in (True, False):
+        if rows == 1 and training:
+            continue
+        rm, rv = torch.zeros(C) + 0.3, torch.ones(C) * 1.7
+        xr, gr, br = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+        rmr, rvr = rm.double().clone(), rv.double().clone()
+        ref = scn3d.bn_relu(xr, gr, br, rmr, rvr, training)
+        (ref * gout.double()).sum().backward()
+        dev = "cuda"
+        xb = torch.zeros(rows, C + 16, device=dev)
+        xb[:, 16:] = x.to(dev)
+        xv = s3.View(xb, 16, C)
+        yv = s3.new_view(rows, C, dev)
+        stats = torch.empty(4, C, device=dev)
+        rmd, rvd = rm.to(dev), rv.to(dev)
+        s3.bnrelu_fwd(xv, yv, gam.to(dev), bet.to(dev), rmd, rvd, training, stats)
+        np.testing.assert_allclose(yv.dense().cpu().numpy(), ref.detach().float().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rmd.cpu().numpy(), rmr.float().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rvd.cpu().numpy(), rvr.float().numpy(), rtol=1e-5, atol=1e-6)
+        dx = s3.View(torch.ones(rows, C, device=dev))
+        dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        s3.bnrelu_bwd(s3.View(gout.to(dev)), xv, dx, stats, training, dg, db, acc_dx=True)
+        np.testing.assert_allclose(dx.dense().cpu().numpy() - 1.0, xr.grad.float().numpy(), rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1):
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    cfg = default_cfg(C, dual)
+    cfg.MODEL_3D.SCN.num_planes = num_planes
+    cfg.MODEL_3D.SCN.in_channels = in_channels
+    cfg.MODEL_3D.SCN.block_reps = block_reps
+    model, _ = build_model_3d(cfg)
+    sd = model.state_dict()
+    model.load_state_dict({k: det_tensor_like(k, v) for k, v in sd.items()})
+    return model.cuda()
+
+
+def det_tensor_like(k, v):
+    from oracle.params import det_tensor
+    return det_tensor(k, v.shape)
+
+
+def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64):
+    P = {k: v.detach().cpu().to(dtype).clone() for k, v in model.state_dict().items()}
+    for k in P:
+        if "running" not in k:
+            P[k].requires_grad_(True)
+    og = scn3d.Geometry(coords, num_planes, full_scale)
+    f = feats.to(dtype).clone().requires_grad_(True)
+    out = scn3d.net3dseg_forward(P, og, f, dual_head="linear2.weight" in P, training=training, num_planes=num_planes,
+                                 block_reps=block_reps)
+    if gouts is not None:
+        sum((out[k] * gouts[k].to(dtype)).sum() for k in out).backward()
+    return P, f, out
+
+
+@pytest.mark.parametrize("num_planes,in_ch,reps,training", [(3, 1, 1, True), (3, 4, 2, True), (7, 1, 1, True), (7, 1, 1, False)])
+def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
+    torch.manual_seed(0)
+    c = _cloud(7, n=6000, size=120 if num_planes == 7 else 48)
+    model = _build_3d(num_planes, in_ch, block_reps=reps)
+    model.train(training)
+    rng = np.random.Generator(np.random.PCG64(5))
+    feats = torch.from_numpy(rng.random((c.shape[0], in_ch), dtype=np.float32) + 0.5)
+    if not training:
+        # well-conditioned eval case: running statistics := the batch statistics of this input (oracle pass with
+        # momentum 1), otherwise arbitrary running stats blow activations up over 7 levels and ReLU-mask flips
+        # dominate every fp32-vs-fp64 comparison.
+        P0 = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+        old, scn3d.BN_MOMENTUM = scn3d.BN_MOMENTUM, 1.0
+        try:
+            scn3d.net3dseg_forward(P0, scn3d.Geometry(c, num_planes), feats.double(), training=True,
+                                   num_planes=num_planes, block_reps=reps)
+        finally:
+            scn3d.BN_MOMENTUM = old
+        model.load_state_dict({k: v.float() for k, v in P0.items()})
+    f_dev = feats.cuda().requires_grad_(True)
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    out = model({"x": [torch.from_numpy(c), f_dev]})
+    gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
+    sum((out[k] * gouts[k].cuda()).sum() for k in out).backward()
+    model_ref = _build_3d(num_planes, in_ch, block_reps=reps)
+    model_ref.load_state_dict(sd_before)
+    P, f, ref = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps)
+    # yardstick: the same oracle in fp32 -- the HIP path (fp32) may differ from the fp64 truth by a small multiple of
+    # what plain fp32 torch-CPU arithmetic differs by (summation-order noise grows with depth).
+    model_ref.load_state_dict(sd_before)
+    P32, f32, ref32 = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, dtype=torch.float32)
+
+    def close(got, truth, yard, what):
+        scale = max(1e-6, float(np.abs(truth).max()))
+        err = float(np.abs(got - truth).max())
+        yerr = float(np.abs(yard - truth).max())
+        assert err <= max(4.0 * yerr, 2e-4 * scale), (what, err, yerr, scale)
+        assert err <= 1e-2 * scale, (what, err, scale)
+
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        close(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), ref32[k].detach().double().numpy(), k)
+    named = dict(model.named_parameters())
+    for k, p in P.items():
+        if p.requires_grad:
+            close(named[k].grad.cpu().numpy(), p.grad.numpy(), P32[k].grad.double().numpy(), k)
+    close(f_dev.grad.cpu().numpy(), f.grad.numpy(), f32.grad.double().numpy(), "dfeats")
+    if training:  # running statistics were updated exactly like the oracle's
+        sd = model.state_dict()
+        for k in P:
+            if "running" in k:
+                np.testing.assert_allclose(sd[k].cpu().numpy(), P[k].float().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_net3dseg_duplicate_points_and_extra_feature_rows():
+    # nuScenes quirk (Appendix B.8): more feature rows than coords; and every point duplicated once.
+    c = _cloud(9, n=800, size=24)
+    c = np.concatenate([c, c], 0)
+    model = _build_3d(3).eval()
+    feats = torch.ones(c.shape[0] + 37, 1)
+    out = model({"x": [torch.from_numpy(c), feats]})
+    _, _, ref = _oracle_run(model, c, feats, 3, False, None)
+    r = ref["seg_logit"].detach().float().numpy()
+    np.testing.assert_allclose(out["seg_logit"].detach().cpu().numpy(), r, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(r).max()))
+    assert out["feats"].shape == (c.shape[0], 16)
+    half = c.shape[0] // 2
+    assert torch.equal(out["feats"][:half], out["feats"][half:])
