@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (dense)
 CLASS_WEIGHTS = [2.68678412, 4.36182969, 5.47896839, 3.89026883, 1.0]  # configs/nuscenes/usa_singapore yaml:54
 
 
@@ -32,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="3d", choices=["3d"])
+    ap.add_argument("--workload", default="joint", choices=["joint", "3d"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -77,6 +78,80 @@ class ConvTimer:
         n = len(self.records)
         return dict(launches=n, avg_us=1e3 * ms / n, bytes_per_launch=nbytes / n, gbs=nbytes / (ms * 1e-3) / 1e9,
                     tflops=flops / (ms * 1e-3) / 1e12)
+
+
+class Conv2dTimer:
+    """HIP-event brackets around every dense implicit-GEMM launch of the 2D branch (fwd, dgrad, convT classes)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from mopa_amd import dense2d
+        inner = dense2d.igemm
+        timer = self
+
+        def wrapped(x_ptr, w, bias, out_ptr, geom, accumulate=False):
+            if not timer.enabled:
+                return inner(x_ptr, w, bias, out_ptr, geom, accumulate)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            inner(x_ptr, w, bias, out_ptr, geom, accumulate)
+            e.record()
+            g = list(geom)
+            M = g[0] * g[3] * g[4]  # B * OHl * OWl
+            taps, cin, cout = g[15] * g[16], g[21], g[22]
+            # bytes: activations read once + outputs written once + weights once (ideal reuse)
+            timer.records.append((s, e, 4 * (M * cin + M * cout + taps * cin * cout), 2 * M * cout * taps * cin))
+
+        dense2d.igemm = wrapped
+
+    summary = ConvTimer.summary
+
+
+def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
+    """CPU restatement (oracle, kind 'port') of one scan of the joint step: 2D + 3D forward/backward + CE/KL losses."""
+    from mopa_amd import synth
+    from oracle import losses as ol
+    from oracle import net2d, scn3d
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 32)))
+    s = synth.make_scan(4242)
+    coords = np.concatenate([s["coords"], np.zeros((len(s["coords"]), 1), np.int64)], 1)
+    P2 = {k: v.detach().cpu().clone() for k, v in model2d.state_dict().items()}
+    P3 = {k: v.detach().cpu().float().clone() for k, v in model3d.state_dict().items()}
+    for P in (P2, P3):
+        for k, v in P.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+    img = torch.from_numpy(s["img"])[None]
+    lab = torch.from_numpy(s["seg_label"])
+    feats = torch.ones(len(coords), 1)
+
+    def one_pass():
+        t0 = time.time()
+        o2 = net2d.net2dseg_forward(P2, img, [s["img_indices"]], training=True, dropout_p=0.4)
+        o3 = scn3d.net3dseg_forward(P3, scn3d.Geometry(coords, 7), feats, training=True)
+        l2 = ol.seg_ce(o2["seg_logit"], lab) + ol.xm_kl(o2["seg_logit2"], o3["seg_logit"])
+        l3 = ol.seg_ce(o3["seg_logit"], lab) + ol.xm_kl(o3["seg_logit2"], o2["seg_logit"])
+        l2.backward()
+        l3.backward()
+        return time.time() - t0
+
+    warm = one_pass()
+    n, t_total = 0, 0.0
+    while n < 3 and t_total + warm < seconds_budget:
+        t_total += one_pass()
+        n += 1
+    if n == 0:
+        n, t_total = 1, warm
+    return dict(value=n / t_total, unit="scans/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} x (1 synthetic scan: 302x480 image + 34,880 pts, Net2DSeg+Net3DSeg fwd+bwd+CE+KL, "
+                       "torch-CPU fp32 oracle)")
 
 
 def cpu_baseline_3d(model, seconds_budget=25.0):
@@ -127,40 +202,58 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from mopa_amd import synth
-    from mopa_amd.common.utils.loss import seg_ce
+    from mopa_amd.common.utils.loss import seg_ce, xm_kl
     from mopa_amd.config import default_cfg
-    from mopa_amd.models.build import build_model_3d
+    from mopa_amd.models.build import build_model_2d, build_model_3d
     from mopa_amd.optim import FlatAdam
     from mopa_amd.sparse3d import Geometry3D
 
+    joint = args.workload == "joint"
     torch.manual_seed(1 + rank)
     cfg = default_cfg(num_classes=5, dual_head=True)
     model3d, _ = build_model_3d(cfg)
     model3d = model3d.to(dev).train()
+    models = [model3d]
+    if joint:
+        model2d, _ = build_model_2d(cfg)
+        model2d = model2d.to(dev).train()
+        models.append(model2d)
     if world > 1:  # identical initial weights on every rank
-        for p in model3d.parameters():
-            dist.broadcast(p.data, 0)
-    opt3d = FlatAdam(model3d.parameters(), lr=1e-3)
+        for m in models:
+            for p in m.parameters():
+                dist.broadcast(p.data, 0)
+    opts = [FlatAdam(m.parameters(), lr=1e-3) for m in models]
     cw = torch.tensor(CLASS_WEIGHTS, device=dev)
+    H, W = 302, 480
 
-    # ---- synthetic batches, resident in HBM before timing (two distinct batches, alternated)
+    # ---- synthetic batches, resident in HBM before timing.  joint: [source, target] of one xMUDA iteration;
+    #      3d: two batches alternated.
     B = args.batch
     batches = []
     for j in range(2):
         scans = []
         for i in range(B):
-            pts = synth.lidar_points(1000 * rank + j * B + i)
-            rng = np.random.Generator(np.random.PCG64(99 + 1000 * rank + j * B + i))
+            seed = 1000 * rank + j * B + i
+            pts = synth.lidar_points(seed)
+            rng = np.random.Generator(np.random.PCG64(99 + seed))
             lab = rng.integers(0, 5, len(pts)).astype(np.int64)
             lab[rng.random(len(pts)) < 0.1] = -100
-            scans.append((synth.voxelize(pts), lab))
+            scans.append((synth.voxelize(pts), lab, rng))
         locs = torch.cat([torch.cat([torch.from_numpy(c), torch.full((len(c), 1), i, dtype=torch.int64)], 1)
-                          for i, (c, _) in enumerate(scans)])
-        batches.append(dict(locs=locs.to(dev), feats=torch.ones(locs.shape[0], 1, device=dev),
-                            label=torch.cat([torch.from_numpy(l) for _, l in scans]).to(dev)))
+                          for i, (c, _, _) in enumerate(scans)])
+        bt = dict(locs=locs.to(dev), feats=torch.ones(locs.shape[0], 1, device=dev),
+                  label=torch.cat([torch.from_numpy(l) for _, l, _ in scans]).to(dev))
+        if joint:
+            bt["img"] = torch.stack([torch.from_numpy(r.random((3, H, W), dtype=np.float32)) for _, _, r in scans]).to(dev)
+            idx = [np.stack([r.integers(0, H, len(c)), r.integers(0, W, len(c))], 1) for c, _, r in scans]
+            bt["pix"] = model2d.pack_indices(idx, H, W, dev)
+        batches.append(bt)
 
     timer = ConvTimer()
     timer.install()
+    timer2d = Conv2dTimer()
+    if joint:
+        timer2d.install()
     for b in batches:  # rule counts for the algorithmic-bytes model (one-off, outside the timed region)
         g = Geometry3D(b["locs"], 7, 4096, dev)
         for l in range(7):
@@ -170,17 +263,39 @@ def main():
             timer.rules[(8, g.num_active[l], g.num_active[l + 1])] = g.num_active[l]   # up / conv-dgrad
         del g
 
-    def step(i):
-        b = batches[i % 2]
-        opt3d.zero_grad()
+    def half(b, lam_xm, supervised):
+        """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
         geom = Geometry3D(b["locs"], 7, 4096, dev)
-        out = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
-        loss = seg_ce(out["seg_logit"], b["label"], cw) + seg_ce(out["seg_logit2"], b["label"], cw)
-        loss.backward()
-        opt3d.all_reduce()
-        opt3d.step(1.0 / world)
+        o3 = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
+        o2 = model2d({"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None})
+        l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
+        l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
+        if supervised:
+            l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
+            l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+        l2.backward()
+        l3.backward()
+        return l2.detach() + l3.detach()
+
+    def step(i):
+        for o in opts:
+            o.zero_grad()
+        if joint:
+            loss = half(batches[0], 1.0, True)          # source: CE + lambda_xm_src * KL   (yaml :56)
+            loss = loss + half(batches[1], 0.1, False)  # target: lambda_xm_trg * KL        (yaml :57)
+        else:
+            b = batches[i % 2]
+            geom = Geometry3D(b["locs"], 7, 4096, dev)
+            out = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
+            loss = seg_ce(out["seg_logit"], b["label"], cw) + seg_ce(out["seg_logit2"], b["label"], cw)
+            loss.backward()
+        for o in opts:
+            o.all_reduce()
+        for o in opts:
+            o.step(1.0 / world)
         return loss
 
+    scans_per_step = 2 * B if joint else B
     t_setup = time.perf_counter()
     for i in range(args.warmup):
         step(i)
@@ -189,7 +304,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = timer2d.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
@@ -198,7 +313,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = timer2d.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,26 +322,40 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        roof = None
+        sp = None
         if ks:
-            roof = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_fwd (fwd + bwd-data)",
-                    "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
-                    "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
+            sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_fwd (fwd + bwd-data)",
+                  "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
+                  "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
+        roof = sp
+        k2 = timer2d.summary() if joint else None
+        if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
+            roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "k_conv2d_igemm (fp32 vector FMA; fwd + bwd-data + convT)",
+                    "launches_per_step": k2["launches"] // args.steps, "avg_launch_us": round(k2["avg_us"], 2),
+                    "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}
+        wl = ("Full xMUDA 2D+3D joint step + xModalKL (BASELINE configs[2]): "
+              f"{B} source + {B} target scans/GPU per step, Net2DSeg(UNetResNet34, 302x480) + Net3DSeg(SCN UNet, 34,880 pts), "
+              "CE + cross-modal KL, backward, Adam") if joint else (
+              "Net3DSeg SCN-UNet only (BASELINE configs[1]): geometry+fwd+CE+bwd+Adam, "
+              f"bs={B} synthetic nuScenes-shape scans/GPU (34,880 pts each)")
         line = {
             "metric": "scans/sec (joint 2D+3D train step) at 1/2/4/8 MI355X; sparse-conv HBM GB/s",
-            "value": round(world * B * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Net3DSeg SCN-UNet only (BASELINE configs[1]): geometry+fwd+CE+bwd+Adam, "
-                                   f"bs={B} synthetic nuScenes-shape scans/GPU (34,880 pts each)",
-                       "global_batch": B * world, "points_per_scan": 34880, "parallelism": f"dp{world}"},
+            "value": round(world * scans_per_step * args.steps / elapsed, 3), "unit": "scans/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "scans_per_step_per_gpu": scans_per_step, "global_batch": scans_per_step * world,
+                       "points_per_scan": 34880, "image": "302x480", "parallelism": f"dp{world}"},
+            "iterations_per_s": round(world * args.steps / elapsed, 3),
             "roofline": roof,
+            "roofline_sparse_conv": sp,
         }
         print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline:
             t_cpu = time.perf_counter()
-            line["cpu_baseline"] = cpu_baseline_3d(model3d)
+            line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d) if joint else cpu_baseline_3d(model3d)
             print(f"[bench] cpu baseline took {time.perf_counter() - t_cpu:.1f}s", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if world > 1:

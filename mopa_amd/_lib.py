@@ -42,6 +42,23 @@ SIGNATURES = {
     "mopa_output_layer_heads_fwd": ("i", "pipiiipppppppp"),
     "mopa_output_layer_heads_bwd_workspace_bytes": ("z", "iii"),
     "mopa_output_layer_heads_bwd": ("i", "ppppppppiiiipippppipzp"),
+    "mopa_bn_act_fwd": ("i", "pipiiippppfffipiippzp"),
+    "mopa_bn_act_bwd": ("i", "pipipiiipfipipiiippiipzp"),
+    # ---- dense 2D branch (conv2d.hip, ops2d.hip)
+    "mopa_conv2d_igemm": ("i", "pppppip"),
+    "mopa_conv2d_wgrad_workspace_bytes": ("z", "p"),
+    "mopa_conv2d_bwd_weight": ("i", "ppppipzp"),
+    "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),
+    "mopa_conv2d_stem_relayout": ("i", "ppiiip"),
+    "mopa_img_to_nhwc4": ("i", "piiiiipp"),
+    "mopa_maxpool3x3s2_fwd": ("i", "piiiiipipp"),
+    "mopa_maxpool3x3s2_bwd": ("i", "pipiiiipiip"),
+    "mopa_dropout_rows": ("i", "pipiliflp"),
+    "mopa_pixel_head_fwd": ("i", "piiiiiiiipppp"),
+    "mopa_pixel_head_bwd_workspace_bytes": ("z", "iiiii"),
+    "mopa_pixel_head_bwd": ("i", "ppiiiiiiiippiippipzp"),
+    "mopa_colsum_workspace_bytes": ("z", "li"),
+    "mopa_colsum": ("i", "pilipipzp"),
     # ---- losses (losses.hip)
     "mopa_loss_workspace_bytes": ("z", "l"),
     "mopa_softmax_kl_fwd": ("i", "ppiippzp"),

@@ -1,0 +1,401 @@
+// Dense 2D convolution of the image branch as an LDS-tiled implicit GEMM on the fp32 vector pipe (no MFMA here by
+// design: north_star keeps the matrix cores for the sparse conv).  NHWC activations, one kernel for
+//   * forward conv (3x3 s1/s2, 1x1 s2, the 7x7 stem through a 16-wide tap trick),
+//   * backward-data (stride 1 directly; stride 2 as 4 output-parity classes so no FLOP is wasted on zeros),
+//   * ConvTranspose2d k2 s2 (4 output-parity classes of a 1x1 conv) and its backward-data (a 2x2 s2 conv),
+// selected by an index map, plus a split-K backward-weight kernel.
+//
+// Replaces the cuDNN calls behind mopa/models/resnet34_unet.py:93-110,144-182 (Conv2d / ConvTranspose2d of
+// UNetResNet34).  Oracle: oracle/net2d.py (torch-CPU conv2d / conv_transpose2d), golden fixture G1.
+//
+// GEMM view:  out[m][n] = sum_{tap, c} A[m][tap][c] * Wt[tap][c][n]
+//   m = (b, oy, ox) over a LOGICAL output grid [B][OHl][OWl]; the element lands at (oy*OS+OOY, ox*OS+OOX) of the
+//   actual output image [OHa][OWa];  tap = (ty, tx) over [TH][TW] logical taps; its input pixel is
+//   (oy*IS + IY0 + ty*IDY, ox*IS + IX0 + tx*IDX), zero outside [IH][IW]; its weight slice is
+//   w[(KH0 + ty*KS) * KWF + (KW0 + tx*KS)] of shape [Cin][Cout].
+#include "common.h"
+#include <string.h>
+
+struct ConvGeom {
+  int B, IH, IW, OHl, OWl, OHa, OWa;
+  int OS, OOY, OOX;
+  int IS, IY0, IX0, IDY, IDX;
+  int TH, TW, KH0, KW0, KS, KWF;
+  int Cin, Cout, ld_in, ld_out;
+};
+
+#define BK 16
+#define APAD 4
+
+// BM x BN output tile per 256-thread block, 8x8 register micro-tile per thread (TX = BN/8 threads across n).
+// LDS: A is kept k-major ([k][m], transposed while staging) so that each k-step is 2+2 ds_read_b128 feeding
+// 64 FMAs with only 16 operand registers live; double-buffered, one barrier per 16-deep K-chunk, the next chunk's
+// global loads are issued before the FMAs of the current one.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          const ConvGeom g, int accumulate) {
+  constexpr int TX = BN / 8, TY = 256 / TX;
+  static_assert(TY * 8 == BM, "tile shape");
+  constexpr int AROWS = BM / 64;             // A float4 loads per thread per K-chunk
+  constexpr int BVEC = (BK * BN / 4) / 256;  // B float4 loads per thread per K-chunk
+  constexpr int BMP = BM + APAD;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BMP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  const int t = threadIdx.x, tx = t % TX, ty = t / TX;
+  const int M = g.B * g.OHl * g.OWl;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ohw = g.OHl * g.OWl;
+
+  // staging assignment: A row = t/4 + 64*j, k-quad = t%4
+  const int akq = t & 3, arow = t >> 2;
+  int ab[AROWS], aoy[AROWS], aox[AROWS];
+#pragma unroll
+  for (int j = 0; j < AROWS; ++j) {
+    const int m = m0 + arow + 64 * j;
+    if (m < M) {
+      const int b = m / ohw, r = m - b * ohw;
+      ab[j] = b; aoy[j] = r / g.OWl; aox[j] = r - aoy[j] * g.OWl;
+    } else {
+      ab[j] = -1; aoy[j] = 0; aox[j] = 0;
+    }
+  }
+  const int cchunks = g.Cin / BK;
+  const int niter = g.TH * g.TW * cchunks;
+  float4 ra[AROWS], rb[BVEC];
+
+#define LOAD_TILE(IT)                                                                                              \
+  {                                                                                                                \
+    const int tap_ = (IT) / cchunks, c0_ = ((IT) - tap_ * cchunks) * BK;                                           \
+    const int tyy_ = tap_ / g.TW, txx_ = tap_ - tyy_ * g.TW;                                                       \
+    _Pragma("unroll") for (int j = 0; j < AROWS; ++j) {                                                            \
+      const int iy = aoy[j] * g.IS + g.IY0 + tyy_ * g.IDY, ix = aox[j] * g.IS + g.IX0 + txx_ * g.IDX;              \
+      if (ab[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)                            \
+        ra[j] = *reinterpret_cast<const float4*>(in + ((int64_t)(ab[j] * g.IH + iy) * g.IW + ix) * g.ld_in + c0_ + akq * 4); \
+      else                                                                                                         \
+        ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                   \
+    }                                                                                                              \
+    const float* wt_ = w + ((int64_t)((g.KH0 + tyy_ * g.KS) * g.KWF + g.KW0 + txx_ * g.KS) * g.Cin + c0_) * g.Cout + n0; \
+    _Pragma("unroll") for (int j = 0; j < BVEC; ++j) {                                                             \
+      const int idx = t + 256 * j, k = idx / (BN / 4), c4 = idx - k * (BN / 4);                                    \
+      rb[j] = *reinterpret_cast<const float4*>(wt_ + (int64_t)k * g.Cout + c4 * 4);                                \
+    }                                                                                                              \
+  }
+#define STORE_TILE(BUF)                                                                                            \
+  {                                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < AROWS; ++j) {                                                            \
+      As[BUF][akq * 4 + 0][arow + 64 * j] = ra[j].x;                                                               \
+      As[BUF][akq * 4 + 1][arow + 64 * j] = ra[j].y;                                                               \
+      As[BUF][akq * 4 + 2][arow + 64 * j] = ra[j].z;                                                               \
+      As[BUF][akq * 4 + 3][arow + 64 * j] = ra[j].w;                                                               \
+    }                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < BVEC; ++j) {                                                             \
+      const int idx = t + 256 * j, k = idx / (BN / 4), c4 = idx - k * (BN / 4);                                    \
+      *reinterpret_cast<float4*>(&Bs[BUF][k][c4 * 4]) = rb[j];                                                     \
+    }                                                                                                              \
+  }
+
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < niter; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < niter) LOAD_TILE(it + 1);  // global loads in flight while this tile is consumed
+#pragma unroll 4
+    for (int k = 0; k < BK; ++k) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][k][ty * 8]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&As[cur][k][ty * 8 + 4]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][k][tx * 4]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][k][BN / 2 + tx * 4]);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[i][0] = fmaf(av[i], b0.x, acc[i][0]); acc[i][1] = fmaf(av[i], b0.y, acc[i][1]);
+        acc[i][2] = fmaf(av[i], b0.z, acc[i][2]); acc[i][3] = fmaf(av[i], b0.w, acc[i][3]);
+        acc[i][4] = fmaf(av[i], b1.x, acc[i][4]); acc[i][5] = fmaf(av[i], b1.y, acc[i][5]);
+        acc[i][6] = fmaf(av[i], b1.z, acc[i][6]); acc[i][7] = fmaf(av[i], b1.w, acc[i][7]);
+      }
+    }
+    if (it + 1 < niter) {
+      STORE_TILE(cur ^ 1);
+      __syncthreads();
+    }
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+  // epilogue
+  float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+  if (bias) {
+    bv0 = *reinterpret_cast<const float4*>(bias + n0 + tx * 4);
+    bv1 = *reinterpret_cast<const float4*>(bias + n0 + BN / 2 + tx * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + ty * 8 + i;
+    if (m >= M) continue;
+    const int b = m / ohw, r = m - b * ohw;
+    const int oy = r / g.OWl, ox = r - oy * g.OWl;
+    float* o = out + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + n0;
+    float4 v0 = make_float4(acc[i][0] + bv0.x, acc[i][1] + bv0.y, acc[i][2] + bv0.z, acc[i][3] + bv0.w);
+    float4 v1 = make_float4(acc[i][4] + bv1.x, acc[i][5] + bv1.y, acc[i][6] + bv1.z, acc[i][7] + bv1.w);
+    float4* p0 = reinterpret_cast<float4*>(o + tx * 4);
+    float4* p1 = reinterpret_cast<float4*>(o + BN / 2 + tx * 4);
+    if (accumulate) {
+      const float4 q0 = *p0, q1 = *p1;
+      v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
+      v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
+    }
+    *p0 = v0;
+    *p1 = v1;
+  }
+}
+
+// geom: 25 int32 in the ConvGeom order.  bias may be null.  accumulate: out += result (gradient accumulation).
+MOPA_API int mopa_conv2d_igemm(const float* in, const float* weight, const float* bias, float* out,
+                               const int32_t* geom_host, int32_t accumulate, void* stream) {
+  ConvGeom g;
+  static_assert(sizeof(ConvGeom) == 25 * sizeof(int), "ConvGeom layout");
+  memcpy(&g, geom_host, sizeof(g));
+  if (g.Cin % BK != 0 || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0 || g.B <= 0) return MOPA_ERR_ARG;
+  if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return MOPA_ERR_ARG;
+  const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.Cout % 128 == 0 && M >= 128 * 512) {
+    dim3 grid((unsigned)cdiv64(M, 128), g.Cout / 128);
+    k_conv2d_igemm<128, 128><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate);
+  } else {
+    dim3 grid((unsigned)cdiv64(M, 256), g.Cout / 64);
+    k_conv2d_igemm<256, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate);
+  }
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Backward-weight: dW[tap][ci][co] = sum_m A[m][tap][ci] * dY[m][co]   (same index map as above; dY plays "out").
+// Block = one 64x64 (ci, co) tile of one tap over a slice of the pixels; pixels are the GEMM K dimension, staged
+// 16 at a time.  Slice partials go to slabs [split][taps*Cin*Cout] and are summed in order by k_reduce (determinism).
+#define WBK 16
+template <int WM>  // 64, or 16 for the stem's 16-wide tap trick
+__global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ in, const float* __restrict__ dy,
+                                                       float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
+  constexpr int WN = 64;
+  constexpr int MT = WM / 16;  // micro rows per thread (ty has 16 values)
+  __shared__ __attribute__((aligned(16))) float As[2][WBK][WM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK][WN + 4];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int tap = blockIdx.x;
+  const int tiles_n = g.Cout / WN;
+  const int ci0 = (blockIdx.y / tiles_n) * WM, co0 = (blockIdx.y % tiles_n) * WN;
+  const int tyy = tap / g.TW, txx = tap - tyy * g.TW;
+  const int M = g.B * g.OHl * g.OWl;
+  const int mbeg = blockIdx.z * m_per_split, mend = min(M, mbeg + m_per_split);
+  // staging: pixel k = t / 16, 4-float group = t % 16 (covers 64 floats per pixel row)
+  const int sk = t >> 4, sq = t & 15;
+  float acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  float4 ra, rb;
+  auto load_tile = [&](int mb) {
+    const int m = mb + sk;
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = ra;
+    if (m < mend) {
+      const int b = m / (g.OHl * g.OWl), r = m - b * g.OHl * g.OWl;
+      const int oy = r / g.OWl, ox = r - oy * g.OWl;
+      const int iy = oy * g.IS + g.IY0 + tyy * g.IDY, ix = ox * g.IS + g.IX0 + txx * g.IDX;
+      if (sq * 4 < WM && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+        ra = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + ci0 + sq * 4);
+      rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + co0 + sq * 4);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (sq * 4 < WM) *reinterpret_cast<float4*>(&As[buf][sk][sq * 4]) = ra;
+    *reinterpret_cast<float4*>(&Bs[buf][sk][sq * 4]) = rb;
+  };
+  int buf = 0;
+  if (mbeg < mend) {
+    load_tile(mbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int mb = mbeg; mb < mend; mb += WBK) {
+    const bool more = mb + WBK < mend;
+    if (more) load_tile(mb + WBK);
+#pragma unroll
+    for (int k = 0; k < WBK; ++k) {
+      const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][k][tx * 4]);
+      float a[MT];
+      if (MT == 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][k][ty * 4]);
+        a[0] = a4.x; a[1 % MT] = a4.y; a[2 % MT] = a4.z; a[3 % MT] = a4.w;
+      } else {
+        a[0] = As[buf][k][ty];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = fmaf(a[i], b4.x, acc[i][0]); acc[i][1] = fmaf(a[i], b4.y, acc[i][1]);
+        acc[i][2] = fmaf(a[i], b4.z, acc[i][2]); acc[i][3] = fmaf(a[i], b4.w, acc[i][3]);
+      }
+    }
+    if (more) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  const int64_t wsz = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
+  float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)tap * g.Cin + ci0) * g.Cout + co0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ci = (MT == 4) ? ty * 4 + i : ty;
+    *reinterpret_cast<float4*>(dst + (int64_t)ci * g.Cout + tx * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  }
+}
+
+__global__ void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw, int accumulate) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? dw[i] : 0.f;
+    for (int c = 0; c < nsplit; ++c) s += slabs[(int64_t)c * n + i];
+    dw[i] = s;
+  }
+}
+
+static void wgrad_split(const ConvGeom& g, int* nsplit, int* m_per_split) {
+  const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
+  const int wm = g.Cin >= 64 ? 64 : 16;
+  const int64_t tiles = (int64_t)g.TH * g.TW * (g.Cin / wm) * (g.Cout / 64);
+  int64_t ns = cdiv64(2048, tiles);
+  const int64_t maxs = cdiv64(M, 256);
+  if (ns > maxs) ns = maxs;
+  if (ns > 512) ns = 512;
+  if (ns < 1) ns = 1;
+  int64_t mps = cdiv64(cdiv64(M, ns), WBK) * WBK;
+  *nsplit = (int)cdiv64(M, mps);
+  *m_per_split = (int)mps;
+}
+
+MOPA_API size_t mopa_conv2d_wgrad_workspace_bytes(const int32_t* geom_host) {
+  ConvGeom g;
+  memcpy(&g, geom_host, sizeof(g));
+  int ns, mps;
+  wgrad_split(g, &ns, &mps);
+  return align_up((size_t)ns * g.TH * g.TW * g.Cin * g.Cout * sizeof(float), 256);
+}
+
+// dweight[TH*TW][Cin][Cout] (logical taps, already in the igemm weight layout) (+)= sum_m A^T dY.
+MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dweight, const int32_t* geom_host,
+                                    int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+  ConvGeom g;
+  memcpy(&g, geom_host, sizeof(g));
+  if ((g.Cin % 64 != 0 && g.Cin != 16) || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_conv2d_wgrad_workspace_bytes(geom_host)) return MOPA_ERR_WORKSPACE;
+  int ns, mps;
+  wgrad_split(g, &ns, &mps);
+  hipStream_t st = (hipStream_t)stream;
+  float* slabs = (float*)ws;
+  if (g.Cin >= 64) {
+    dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
+    k_conv2d_wgrad<64><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+  } else {
+    dim3 grid(g.TH * g.TW, g.Cout / 64, ns);
+    k_conv2d_wgrad<16><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+  }
+  const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
+  k_reduce_slabs2<<<stream_grid(n, 256), 256, 0, st>>>(slabs, ns, n, dweight, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight re-layout between the parameter layout of torch (state_dict compatible) and the igemm layout.
+//   mode 0: conv   OIHW (O,I,kh,kw) -> [kh][kw][I][O]           (forward)
+//   mode 1: conv   OIHW             -> [kh][kw][O][I]           (backward-data; taps NOT flipped: the index map does it)
+//   mode 2: convT  IOHW (I,O,kh,kw) -> [kh][kw][I][O]           (forward)
+//   mode 3: convT  IOHW             -> [kh][kw][O][I]           (backward-data)
+// dst is indexed [kh][kw][R][C]; inverse = 1 scatters a gradient in igemm layout back to the parameter layout
+// (modes 0 and 2 only).
+__global__ void k_relayout_w(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int KH, int KW, int mode,
+                             int inverse, int accumulate) {
+  const int64_t n = (int64_t)O * I * KH * KW;
+  const int R = (mode == 0 || mode == 2) ? I : O, C = (mode == 0 || mode == 2) ? O : I;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes the igemm layout [kh][kw][R][C]
+    const int c = (int)(i % C);
+    int64_t r1 = i / C;
+    const int r = (int)(r1 % R);
+    r1 /= R;
+    const int kw = (int)(r1 % KW), kh = (int)(r1 / KW);
+    const int o = (mode == 0 || mode == 2) ? c : r, ii = (mode == 0 || mode == 2) ? r : c;
+    const int64_t p = (mode < 2) ? (((int64_t)o * I + ii) * KH + kh) * KW + kw   // OIHW
+                                 : (((int64_t)ii * O + o) * KH + kh) * KW + kw;  // IOHW
+    if (!inverse) dst[i] = src[p];
+    else dst[p] = (accumulate ? dst[p] : 0.f) + src[i];
+  }
+}
+
+MOPA_API int mopa_conv2d_relayout_weight(const float* src, float* dst, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                                         int32_t mode, int32_t inverse, int32_t accumulate, void* stream) {
+  if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || mode < 0 || mode > 3 || (inverse && (mode & 1))) return MOPA_ERR_ARG;
+  k_relayout_w<<<stream_grid((int64_t)O * I * KH * KW, 256), 256, 0, (hipStream_t)stream>>>(src, dst, O, I, KH, KW, mode,
+                                                                                            inverse, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// Stem (conv1 7x7, Cin=3): weights OIHW (64,3,7,7) <-> igemm layout [7][2][16][64] where tap (kh, tx) covers
+// kw = 4*tx .. 4*tx+3 and channel slot 4 (kw=7 and c=3 are zero).  inverse = 1 maps a gradient back.
+__global__ void k_stem_relayout(const float* __restrict__ src, float* __restrict__ dst, int O, int inverse, int accumulate) {
+  const int n = 7 * 2 * 16 * O;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = i % O;
+    int r = i / O;
+    const int k16 = r % 16; r /= 16;
+    const int tx = r % 2, kh = r / 2;
+    const int kw = 4 * tx + k16 / 4, c = k16 % 4;
+    const bool real = kw < 7 && c < 3;
+    const int p = ((o * 3 + c) * 7 + kh) * 7 + kw;
+    if (!inverse) dst[i] = real ? src[p] : 0.f;
+    else if (real) dst[p] = (accumulate ? dst[p] : 0.f) + src[i];
+  }
+}
+MOPA_API int mopa_conv2d_stem_relayout(const float* src, float* dst, int32_t O, int32_t inverse, int32_t accumulate, void* stream) {
+  if (O <= 0) return MOPA_ERR_ARG;
+  k_stem_relayout<<<stream_grid(7 * 2 * 16 * O, 256), 256, 0, (hipStream_t)stream>>>(src, dst, O, inverse, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// img NCHW (B,3,H,W) -> zero-padded NHWC4 (B, Hp+6, Wp+8, 4): 3 px of conv padding on top/left, 3 bottom,
+// 5 right (3 + 2 so the 16-float tap reads of the stem stay inside the row), channel 3 = 0;
+// (Hp,Wp) = (H,W) rounded up to 16 (resnet34_unet.py:133-138).
+__global__ void k_img_to_nhwc4(const float* __restrict__ img, int B, int H, int W, int Hp, int Wp, float* __restrict__ out) {
+  const int PH = Hp + 6, PW = Wp + 8;
+  const int64_t n = (int64_t)B * PH * PW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % PW) - 3;
+    const int64_t r = i / PW;
+    const int y = (int)(r % PH) - 3, b = (int)(r / PH);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const int64_t base = ((int64_t)b * 3 * H + y) * W + x;
+      v.x = img[base]; v.y = img[base + (int64_t)H * W]; v.z = img[base + 2 * (int64_t)H * W];
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+MOPA_API int mopa_img_to_nhwc4(const float* img, int32_t B, int32_t H, int32_t W, int32_t Hp, int32_t Wp, float* out, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Hp < H || Wp < W) return MOPA_ERR_ARG;
+  k_img_to_nhwc4<<<stream_grid((int64_t)B * (Hp + 6) * (Wp + 8), 256), 256, 0, (hipStream_t)stream>>>(img, B, H, W, Hp, Wp, out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

@@ -43,44 +43,54 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
   }
 }
 
-// One block; thread per channel.  Writes scale/shift (y = x*scale + shift), mean, invstd; updates running stats.
-__global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, const float* __restrict__ x0, int A, int C,
+// One block of 256; each wave reduces the block partials of its channels (lanes stride over blocks), then lane 0
+// writes scale/shift (y = x*scale + shift), mean, invstd and updates the running statistics.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int nblk, const float* __restrict__ x0, int A, int C,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                               float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = wv; c < C; c += 4) {
     float mean, var;
     if (training) {
       double s = 0.0, ss = 0.0;
-      for (int b = 0; b < nblk; ++b) {
+      for (int b = lane; b < nblk; b += 64) {
         s += (double)partial[(int64_t)b * 2 * C + c];
         ss += (double)partial[(int64_t)b * 2 * C + C + c];
       }
+      s = wave_sum_d(s);
+      ss = wave_sum_d(ss);
       const double m = s / A;
       double v = ss / A - m * m;
       if (v < 0) v = 0;
       mean = (float)((double)x0[c] + m);
       var = (float)v;
-      const float unbiased = (float)(v * ((double)A / (double)(A > 1 ? A - 1 : 1)));
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      if (lane == 0) {
+        const float unbiased = (float)(v * ((double)A / (double)(A > 1 ? A - 1 : 1)));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
     } else {
       mean = running_mean[c];
       var = running_var[c];
     }
-    const float invstd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    save_mean[c] = mean;
-    save_invstd[c] = invstd;
+    if (lane == 0) {
+      const float invstd = 1.0f / sqrtf(var + eps);
+      const float sc = gamma[c] * invstd;
+      scale[c] = sc;
+      shift[c] = beta[c] - mean * sc;
+      save_mean[c] = mean;
+      save_invstd[c] = invstd;
+    }
   }
 }
 
+// y = act(x*scale + shift (+ res));  act: 0 = identity, 1 = leaky-ReLU(leak)
 __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                         int ldy, int A, int C, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float leak) {
+                                                        const float* __restrict__ shift, float leak,
+                                                        const float* __restrict__ res, int ld_res, int act) {
   const int CQ = C >> 2;
   const int64_t total = (int64_t)A * CQ;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -90,8 +100,14 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
     const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
-    o.x = o.x > 0.f ? o.x : o.x * leak; o.y = o.y > 0.f ? o.y : o.y * leak;
-    o.z = o.z > 0.f ? o.z : o.z * leak; o.w = o.w > 0.f ? o.w : o.w * leak;
+    if (res) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)row * ld_res + cq * 4);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    if (act) {
+      o.x = o.x > 0.f ? o.x : o.x * leak; o.y = o.y > 0.f ? o.y : o.y * leak;
+      o.z = o.z > 0.f ? o.z : o.z * leak; o.w = o.w > 0.f ? o.w : o.w * leak;
+    }
     *reinterpret_cast<float4*>(y + (int64_t)row * ldy + cq * 4) = o;
   }
 }
@@ -100,12 +116,14 @@ MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
   return align_up((size_t)cdiv64(num_rows, BN_ROWS_PER_BLOCK) * 2 * C * sizeof(float), 256);
 }
 
-// y = leaky_relu(batchnorm(x)).  stats[4][C] receives scale, shift, mean, invstd (saved for backward).
-MOPA_API int mopa_bnrelu_rows_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
-                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                  float momentum, float eps, float leak, int32_t training, float* stats, void* ws,
-                                  size_t ws_bytes, void* stream) {
+// y = act(batchnorm(x) (+ res)).  stats[4][C] receives scale, shift, mean, invstd (saved for backward).
+// act: 0 identity / 1 leaky-ReLU(leak).  res (optional) is added before the activation (ResNet BasicBlock tail).
+MOPA_API int mopa_bn_act_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float leak, int32_t act, const float* res, int32_t ld_res,
+                             int32_t training, float* stats, void* ws, size_t ws_bytes, void* stream) {
   if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
+  if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
   float* partial = (float*)ws;
@@ -118,16 +136,32 @@ MOPA_API int mopa_bnrelu_rows_fwd(const float* x, int32_t ldx, float* y, int32_t
   k_bn_finalize<<<1, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
                                    eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
   k_bn_relu_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
-                                                                                  stats + C, leak);
+                                                                                  stats + C, leak, res, ld_res, act);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
 
+MOPA_API int mopa_bnrelu_rows_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, float leak, int32_t training, float* stats, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  return mopa_bn_act_fwd(x, ldx, y, ldy, num_rows, C, gamma, beta, running_mean, running_var, momentum, eps, leak, 1,
+                         nullptr, 0, training, stats, ws, ws_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------ BN backward
-// dz = dy * (y > 0 ? 1 : leak) with y recomputed from x; partial sums of dz and dz*xhat.
+// dz = dy * act'(.)  where the activation mask comes from the saved output y (ymask, needed when a residual was
+// added) or is recomputed from x (ymask == null).  act == 0: dz = dy.  Partial sums of dz and dz*xhat.
+__device__ __forceinline__ float bn_dz(float g, float xv, float sc, float sh, float leak, int act, const float* ym, int j) {
+  if (!act) return g;
+  const float yv = ym ? ym[j] : fmaf(xv, sc, sh);
+  return yv > 0.f ? g : g * leak;
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, int ld_dy,
                                                          const float* __restrict__ x, int ldx, int A, int C,
                                                          const float* __restrict__ stats, float leak,
+                                                         const float* __restrict__ ymask, int ld_ym, int act,
                                                          float* __restrict__ partial) {
   extern __shared__ float lds[];
   const int CQ = C >> 2;
@@ -145,11 +179,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     for (int row = rbeg + rl; row < rend; row += RL) {
       const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
       const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ymask) yv = *reinterpret_cast<const float4*>(ymask + (int64_t)row * ld_ym + cq * 4);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float yv = fmaf(xs[j], sc[j], sh[j]);
-        const float dz = yv > 0.f ? gs[j] : gs[j] * leak;
+        const float dz = bn_dz(gs[j], xs[j], sc[j], sh[j], leak, act, ymask ? ys : nullptr, j);
         s[j] += dz;
         ss[j] += dz * ((xs[j] - mu[j]) * is[j]);
       }
@@ -170,40 +205,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
 }
 
 // dgamma/dbeta (+= if accumulate) and the two per-channel means used by the apply pass (coef[2][C]).
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int A, int C, float* __restrict__ dgamma,
-                                  float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int A, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                          float* __restrict__ coef) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = wv; c < C; c += 4) {
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
       s += (double)partial[(int64_t)b * 2 * C + c];
       ss += (double)partial[(int64_t)b * 2 * C + C + c];
     }
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
-    coef[c] = (float)(s / A);
-    coef[C + c] = (float)(ss / A);
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    if (lane == 0) {
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+      coef[c] = (float)(s / A);
+      coef[C + c] = (float)(ss / A);
+    }
   }
 }
 
 // training: dx = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = scale * dz.   dx (+)= if acc_dx.
+// dres (optional) receives dz, the gradient of the residual input (+= if acc_dres).
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x,
                                                        int ldx, float* __restrict__ dx, int ld_dx, int A, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ coef,
-                                                       float leak, int training, int acc_dx) {
+                                                       float leak, int training, int acc_dx, const float* __restrict__ ymask,
+                                                       int ld_ym, int act, float* __restrict__ dres, int ld_dres, int acc_dres) {
   const int CQ = C >> 2;
   const int64_t total = (int64_t)A * CQ;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
     const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
     const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    float o[4];
+    float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ymask) yv = *reinterpret_cast<const float4*>(ymask + (int64_t)row * ld_ym + cq * 4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+    float o[4], dzv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = cq * 4 + j;
       const float sc = stats[c], sh = stats[C + c];
-      const float yv = fmaf(xs[j], sc, sh);
-      const float dz = yv > 0.f ? gs[j] : gs[j] * leak;
+      const float dz = bn_dz(gs[j], xs[j], sc, sh, leak, act, ymask ? ys : nullptr, j);
+      dzv[j] = dz;
       if (training) {
         const float xhat = (xs[j] - stats[2 * C + c]) * stats[3 * C + c];
         o[j] = sc * (dz - coef[c] - xhat * coef[C + c]);
@@ -217,32 +262,53 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
     }
     *dp = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) {
+      float4* rp = reinterpret_cast<float4*>(dres + (int64_t)row * ld_dres + cq * 4);
+      if (acc_dres) {
+        const float4 p = *rp;
+        dzv[0] += p.x; dzv[1] += p.y; dzv[2] += p.z; dzv[3] += p.w;
+      }
+      *rp = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+    }
   }
+}
+
+MOPA_API size_t mopa_bnrelu_rows_bwd_workspace_bytes(int32_t num_rows, int32_t C) {
+  return mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+// General backward of mopa_bn_act_fwd.  ymask: the forward output y (required when a residual was added; optional
+// otherwise).  dres: gradient of the residual input (optional).
+MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
+                             int32_t num_rows, int32_t C, const float* stats, float leak, int32_t act,
+                             const float* ymask, int32_t ld_ym, float* dres, int32_t ld_dres, int32_t accumulate_dres,
+                             int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads,
+                             int32_t accumulate_dx, void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3))
+    return MOPA_ERR_ARG;
+  if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_bnrelu_rows_bwd_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
+  float* partial = (float*)ws;
+  float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
+  const int RL = 256 / (C >> 2);
+  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask,
+                                                                          ld_ym, act, partial);
+  k_bn_bwd_finalize<<<1, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
+  k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(
+      dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
+      ld_dres, accumulate_dres);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
 }
 
 MOPA_API int mopa_bnrelu_rows_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
                                   int32_t num_rows, int32_t C, const float* stats, float leak, int32_t training,
                                   float* dgamma, float* dbeta, int32_t accumulate_param_grads, int32_t accumulate_dx,
                                   void* ws, size_t ws_bytes, void* stream) {
-  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3))
-    return MOPA_ERR_ARG;
-  const size_t need = mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
-  if (ws_bytes < need) return MOPA_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
-  float* partial = (float*)ws;
-  float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
-  const int RL = 256 / (C >> 2);
-  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, partial);
-  k_bn_bwd_finalize<<<1, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
-  k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C,
-                                                                                 stats, coef, leak, training, accumulate_dx);
-  MOPA_CHECK_LAUNCH();
-  return MOPA_OK;
-}
-
-MOPA_API size_t mopa_bnrelu_rows_bwd_workspace_bytes(int32_t num_rows, int32_t C) {
-  return mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
+  return mopa_bn_act_bwd(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, leak, 1, nullptr, 0, nullptr, 0, 0, training,
+                         dgamma, dbeta, accumulate_param_grads, accumulate_dx, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------ InputLayer mode 4

@@ -1,0 +1,424 @@
+"""Host side of the 2D image branch: UNetResNet34 + Net2DSeg heads as ONE autograd node over the C-ABI kernels.
+
+What it replaces: the torch.nn / cuDNN graph of ``mopa/models/resnet34_unet.py:131-191`` and the heads / point
+gather of ``mopa/models/xmuda_arch.py:49-79``.  Activations are NHWC fp32 (``[B*H*W, C]`` row-major, optionally a
+column slice of a wider buffer, which is how the decoder's ``torch.cat([skip, up])`` disappears); parameters keep
+torch's layouts and names (``state_dict`` compatible) and are re-laid-out for the implicit-GEMM kernels on the fly.
+Oracle: ``oracle/net2d.py``; golden fixture G1.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import call, ptr, query, stream, workspace
+from .sparse3d import View
+
+BN_EPS = 1e-5       # torch.nn.BatchNorm2d defaults
+BN_MOMENTUM = 0.1
+DEBUG = None  # tests may set this to a dict to capture intermediate gradients
+LAYERS = [("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2), ("layer4", 512, 3, 2)]
+
+
+def _ws(n, dev):
+    return workspace.get(max(int(n), 256), dev)
+
+
+class Img(View):
+    """NHWC activation: rows = B*H*W pixels, C channels at column offset `col` of tensor t (ld = t.shape[1])."""
+
+    __slots__ = ("B", "H", "W")
+
+    def __init__(self, t, B, H, W, col=0, C=None):
+        super().__init__(t, col, C)
+        self.B, self.H, self.W = B, H, W
+
+
+def new_img(B, H, W, C, dev, ld=None, zero=False):
+    alloc = torch.zeros if zero else torch.empty
+    return Img(alloc(B * H * W, ld or C, dtype=torch.float32, device=dev), B, H, W, 0, C)
+
+
+def _geom(**kw):
+    order = ["B", "IH", "IW", "OHl", "OWl", "OHa", "OWa", "OS", "OOY", "OOX", "IS", "IY0", "IX0", "IDY", "IDX",
+             "TH", "TW", "KH0", "KW0", "KS", "KWF", "Cin", "Cout", "ld_in", "ld_out"]
+    d = dict(OS=1, OOY=0, OOX=0, IS=1, IY0=0, IX0=0, IDY=1, IDX=1, KH0=0, KW0=0, KS=1)
+    d.update(kw)
+    return (ctypes.c_int32 * 25)(*[int(d[k]) for k in order])
+
+
+def igemm(x_ptr, w, bias, out_ptr, geom, accumulate=False):
+    call("mopa_conv2d_igemm", x_ptr, ptr(w), ptr(bias), out_ptr, ctypes.addressof(geom), int(accumulate), stream())
+
+
+def wgrad(x_ptr, dy_ptr, dw_ptr, geom, dev, accumulate=False):
+    wsb = query("mopa_conv2d_wgrad_workspace_bytes", ctypes.addressof(geom))
+    ws = _ws(wsb, dev)
+    call("mopa_conv2d_bwd_weight", x_ptr, dy_ptr, dw_ptr, ctypes.addressof(geom), int(accumulate), ptr(ws), ws.numel(),
+         stream())
+
+
+def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
+    call("mopa_conv2d_relayout_weight", ptr(src), ptr(dst), O, I, KH, KW, mode, int(inverse), int(accumulate), stream())
+
+
+# ------------------------------------------------------------------------------------------------ conv wrappers
+class ConvOp:
+    """Conv2d(k, stride s, padding p) in NHWC through the implicit-GEMM kernels (fwd, dgrad, wgrad)."""
+
+    def __init__(self, weight, bias, k, s, p):
+        self.w, self.b, self.k, self.s, self.p = weight, bias, k, s, p
+        self.O, self.I = weight.shape[0], weight.shape[1]
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.p - self.k) // self.s + 1, (W + 2 * self.p - self.k) // self.s + 1
+
+    def _fwd_geom(self, x: Img, out: Img):
+        return _geom(B=x.B, IH=x.H, IW=x.W, OHl=out.H, OWl=out.W, OHa=out.H, OWa=out.W, IS=self.s, IY0=-self.p,
+                     IX0=-self.p, TH=self.k, TW=self.k, KWF=self.k, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
+
+    def forward(self, x: Img, out: Img):
+        wl = torch.empty(self.k, self.k, self.I, self.O, dtype=torch.float32, device=self.w.device)
+        relayout(self.w, wl, self.O, self.I, self.k, self.k, 0)
+        igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
+
+    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool):
+        dev = self.w.device
+        k, s, p = self.k, self.s, self.p
+        # weight gradient in igemm layout, then scattered back to OIHW
+        dwl = torch.empty(k, k, self.I, self.O, dtype=torch.float32, device=dev)
+        wgrad(x.p, dout.p, ptr(dwl), self._fwd_geom(x, dout), dev)
+        relayout(dwl, dw, self.O, self.I, k, k, 0, inverse=True)
+        if db is not None:
+            colsum(dout, db)
+        if dx is None:
+            return
+        wt = torch.empty(k, k, self.O, self.I, dtype=torch.float32, device=dev)
+        relayout(self.w, wt, self.O, self.I, k, k, 1)
+        if s == 1:
+            g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IY0=p, IX0=p, IDY=-1, IDX=-1,
+                      TH=k, TW=k, KWF=k, Cin=self.O, Cout=self.I, ld_in=dout.ld, ld_out=dx.ld)
+            igemm(dout.p, wt, None, dx.p, g, acc_dx)
+            return
+        assert s == 2
+        if not acc_dx:
+            dx.dense().zero_() if dx.C != dx.ld else dx.t.zero_()
+        for ph in range(2):
+            for pw in range(2):
+                khs = [kh for kh in range(k) if (ph + p - kh) % 2 == 0]
+                kws = [kw for kw in range(k) if (pw + p - kw) % 2 == 0]
+                ohl, owl = (x.H - ph + 1) // 2, (x.W - pw + 1) // 2
+                if not khs or not kws or ohl <= 0 or owl <= 0:
+                    continue
+                g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=ohl, OWl=owl, OHa=x.H, OWa=x.W, OS=2, OOY=ph, OOX=pw,
+                          IY0=(ph + p - khs[0]) // 2, IX0=(pw + p - kws[0]) // 2, IDY=-1, IDX=-1, TH=len(khs),
+                          TW=len(kws), KH0=khs[0], KW0=kws[0], KS=2, KWF=k, Cin=self.O, Cout=self.I, ld_in=dout.ld,
+                          ld_out=dx.ld)
+                igemm(dout.p, wt, None, dx.p, g, True)
+
+
+class ConvTOp:
+    """ConvTranspose2d(k=2, s=2) + bias: 4 output-parity classes of a 1x1 conv."""
+
+    def __init__(self, weight, bias):
+        self.w, self.b = weight, bias
+        self.I, self.O = weight.shape[0], weight.shape[1]
+
+    def _geom(self, x: Img, out: Img, ky, kx):
+        return _geom(B=x.B, IH=x.H, IW=x.W, OHl=x.H, OWl=x.W, OHa=out.H, OWa=out.W, OS=2, OOY=ky, OOX=kx, TH=1, TW=1,
+                     KH0=ky, KW0=kx, KWF=2, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
+
+    def forward(self, x: Img, out: Img):
+        wl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=self.w.device)
+        relayout(self.w, wl, self.O, self.I, 2, 2, 2)
+        for ky in range(2):
+            for kx in range(2):
+                igemm(x.p, wl, self.b, out.p, self._geom(x, out, ky, kx))
+
+    def backward(self, x: Img, dout: Img, dx: Img, dw, db):
+        dev = self.w.device
+        dwl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=dev)
+        for ky in range(2):
+            for kx in range(2):
+                g = self._geom(x, dout, ky, kx)
+                g[17], g[18] = 0, 0  # KH0/KW0: the per-class launch writes a single-tap slab
+                wgrad(x.p, dout.p, ptr(dwl, (ky * 2 + kx) * self.I * self.O), g, dev)
+        relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True)
+        colsum(dout, db)
+        wt = torch.empty(2, 2, self.O, self.I, dtype=torch.float32, device=dev)
+        relayout(self.w, wt, self.O, self.I, 2, 2, 3)
+        g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IS=2, TH=2, TW=2, KWF=2,
+                  Cin=self.O, Cout=self.I, ld_in=dout.ld, ld_out=dx.ld)
+        igemm(dout.p, wt, None, dx.p, g, False)
+
+
+def colsum(x: View, out: torch.Tensor, accumulate=False):
+    wsb = query("mopa_colsum_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, out.device)
+    call("mopa_colsum", x.p, x.ld, x.rows, x.C, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream())
+
+
+def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
+    wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bn_act_fwd", x.p, x.ld, y.p, y.ld, x.rows, x.C, ptr(P[name + ".weight"]), ptr(P[name + ".bias"]),
+         ptr(P[name + ".running_mean"]), ptr(P[name + ".running_var"]), BN_MOMENTUM, BN_EPS, 0.0, int(act),
+         res.p if res is not None else None, res.ld if res is not None else 0, int(training), ptr(stats), ptr(ws),
+         ws.numel(), stream())
+
+
+def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, acc_dx=False):
+    wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bn_act_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), 0.0, int(act),
+         ymask.p if ymask is not None else None, ymask.ld if ymask is not None else 0,
+         dres.p if dres is not None else None, dres.ld if dres is not None else 0, int(acc_dres), int(training),
+         ptr(dgamma), ptr(dbeta), 0, int(acc_dx), ptr(ws), ws.numel(), stream())
+
+
+# ------------------------------------------------------------------------------------------------ the network
+class Net2DFunction(torch.autograd.Function):
+    """img (B,3,H,W) -> feats (N,64), seg_logit, seg_logit2, seg_logit_all (B,H,W,C) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, spec, img, point_pix, training, drop_p, drop_seed, *flat):
+        dev = img.device
+        P = dict(zip(spec.order, flat))
+        pre = "net_2d."
+        B, _, H, W = img.shape
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        tape = []
+        ctx.bn_names = []
+
+        def bn(name, x, act=1, res=None, out=None):
+            y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
+            stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
+            bn_fwd(x, y, P, name, act, res, training, stats)
+            if training:
+                P[name + ".num_batches_tracked"].add_(1)
+            tape.append(("bn", name, x, y, stats, act, res))
+            return y
+
+        def conv(name, x, k, s, p, bias=False, out=None):
+            op = ConvOp(P[name + ".weight"], P[name + ".bias"] if bias else None, k, s, p)
+            oh, ow = op.out_hw(x.H, x.W)
+            out = out if out is not None else new_img(x.B, oh, ow, op.O, dev)
+            op.forward(x, out)
+            tape.append(("conv", name, op, x, out))
+            return out
+
+        def convT(name, x):
+            op = ConvTOp(P[name + ".weight"], P[name + ".bias"])
+            out = new_img(x.B, 2 * x.H, 2 * x.W, op.O, dev)
+            op.forward(x, out)
+            tape.append(("convT", name, op, x, out))
+            return out
+
+        def dropout(x, site, out=None):
+            y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
+            p = drop_p if training else 0.0
+            call("mopa_dropout_rows", x.p, x.ld, y.p, y.ld, x.rows, x.C, float(p), drop_seed * 2 + site, stream())
+            tape.append(("dropout", site, x, y, p))
+            return y
+
+        # ---- stem (resnet34_unet.py:144-148): conv1 7x7 s1 p3 on the /16-padded image, bn1, relu, maxpool
+        x4 = torch.empty(B, Hp + 6, Wp + 8, 4, dtype=torch.float32, device=dev)
+        imgc = img.contiguous().float()
+        call("mopa_img_to_nhwc4", ptr(imgc), B, H, W, Hp, Wp, ptr(x4), stream())
+        w1 = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
+        call("mopa_conv2d_stem_relayout", ptr(P[pre + "conv1.weight"]), ptr(w1), 64, 0, 0, stream())
+        c1 = new_img(B, Hp, Wp, 64, dev)
+        stem_g = _geom(B=B, IH=Hp + 6, IW=Wp + 8, OHl=Hp, OWl=Wp, OHa=Hp, OWa=Wp, IDX=4, TH=7, TW=2, KWF=2, Cin=16,
+                       Cout=64, ld_in=4, ld_out=64)
+        igemm(ptr(x4), w1, None, c1.p, stem_g)
+        tape.append(("stem", x4, c1, stem_g))
+        J = {}  # join buffers: [skip | upsampled]
+        J[0] = torch.empty(B * Hp * Wp, 128, dtype=torch.float32, device=dev)
+        skip0 = bn(pre + "bn1", c1, out=Img(J[0], B, Hp, Wp, 0, 64))
+        H2, W2 = Hp // 2, Wp // 2
+        x = new_img(B, H2, W2, 64, dev)
+        amax = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)
+        call("mopa_maxpool3x3s2_fwd", skip0.p, skip0.ld, B, Hp, Wp, 64, x.p, x.ld, ptr(amax), stream())
+        tape.append(("maxpool", skip0, x, amax))
+        # ---- encoder stages
+        for li, (lname, c, nblocks, stride) in enumerate(LAYERS):
+            for b in range(nblocks):
+                q = f"{pre}{lname}.{b}."
+                s = stride if b == 0 else 1
+                has_ds = (q + "downsample.0.weight") in P
+                y1 = bn(q + "bn1", conv(q + "conv1", x, 3, s, 1))
+                z = conv(q + "conv2", y1, 3, 1, 1)
+                idt = bn(q + "downsample.1", conv(q + "downsample.0", x, 1, s, 0), act=0) if has_ds else x
+                last = b == nblocks - 1
+                out = None
+                if last and lname in ("layer1", "layer2"):
+                    lvl = li + 1
+                    J[lvl] = torch.empty(z.rows, 2 * c, dtype=torch.float32, device=dev)
+                    out = Img(J[lvl], z.B, z.H, z.W, 0, c)
+                tape.append(("block_in", x))
+                x = bn(q + "bn2", z, act=1, res=idt, out=out)
+            if lname == "layer3":   # dropout, then the result is skip3 AND layer4's input (:153-155)
+                J[3] = torch.empty(x.rows, 2 * c, dtype=torch.float32, device=dev)
+                x = dropout(x, 0, out=Img(J[3], x.B, x.H, x.W, 0, c))
+            if lname == "layer4":
+                x = dropout(x, 1)
+        # ---- decoder (:165-182): ConvT+BN+ReLU into the right half of the join buffer, conv3x3 on [skip | up]
+        for stage, lvl in (("5", 3), ("4", 2), ("3", 1), ("2", 0)):
+            tname = f"{pre}dec_t_conv_stage{stage}."
+            up_raw = convT(tname + "0", x)
+            cj = J[lvl].shape[1] // 2
+            bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
+            joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
+            tape.append(("join", lvl, cj))
+            if lvl == 0:
+                x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
+            else:
+                cname = f"{pre}dec_conv_stage{int(stage) - 1}."
+                x = bn(cname + "1", conv(cname + "0", joined, 3, 1, 1, bias=True))
+        feat = x  # (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
+        # ---- heads (xmuda_arch.py:58-77)
+        C = spec.num_classes
+        pred_all = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        call("mopa_pixel_head_fwd", feat.p, feat.ld, B, Hp, Wp, H, W, 64, C, ptr(P["linear.weight"]),
+             ptr(P["linear.bias"]), ptr(pred_all), stream())
+        N = point_pix.numel()
+        feats = torch.empty(N, 64, dtype=torch.float32, device=dev)
+        l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
+        l2 = torch.empty(N, C if spec.dual_head else 0, dtype=torch.float32, device=dev)
+        if N > 0:
+            call("mopa_output_layer_heads_fwd", feat.p, feat.ld, ptr(point_pix), N, 64, C, ptr(P["linear.weight"]),
+                 ptr(P["linear.bias"]), ptr(P["linear2.weight"]) if spec.dual_head else None,
+                 ptr(P["linear2.bias"]) if spec.dual_head else None, ptr(feats), ptr(l1),
+                 ptr(l2) if spec.dual_head else None, stream())
+        ctx.spec, ctx.P, ctx.tape, ctx.J, ctx.training = spec, P, tape, J, training
+        if DEBUG is not None:
+            DEBUG.update({f"J{k}": v.clone() for k, v in J.items()})
+        ctx.feat, ctx.feats, ctx.point_pix, ctx.dims = feat, feats, point_pix, (B, H, W, Hp, Wp, N)
+        ctx.drop_seed = drop_seed
+        return feats, l1, l2, pred_all
+
+    @staticmethod
+    def backward(ctx, dfeats, dl1, dl2, dpred):
+        spec, P, tape, J = ctx.spec, ctx.P, ctx.tape, ctx.J
+        B, H, W, Hp, Wp, N = ctx.dims
+        feat = ctx.feat
+        dev = feat.t.device
+        C = spec.num_classes
+        pre = "net_2d."
+        grads = {k: None for k in spec.order}
+
+        def gbuf(name):
+            g = torch.empty_like(P[name])
+            grads[name] = g
+            return g
+
+        def cont(t):
+            return None if t is None else t.contiguous().float()
+
+        dfeats, dl1, dpred = cont(dfeats), cont(dl1), cont(dpred)
+        dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
+        # ---- heads: d(feat) = point-head part (dense over all pixels, zeros where no point) + full-image part
+        dfeat = new_img(B, Hp, Wp, 64, dev)
+        head_w_acc = False
+        if N > 0 and (dfeats is not None or dl1 is not None or dl2 is not None):
+            rows = B * Hp * Wp
+            row_start = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+            row_points = torch.empty(N, dtype=torch.int32, device=dev)
+            ws = _ws(query("mopa_points_csr_workspace_bytes", rows), dev)
+            call("mopa_points_csr", ptr(ctx.point_pix), N, rows, ptr(row_start), ptr(row_points), ptr(ws), ws.numel(),
+                 stream())
+            ws = _ws(query("mopa_output_layer_heads_bwd_workspace_bytes", N, 64, C), dev)
+            dw1 = gbuf("linear.weight") if dl1 is not None else None
+            db1 = gbuf("linear.bias") if dl1 is not None else None
+            dw2 = gbuf("linear2.weight") if dl2 is not None else None
+            db2 = gbuf("linear2.bias") if dl2 is not None else None
+            call("mopa_output_layer_heads_bwd", ptr(dfeats), ptr(dl1), ptr(dl2), ptr(ctx.feats), ptr(P["linear.weight"]),
+                 ptr(P["linear2.weight"]) if spec.dual_head else None, ptr(row_start), ptr(row_points), rows, N, 64, C,
+                 dfeat.p, dfeat.ld, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), 0, ptr(ws), ws.numel(), stream())
+            head_w_acc = dl1 is not None
+        else:
+            dfeat.t.zero_()
+        if dpred is not None:
+            if not head_w_acc:
+                gbuf("linear.weight"); gbuf("linear.bias")
+            ws = _ws(query("mopa_pixel_head_bwd_workspace_bytes", B, H, W, 64, C), dev)
+            call("mopa_pixel_head_bwd", ptr(dpred), feat.p, feat.ld, B, Hp, Wp, H, W, 64, C, ptr(P["linear.weight"]),
+                 dfeat.p, dfeat.ld, 1, ptr(grads["linear.weight"]), ptr(grads["linear.bias"]), int(head_w_acc), ptr(ws),
+                 ws.numel(), stream())
+
+        gmap = {}
+
+        def key(v):
+            return (v.t.data_ptr(), v.col, v.C)
+
+        def like(v: Img, zero=False):
+            return new_img(v.B, v.H, v.W, v.C, dev, zero=zero)
+
+        gmap[key(feat)] = dfeat
+        dJ = {}  # gradient buffers of the join tensors (full width)
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "bn":
+                _, name, x, y, stats, act, res = rec
+                dy = gmap.pop(key(y))
+                dres = None
+                acc_dres = False
+                if res is not None:
+                    k = key(res)
+                    if k in gmap:
+                        dres, acc_dres = gmap[k], True
+                    else:
+                        dres = like(res)
+                        gmap[k] = dres
+                dx = like(x)
+                gmap[key(x)] = dx
+                bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training,
+                       gbuf(name + ".weight"), gbuf(name + ".bias"))
+            elif kind == "conv":
+                _, name, op, x, out = rec
+                dout = gmap.pop(key(out))
+                k = key(x)
+                acc = k in gmap
+                dx = gmap[k] if acc else like(x)
+                gmap[k] = dx
+                op.backward(x, dout, dx, gbuf(name + ".weight"), gbuf(name + ".bias") if op.b is not None else None, acc)
+            elif kind == "convT":
+                _, name, op, x, out = rec
+                dout = gmap.pop(key(out))
+                dx = like(x)
+                gmap[key(x)] = dx
+                op.backward(x, dout, dx, gbuf(name + ".weight"), gbuf(name + ".bias"))
+            elif kind == "join":
+                _, lvl, cj = rec
+                full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
+                dJ[lvl] = full
+                if DEBUG is not None:
+                    DEBUG[f"dJ{lvl}"] = full.t.clone()
+                gmap[(J[lvl].data_ptr(), 0, cj)] = Img(full.t, full.B, full.H, full.W, 0, cj)
+                gmap[(J[lvl].data_ptr(), cj, cj)] = Img(full.t, full.B, full.H, full.W, cj, cj)
+            elif kind == "dropout":
+                _, site, x, y, p = rec
+                dy = gmap.pop(key(y))
+                dx = like(x)
+                gmap[key(x)] = dx
+                call("mopa_dropout_rows", dy.p, dy.ld, dx.p, dx.ld, x.rows, x.C, float(p), ctx.drop_seed * 2 + site,
+                     stream())
+            elif kind == "maxpool":
+                _, x, y, amax = rec
+                dy = gmap.pop(key(y))
+                k = key(x)
+                acc = k in gmap
+                dx = gmap[k] if acc else like(x)
+                gmap[k] = dx
+                call("mopa_maxpool3x3s2_bwd", dy.p, dy.ld, ptr(amax), x.B, x.H, x.W, x.C, dx.p, dx.ld, int(acc), stream())
+            elif kind == "stem":
+                _, x4, c1, g = rec
+                dout = gmap.pop(key(c1))
+                dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
+                wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
+                call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(gbuf(pre + "conv1.weight")), 64, 1, 0, stream())
+            elif kind == "block_in":
+                pass
+        return (None, None, None, None, None, None) + tuple(grads[k] for k in spec.order)

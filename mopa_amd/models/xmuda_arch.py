@@ -10,7 +10,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import sparse3d
+import numpy as np
+
+from .. import dense2d, sparse3d
+from .resnet34_unet import UNetResNet34
 from .scn_unet import UNetSCN
 
 
@@ -24,6 +27,70 @@ def _require_cuda(module: nn.Module):
     if dev.type != "cuda":
         raise RuntimeError("mopa_amd models run on an MI355X only: call .cuda() first (no CPU fallback)")
     return dev
+
+
+class Net2DSeg(nn.Module):
+    """2D branch (xmuda_arch.py:22-79): UNetResNet34, full-image head, integer point gather, point head(s)."""
+
+    def __init__(self, num_classes, dual_head, backbone_2d, backbone_2d_kwargs, output_all=False):
+        super().__init__()
+        if backbone_2d != "UNetResNet34":
+            raise NotImplementedError("2D backbone {} not supported".format(backbone_2d))
+        self.net_2d = UNetResNet34(**dict(backbone_2d_kwargs))
+        feat_channels = 64
+        self.num_classes = num_classes
+        self.linear = nn.Linear(feat_channels, num_classes)
+        self.output_all = output_all
+        self.dual_head = dual_head
+        if dual_head:
+            self.linear2 = nn.Linear(feat_channels, num_classes)
+        self._order = None
+        self._calls = 0
+
+    @staticmethod
+    def pack_indices(img_indices, H, W, device):
+        """list of B (N_b,2) [row v, col u] arrays -> int32 pixel-row ids into the /16-padded NHWC feature map."""
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        rows = []
+        for b, idx in enumerate(img_indices):
+            idx = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+            idx = idx.astype(np.int64).reshape(-1, 2)
+            if idx.size and (idx.min() < 0 or idx[:, 0].max() >= H or idx[:, 1].max() >= W):
+                raise IndexError(f"img_indices of image {b} outside the {H}x{W} image")
+            rows.append((b * Hp + idx[:, 0]) * Wp + idx[:, 1])
+        flat = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        t = torch.from_numpy(flat.astype(np.int32))
+        return t.pin_memory().to(device, non_blocking=True) if t.numel() else t.to(device)
+
+    def forward(self, data_batch):
+        dev = _require_cuda(self)
+        img = data_batch["img"].to(dev, non_blocking=True)
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise RuntimeError(f"img must be (B,3,H,W), got {tuple(img.shape)}")
+        if img.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
+        H, W = img.shape[2], img.shape[3]
+        pix = data_batch.get("point_pix_2d")
+        if pix is None:
+            if len(data_batch["img_indices"]) != img.shape[0]:
+                raise IndexError("img_indices must hold one array per image")
+            pix = self.pack_indices(data_batch["img_indices"], H, W, dev)
+        if self._order is None:
+            self._order = [k for k, _ in self.named_parameters()] + [k for k, _ in self.named_buffers()]
+        spec = _Spec(order=self._order, num_classes=self.num_classes, dual_head=bool(self.dual_head))
+        tensors = dict(self.named_parameters())
+        tensors.update(dict(self.named_buffers()))
+        self._calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFF
+        feats, l1, l2, pred_all = dense2d.Net2DFunction.apply(spec, img, pix, self.training, float(self.net_2d.dropout.p),
+                                                             seed, *[tensors[k] for k in spec.order])
+        preds = {"feats": feats}
+        if self.output_all:
+            preds["seg_logit_all"] = pred_all
+        if self.dual_head:
+            preds["seg_logit2"] = l2
+        preds["seg_logit"] = l1
+        return preds
 
 
 class Net3DSeg(nn.Module):

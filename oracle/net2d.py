@@ -73,7 +73,7 @@ def _bn(P, name, x, training, relu=True):
 
 
 def unet_resnet34_forward(P: dict, img: torch.Tensor, *, training=True, dropout_p=0.4,
-                          dropout_masks=None, prefix="net_2d."):
+                          dropout_masks=None, prefix="net_2d.", taps=None):
     """UNetResNet34.forward (resnet34_unet.py:131-191).
 
     ``dropout_masks``: optional pair of keep-masks (already scaled by 1/(1-p))
@@ -115,6 +115,9 @@ def unet_resnet34_forward(P: dict, img: torch.Tensor, *, training=True, dropout_
         t = f"{p}dec_t_conv_stage{stage}."
         x = _bn(P, t + "1", F.conv_transpose2d(x, P[t + "0.weight"], P[t + "0.bias"], 2), training)
         x = torch.cat([skip, x], 1)
+        if taps is not None:
+            x.retain_grad() if x.requires_grad else None
+            taps["join" + stage] = x
         nxt = str(int(stage) - 1)
         if nxt == "1":
             x = F.conv2d(x, P[p + "dec_conv_stage1.weight"], P[p + "dec_conv_stage1.bias"], 1, 1)

@@ -1,0 +1,225 @@
+"""Parity of the HIP 2D branch (through the C-ABI) against torch-CPU functional ops and the reference-generated
+golden fixture G1.  fp32 tolerances: rtol 1e-4 / atol 1e-5 per op (relative to the tensor scale), network-level
+gradients 2e-3 of each tensor's max."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import net2d
+from oracle.params import det_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):  # (B,C,H,W) cpu -> Img on cuda
+    from mopa_amd.dense2d import Img
+    B, C, H, W = t.shape
+    return Img(t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().cuda(), B, H, W)
+
+
+def _nchw(img):
+    return img.dense().reshape(img.B, img.H, img.W, img.C).permute(0, 3, 1, 2).cpu()
+
+
+def _close(got, ref, rtol=1e-4, atol=2e-5):
+    ref = ref.detach().float().numpy() if torch.is_tensor(ref) else ref
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H,W", [(64, 64, 3, 1, 1, 19, 30), (64, 128, 3, 2, 1, 22, 36), (64, 128, 1, 2, 0, 22, 36),
+                                                (128, 64, 3, 1, 1, 16, 48), (256, 256, 3, 1, 1, 5, 7), (128, 256, 3, 2, 1, 9, 15)])
+def test_conv_fwd_dgrad_wgrad(cin, cout, k, s, p, H, W):
+    from mopa_amd.dense2d import ConvOp, Img, new_img
+    rng = np.random.Generator(np.random.PCG64(cin + cout + k))
+    B = 2
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W), dtype=np.float32))
+    w = torch.from_numpy(rng.standard_normal((cout, cin, k, k), dtype=np.float32) * 0.05)
+    b = torch.from_numpy(rng.standard_normal(cout, dtype=np.float32))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, s, p)
+    gout = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    (ref * gout.double()).sum().backward()
+    op = ConvOp(w.cuda(), b.cuda(), k, s, p)
+    # input lives in the right half of a wider (join) buffer
+    wide = torch.zeros(B * H * W, 2 * cin, device="cuda")
+    wide[:, cin:] = _nhwc(x).t
+    xi = Img(wide, B, H, W, cin, cin)
+    oh, ow = op.out_hw(H, W)
+    out = new_img(B, oh, ow, cout, "cuda")
+    op.forward(xi, out)
+    _close(_nchw(out), ref)
+    dx = new_img(B, H, W, cin, "cuda")
+    dx.t.fill_(1.0)
+    dw, db = torch.empty_like(op.w), torch.empty_like(op.b)
+    op.backward(xi, _nhwc(gout), dx, dw, db, acc_dx=True)
+    _close(_nchw(dx) - 1.0, xr.grad, rtol=1e-3, atol=1e-4)
+    _close(dw, wr.grad, rtol=1e-3, atol=1e-4)
+    _close(db, br.grad, rtol=1e-3, atol=1e-4)
+    dx2 = new_img(B, H, W, cin, "cuda")
+    op.backward(xi, _nhwc(gout), dx2, dw, db, acc_dx=False)
+    _close(_nchw(dx2), xr.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_conv_transpose_fwd_bwd():
+    from mopa_amd.dense2d import ConvTOp, new_img
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, cin, cout, H, W = 2, 128, 64, 7, 9
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W), dtype=np.float32))
+    w = torch.from_numpy(rng.standard_normal((cin, cout, 2, 2), dtype=np.float32) * 0.05)
+    b = torch.from_numpy(rng.standard_normal(cout, dtype=np.float32))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, 2)
+    gout = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    (ref * gout.double()).sum().backward()
+    op = ConvTOp(w.cuda(), b.cuda())
+    out = new_img(B, 2 * H, 2 * W, cout, "cuda")
+    xi = _nhwc(x)
+    op.forward(xi, out)
+    _close(_nchw(out), ref)
+    dx = new_img(B, H, W, cin, "cuda")
+    dw, db = torch.empty_like(op.w), torch.empty_like(op.b)
+    op.backward(xi, _nhwc(gout), dx, dw, db)
+    _close(_nchw(dx), xr.grad, rtol=1e-3, atol=1e-4)
+    _close(dw, wr.grad, rtol=1e-3, atol=1e-4)
+    _close(db, br.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_maxpool_and_residual_bn():
+    from mopa_amd._lib import call, ptr, stream
+    from mopa_amd.dense2d import bn_bwd, bn_fwd, new_img
+    rng = np.random.Generator(np.random.PCG64(6))
+    B, C, H, W = 2, 64, 14, 18
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, C, H, W), dtype=np.float32), 0))  # many ties at 0, like post-ReLU
+    xr = x.double().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    gout = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    (ref * gout.double()).sum().backward()
+    xi = _nhwc(x)
+    out = new_img(B, H // 2, W // 2, C, "cuda")
+    amax = torch.empty(out.rows * C, dtype=torch.uint8, device="cuda")
+    call("mopa_maxpool3x3s2_fwd", xi.p, xi.ld, B, H, W, C, out.p, out.ld, ptr(amax), stream())
+    _close(_nchw(out), ref)
+    dx = new_img(B, H, W, C, "cuda")
+    go = _nhwc(gout)
+    call("mopa_maxpool3x3s2_bwd", go.p, go.ld, ptr(amax), B, H, W, C, dx.p, dx.ld, 0, stream())
+    _close(_nchw(dx), xr.grad)
+    # BN (no act) -> + residual -> ReLU  == BasicBlock tail
+    z = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32) * 2 + 1)
+    idt = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32))
+    P = {"bn.weight": torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)), "bn.bias": torch.from_numpy(rng.standard_normal(C).astype(np.float32)),
+         "bn.running_mean": torch.zeros(C), "bn.running_var": torch.ones(C)}
+    zr, ir = z.double().requires_grad_(True), idt.double().requires_grad_(True)
+    gr, br = P["bn.weight"].double().requires_grad_(True), P["bn.bias"].double().requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    ref = F.relu(F.batch_norm(zr, rm, rv, gr, br, True, 0.1, 1e-5) + ir)
+    g2 = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32))
+    (ref * g2.double()).sum().backward()
+    Pd = {k: v.cuda() for k, v in P.items()}
+    zi, ii, y = _nhwc(z), _nhwc(idt), new_img(B, H, W, C, "cuda")
+    stats = torch.empty(4, C, device="cuda")
+    bn_fwd(zi, y, Pd, "bn", 1, ii, True, stats)
+    _close(_nchw(y), ref)
+    _close(Pd["bn.running_var"], rv, rtol=1e-5, atol=1e-6)
+    dz, dres = new_img(B, H, W, C, "cuda"), new_img(B, H, W, C, "cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    bn_bwd(_nhwc(g2), zi, dz, stats, 1, y, dres, False, True, dg, db)
+    _close(_nchw(dz), zr.grad, rtol=1e-3, atol=1e-4)
+    _close(_nchw(dres), ir.grad)
+    _close(dg, gr.grad, rtol=1e-3, atol=1e-4)
+    _close(db, br.grad, rtol=1e-3, atol=1e-4)
+
+
+def _build_2d(C=5):
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    model, _ = build_model_2d(default_cfg(C, True))
+    model.load_state_dict({k: det_tensor(k, v.shape) for k, v in model.state_dict().items()})
+    model.net_2d.dropout.p = 0.0
+    return model.cuda()
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def test_net2dseg_golden_eval(golden_dir):
+    for name in ("pad_eval", "nopad_eval"):
+        g = _load(golden_dir, f"g1_net2dseg_{name}.npz")
+        model = _build_2d().eval()
+        B = g["img"].shape[0]
+        out = model({"img": torch.from_numpy(g["img"]), "img_indices": [g[f"idx{i}"] for i in range(B)]})
+        for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
+            _close(out[k], g["out_" + k], rtol=1e-3, atol=2e-4)
+
+
+def test_net2dseg_golden_train_grads(golden_dir):
+    g = _load(golden_dir, "g1_net2dseg_pad_train.npz")
+    model = _build_2d().train()
+    out = model({"img": torch.from_numpy(g["img"]), "img_indices": [g["idx0"], g["idx1"]]})
+    for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
+        _close(out[k], g["out_" + k], rtol=1e-3, atol=2e-4)
+    sum((out[k] * torch.from_numpy(g["gin_" + k]).cuda()).sum() for k in out).backward()
+    named = dict(model.named_parameters())
+    sd = model.state_dict()
+    # Deep gradients of this tiny input (BN over 12 samples in layer4) are ill-conditioned: the reference's own fp32
+    # result is ~1 % off the fp64 truth for conv1.weight.  So the truth is the fp64 oracle, and the golden
+    # (reference, fp32) error against it is the yardstick for the HIP (fp32) error.
+    P = {k: (det_tensor(k, v).double() if "num_batches" not in k else det_tensor(k, v)) for k, v in net2d.param_shapes(5, True).items()}
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    ref = net2d.net2dseg_forward(P, torch.from_numpy(g["img"]).double(), [g["idx0"], g["idx1"]], training=True, dropout_p=0.0)
+    sum((ref[k] * torch.from_numpy(g["gin_" + k]).double()).sum() for k in ref).backward()
+    # A ReLU whose pre-activation is ~1e-5 from zero can take the other branch in a different fp32 summation
+    # order; on this tiny input the bottleneck (layer4 / decoder stage 5 live on a 2x3 map, 12-48 samples per
+    # channel) turns ONE such flip into a several-percent change of every gradient that passes through it
+    # (measured: exactly 1 of 12,288 masks differs from the fp64 oracle).  Those tensors get a loose bound.
+    def bottleneck(name):
+        return any(t in name for t in ("layer4", "dec_t_conv_stage5", "dec_conv_stage4", "layer3.5"))
+
+    for k, v in g.items():
+        if k.startswith("pgrad_"):
+            truth = P[k[6:]].grad.numpy()
+            scale = float(np.abs(truth).max())
+            err = float(np.abs(named[k[6:]].grad.cpu().numpy() - truth).max())
+            yard = float(np.abs(v - truth).max())
+            bound = 0.1 * scale if bottleneck(k) else max(3.0 * yard, 2e-4 * scale)
+            assert err <= bound, (k, err, yard, scale)
+        if k.startswith("buf_"):
+            _close(sd[k[4:]], v, rtol=1e-4, atol=1e-5)
+    norms = json.load(open(os.path.join(golden_dir, "g1_net2dseg_pad_train_gradnorms.json")))
+    gmax = max(float(P[k].grad.norm()) for k in norms)
+    for k, (s, n) in norms.items():
+        truth = float(P[k].grad.norm())
+        got = float(named[k].grad.double().norm())
+        bound = 0.1 * truth if bottleneck(k) else max(3.0 * abs(n - truth), 5e-3 * truth)
+        assert abs(got - truth) <= bound + 1e-6 * gmax, (k, got, truth, n)
+    assert int(sd["net_2d.bn1.num_batches_tracked"]) == 1
+
+
+def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
+    rng = np.random.Generator(np.random.PCG64(8))
+    B, H, W = 2, 45, 70
+    img = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32))
+    idx = [np.stack([rng.integers(0, H, 300), rng.integers(0, W, 300)], 1) for _ in range(B)]
+    model = _build_2d(10).train()
+    out = model({"img": img, "img_indices": idx})
+    P = {k: det_tensor(k, v.shape) for k, v in net2d.param_shapes(10, True).items()}
+    ref = net2d.net2dseg_forward(P, img, idx, training=True, dropout_p=0.0)
+    for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
+        _close(out[k], ref[k], rtol=1e-3, atol=2e-4)
+    # dropout p=0.4: ~40 % zeros at the two sites changes the output but keeps it finite; eval ignores p
+    model.net_2d.dropout.p = 0.4
+    o1 = model({"img": img, "img_indices": idx})
+    assert torch.isfinite(o1["seg_logit"]).all() and not torch.allclose(o1["seg_logit"], out["seg_logit"])
+    model.eval()
+    e1 = model({"img": img, "img_indices": idx})["seg_logit"]
+    e2 = model({"img": img, "img_indices": idx})["seg_logit"]
+    assert torch.equal(e1, e2)
+    with pytest.raises(IndexError):
+        model({"img": img, "img_indices": [idx[0], np.array([[H, 0]])]})
