@@ -60,7 +60,9 @@ class Net2DSeg(nn.Module):
             rows.append((b * Hp + idx[:, 0]) * Wp + idx[:, 1])
         flat = np.concatenate(rows) if rows else np.zeros(0, np.int64)
         t = torch.from_numpy(flat.astype(np.int32))
-        return t.pin_memory().to(device, non_blocking=True) if t.numel() else t.to(device)
+        if torch.device(device).type != "cuda" or t.numel() == 0:
+            return t.to(device)
+        return t.pin_memory().to(device, non_blocking=True)
 
     def forward(self, data_batch):
         dev = _require_cuda(self)

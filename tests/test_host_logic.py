@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference interface: factory, parameter names, batch layout, error behaviour (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net2d, scn3d
+
+
+def test_factory_returns_model_and_metric_with_reference_names():
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    from mopa_amd.models.metric import SegIoU
+    cfg = default_cfg(num_classes=5, dual_head=True)
+    m2, i2 = build_model_2d(cfg)
+    m3, i3 = build_model_3d(cfg)
+    assert isinstance(i2, SegIoU) and i2.name == "iou_2d" and i3.name == "iou_3d"
+    assert sum(p.numel() for p in m2.parameters()) == 23_614_794
+    assert sum(p.numel() for p in m3.parameters()) == 2_688_826
+    sd2, sd3 = m2.state_dict(), m3.state_dict()
+    for k, shape in net2d.param_shapes(5, True).items():
+        assert tuple(sd2[k].shape) == tuple(shape), k
+    for k, shape in scn3d.unet_param_shapes().items():
+        assert tuple(sd3["net_3d." + k].shape) == tuple(shape), k
+    assert set(sd2) == set(net2d.param_shapes(5, True))
+    # plain dict / attribute configs both work, unsupported backbones raise like the reference (xmuda_arch.py:37,98)
+    cfg.MODEL_3D.TYPE = "SPVCNN"
+    cfg.MODEL_3D["SPVCNN"] = {}
+    with pytest.raises(NotImplementedError):
+        build_model_3d(cfg)
+
+
+def test_no_cpu_fallback():
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    m3, _ = build_model_3d(default_cfg())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m3({"x": [torch.zeros(4, 4, dtype=torch.int64), torch.ones(4, 1)]})
+    m2, _ = build_model_2d(default_cfg())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m2({"img": torch.zeros(1, 3, 32, 48), "img_indices": [np.zeros((2, 2), np.int64)]})
+
+
+def test_pretrained_needs_local_weights(monkeypatch):
+    from mopa_amd.models.resnet34_unet import UNetResNet34
+    monkeypatch.delenv("MOPA_RESNET34_WEIGHTS", raising=False)
+    with pytest.raises(RuntimeError, match="MOPA_RESNET34_WEIGHTS"):
+        UNetResNet34(pretrained=True)
+
+
+def test_pack_indices_layout_and_bounds():
+    from mopa_amd.models.xmuda_arch import Net2DSeg
+    idx = [np.array([[0, 0], [29, 45], [3, 7]]), torch.tensor([[1, 2]])]
+    pix = Net2DSeg.pack_indices(idx, 30, 46, "cpu").numpy()
+    Hp, Wp = 32, 48
+    assert pix.tolist() == [0, 29 * Wp + 45, 3 * Wp + 7, (Hp + 1) * Wp + 2]
+    with pytest.raises(IndexError):
+        Net2DSeg.pack_indices([np.array([[30, 0]])], 30, 46, "cpu")
+
+
+def test_synthetic_batch_layout_matches_collate():
+    from mopa_amd import synth
+    b = synth.make_batch(2, H=30, W=46)
+    locs, feats = b["x"]
+    assert locs.dtype == torch.int64 and locs.shape[1] == 4 and feats.shape == (locs.shape[0], 1)
+    assert locs[:, 3].unique().tolist() == [0, 1] and int(locs[:, :3].max()) < 4096 and int(locs.min()) == 0
+    assert b["img"].shape == (2, 3, 30, 46) and len(b["img_indices"]) == 2 and b["img_indices"][0].shape[1] == 2
+    assert b["seg_label"].shape[0] == locs.shape[0] and int(b["seg_label"].min()) == -100
+    assert b["sam_mask_ls"][0].dtype == torch.int32 and b["sam_mask_ls"][0].shape == (30, 46)
+    # seeds: scan i of rank r uses 1000*r + i
+    assert not torch.equal(synth.make_batch(1, rank=1, H=30, W=46)["x"][0], synth.make_batch(1, rank=0, H=30, W=46)["x"][0])
+
+
+def test_segiou_matches_golden(golden_dir):
+    import os
+    from mopa_amd.models.metric import SegIoU
+    g = dict(np.load(os.path.join(golden_dir, "g5_misc.npz")))
+    m = SegIoU(5, name="iou")
+    logit, gt = torch.from_numpy(g["logit"]), torch.from_numpy(g["gt"])
+    m.update_dict({"seg_logit": logit}, {"seg_label": gt})
+    m.update_dict({"seg_logit": logit.flip(0)}, {"seg_label": gt})
+    assert (m.mat.numpy() == g["iou_mat"]).all()
+    np.testing.assert_allclose(m.iou.numpy(), g["iou"], rtol=1e-6)
+
+
+def test_voxelizer_matches_golden(golden_dir):
+    import os
+    from mopa_amd import synth
+    g = dict(np.load(os.path.join(golden_dir, "g4_voxelize.npz")))
+    # case 0 of G4 is augment_and_scale_3d without augmentation == synth.voxelize
+    assert np.array_equal(synth.voxelize(g["points0"], 20), g["coords0"])
