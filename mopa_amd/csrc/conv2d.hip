@@ -31,12 +31,12 @@ struct ConvGeom {
 // LDS: A is kept k-major ([k][m], transposed while staging) so that each k-step is 2+2 ds_read_b128 feeding
 // 64 FMAs with only 16 operand registers live; double-buffered, one barrier per 16-deep K-chunk, the next chunk's
 // global loads are issued before the FMAs of the current one.
-template <int BM, int BN>
+template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           const ConvGeom g, int accumulate) {
-  constexpr int TX = BN / 8, TY = 256 / TX;
-  static_assert(TY * 8 == BM, "tile shape");
+  constexpr int TX = BN / TN, TY = 256 / TX;
+  static_assert(TY * TM == BM && (TM == 4 || TM == 8) && (TN == 4 || TN == 8), "tile shape");
   constexpr int AROWS = BM / 64;             // A float4 loads per thread per K-chunk
   constexpr int BVEC = (BK * BN / 4) / 256;  // B float4 loads per thread per K-chunk
   constexpr int BMP = BM + APAD;
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
     }                                                                                                              \
   }
 
-  float acc[8][8];
+  float acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
 
   LOAD_TILE(0);
   STORE_TILE(0);
@@ -110,18 +110,25 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
     if (it + 1 < niter) LOAD_TILE(it + 1);  // global loads in flight while this tile is consumed
 #pragma unroll 4
     for (int k = 0; k < BK; ++k) {
-      const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][k][ty * 8]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&As[cur][k][ty * 8 + 4]);
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][k][tx * 4]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][k][BN / 2 + tx * 4]);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        acc[i][0] = fmaf(av[i], b0.x, acc[i][0]); acc[i][1] = fmaf(av[i], b0.y, acc[i][1]);
-        acc[i][2] = fmaf(av[i], b0.z, acc[i][2]); acc[i][3] = fmaf(av[i], b0.w, acc[i][3]);
-        acc[i][4] = fmaf(av[i], b1.x, acc[i][4]); acc[i][5] = fmaf(av[i], b1.y, acc[i][5]);
-        acc[i][6] = fmaf(av[i], b1.z, acc[i][6]); acc[i][7] = fmaf(av[i], b1.w, acc[i][7]);
+      float av[TM], bv[TN];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][k][ty * TM]);
+        av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w;
+        if (TM == 8) {
+          const float4 a1 = *reinterpret_cast<const float4*>(&As[cur][k][ty * TM + 4]);
+          av[TM - 4] = a1.x; av[TM - 3] = a1.y; av[TM - 2] = a1.z; av[TM - 1] = a1.w;
+        }
+        const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][k][tx * 4]);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        if (TN == 8) {
+          const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][k][BN / 2 + tx * 4]);
+          bv[TN - 4] = b1.x; bv[TN - 3] = b1.y; bv[TN - 2] = b1.z; bv[TN - 1] = b1.w;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
     }
     if (it + 1 < niter) {
       STORE_TILE(cur ^ 1);
@@ -134,45 +141,66 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
   float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
   if (bias) {
     bv0 = *reinterpret_cast<const float4*>(bias + n0 + tx * 4);
-    bv1 = *reinterpret_cast<const float4*>(bias + n0 + BN / 2 + tx * 4);
+    if (TN == 8) bv1 = *reinterpret_cast<const float4*>(bias + n0 + BN / 2 + tx * 4);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + ty * 8 + i;
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + ty * TM + i;
     if (m >= M) continue;
     const int b = m / ohw, r = m - b * ohw;
     const int oy = r / g.OWl, ox = r - oy * g.OWl;
     float* o = out + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + n0;
     float4 v0 = make_float4(acc[i][0] + bv0.x, acc[i][1] + bv0.y, acc[i][2] + bv0.z, acc[i][3] + bv0.w);
-    float4 v1 = make_float4(acc[i][4] + bv1.x, acc[i][5] + bv1.y, acc[i][6] + bv1.z, acc[i][7] + bv1.w);
     float4* p0 = reinterpret_cast<float4*>(o + tx * 4);
-    float4* p1 = reinterpret_cast<float4*>(o + BN / 2 + tx * 4);
     if (accumulate) {
-      const float4 q0 = *p0, q1 = *p1;
+      const float4 q0 = *p0;
       v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
-      v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
     }
     *p0 = v0;
-    *p1 = v1;
+    if (TN == 8) {
+      float4 v1 = make_float4(acc[i][TN - 4] + bv1.x, acc[i][TN - 3] + bv1.y, acc[i][TN - 2] + bv1.z, acc[i][TN - 1] + bv1.w);
+      float4* p1 = reinterpret_cast<float4*>(o + BN / 2 + tx * 4);
+      if (accumulate) {
+        const float4 q1 = *p1;
+        v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
+      }
+      *p1 = v1;
+    }
   }
 }
 
-// geom: 25 int32 in the ConvGeom order.  bias may be null.  accumulate: out += result (gradient accumulation).
+// Tile choice, from measurements on MI355X at the network's own shapes (scratch/bench_igemm.py, B=8):
+//   M >= 200k pixels: 256x64 (8x8 register tile) 68-82 TF/s; with Cout % 128 == 0 and M >= 1M: 128x128 84 TF/s;
+//   M <  200k pixels (layer2-4, decoder stages 3-5): 64x64 (4x4 register tile) fills the 256 CUs -- 50-69 TF/s
+//   where the large tiles reach 34-60 (4,560 pixels x 512 channels is 144 blocks of 256x64 on 256 CUs).
+struct TileCfg { int bm, bn; };
+static const TileCfg kTiles[4] = {{256, 64}, {128, 128}, {128, 64}, {64, 64}};
+static int pick_tile(int64_t M, int cout) {
+  if (M >= 200000) return (cout % 128 == 0 && M >= 1000000) ? 1 : 0;
+  return 3;
+}
+
+// geom: 25 int32 in the ConvGeom order.  bias may be null.
+// flags: bit 0 = accumulate (out += result, used for gradient accumulation); bits 8-15 = tile override + 1 (tuning only).
 MOPA_API int mopa_conv2d_igemm(const float* in, const float* weight, const float* bias, float* out,
-                               const int32_t* geom_host, int32_t accumulate, void* stream) {
+                               const int32_t* geom_host, int32_t flags, void* stream) {
   ConvGeom g;
   static_assert(sizeof(ConvGeom) == 25 * sizeof(int), "ConvGeom layout");
   memcpy(&g, geom_host, sizeof(g));
-  if (g.Cin % BK != 0 || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0 || g.B <= 0) return MOPA_ERR_ARG;
+  if (g.Cin % BK != 0 || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0 || g.B <= 0 || g.TH * g.TW <= 0) return MOPA_ERR_ARG;
   if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return MOPA_ERR_ARG;
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
+  if (M <= 0) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (g.Cout % 128 == 0 && M >= 128 * 512) {
-    dim3 grid((unsigned)cdiv64(M, 128), g.Cout / 128);
-    k_conv2d_igemm<128, 128><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate);
-  } else {
-    dim3 grid((unsigned)cdiv64(M, 256), g.Cout / 64);
-    k_conv2d_igemm<256, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate);
+  const int accumulate = flags & 1;
+  int tile = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) - 1 : pick_tile(M, g.Cout);
+  if (tile < 0 || tile > 3 || g.Cout % kTiles[tile].bn) return MOPA_ERR_ARG;
+  dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn);
+  switch (tile) {
+    case 0: k_conv2d_igemm<256, 64, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
+    case 1: k_conv2d_igemm<128, 128, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
+    case 2: k_conv2d_igemm<128, 64, 8, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
+    default: k_conv2d_igemm<64, 64, 4, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
   }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

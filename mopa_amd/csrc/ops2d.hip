@@ -315,18 +315,24 @@ __global__ __launch_bounds__(256) void k_colsum_reduce(const float* __restrict__
     if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
   }
 }
-#define COLSUM_ROWS 1024
+static inline int colsum_rows(int64_t num_rows) {
+  int64_t r = cdiv64(num_rows, 2048);
+  if (r < 32) r = 32;
+  if (r > 1024) r = 1024;
+  return (int)r;
+}
 MOPA_API size_t mopa_colsum_workspace_bytes(int64_t num_rows, int32_t C) {
-  return align_up((size_t)cdiv64(num_rows, COLSUM_ROWS) * C * sizeof(float), 256);
+  return align_up((size_t)cdiv64(num_rows, colsum_rows(num_rows)) * C * sizeof(float), 256);
 }
 MOPA_API int mopa_colsum(const float* x, int32_t ld, int64_t num_rows, int32_t C, float* out, int32_t accumulate, void* ws,
                          size_t ws_bytes, void* stream) {
   if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ld < C || (ld & 3)) return MOPA_ERR_ARG;
   if (ws_bytes < mopa_colsum_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(num_rows, COLSUM_ROWS);
+  const int rpb = colsum_rows(num_rows);
+  const int nblk = (int)cdiv64(num_rows, rpb);
   const int RL = 256 / (C >> 2);
-  k_colsum_partial<<<nblk, 256, (size_t)RL * C * sizeof(float), st>>>(x, ld, (int)num_rows, C, COLSUM_ROWS, (float*)ws);
+  k_colsum_partial<<<nblk, 256, (size_t)RL * C * sizeof(float), st>>>(x, ld, (int)num_rows, C, rpb, (float*)ws);
   k_colsum_reduce<<<16, 256, 0, st>>>((const float*)ws, nblk, C, out, accumulate);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

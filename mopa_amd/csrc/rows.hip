@@ -7,18 +7,26 @@
 // Semantics: SURVEY.md Appendix A.2, A.3, A.6; oracle: oracle/scn3d.py::{input_layer,output_layer,bn_relu}.
 #include "common.h"
 
-#define BN_ROWS_PER_BLOCK 1024
+// Rows handled by one block of the two-stage reductions: enough blocks to fill 256 CUs several times over even for
+// the short-and-wide tensors of the deep layers (e.g. 4,560 rows x 512 channels), capped at 1024 rows.
+static inline int bn_rows_per_block(int64_t num_rows) {
+  int64_t r = cdiv64(num_rows, 2048);
+  if (r < 32) r = 32;
+  if (r > 1024) r = 1024;
+  return (int)r;
+}
+static inline int bn_num_blocks(int64_t num_rows) { return (int)cdiv64(num_rows, bn_rows_per_block(num_rows)); }
 
 // ------------------------------------------------------------------------------------------ BN statistics
 // partial[blk][0][c] = sum(x - x0), partial[blk][1][c] = sum((x - x0)^2) with x0 = first row (shifted sums keep
 // fp32 accurate when |mean| >> std).  C % 4 == 0.
-__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int ld, int A, int C,
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int ld, int A, int C, int rpb,
                                                            float* __restrict__ partial) {
   extern __shared__ float lds[];  // [2][RL][C]
   const int CQ = C >> 2;
   const int RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-  const int rbeg = blockIdx.x * BN_ROWS_PER_BLOCK, rend = min(A, rbeg + BN_ROWS_PER_BLOCK);
+  const int rbeg = blockIdx.x * rpb, rend = min(A, rbeg + rpb);
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (rl < RL) {
     const float4 k = *reinterpret_cast<const float4*>(x + cq * 4);
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
 }
 
 MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
-  return align_up((size_t)cdiv64(num_rows, BN_ROWS_PER_BLOCK) * 2 * C * sizeof(float), 256);
+  return align_up((size_t)bn_num_blocks(num_rows) * 2 * C * sizeof(float), 256);
 }
 
 // y = act(batchnorm(x) (+ res)).  stats[4][C] receives scale, shift, mean, invstd (saved for backward).
@@ -125,13 +133,13 @@ MOPA_API int mopa_bn_act_fwd(const float* x, int32_t ldx, float* y, int32_t ldy,
   if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
   if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
+  const int nblk = bn_num_blocks(num_rows);
   float* partial = (float*)ws;
   if (training) {
     if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
     const int RL = 256 / (C >> 2);
     if (RL < 1) return MOPA_ERR_ARG;
-    k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, partial);
+    k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, bn_rows_per_block(num_rows), partial);
   }
   k_bn_finalize<<<1, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
                                    eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
@@ -161,13 +169,13 @@ __device__ __forceinline__ float bn_dz(float g, float xv, float sc, float sh, fl
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, int ld_dy,
                                                          const float* __restrict__ x, int ldx, int A, int C,
                                                          const float* __restrict__ stats, float leak,
-                                                         const float* __restrict__ ymask, int ld_ym, int act,
+                                                         const float* __restrict__ ymask, int ld_ym, int act, int rpb,
                                                          float* __restrict__ partial) {
   extern __shared__ float lds[];
   const int CQ = C >> 2;
   const int RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-  const int rbeg = blockIdx.x * BN_ROWS_PER_BLOCK, rend = min(A, rbeg + BN_ROWS_PER_BLOCK);
+  const int rbeg = blockIdx.x * rpb, rend = min(A, rbeg + rpb);
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (rl < RL) {
     float sc[4], sh[4], mu[4], is[4];
@@ -289,12 +297,12 @@ MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int
   if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
   if (ws_bytes < mopa_bnrelu_rows_bwd_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(num_rows, BN_ROWS_PER_BLOCK);
+  const int nblk = bn_num_blocks(num_rows);
   float* partial = (float*)ws;
   float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
   const int RL = 256 / (C >> 2);
   k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask,
-                                                                          ld_ym, act, partial);
+                                                                          ld_ym, act, bn_rows_per_block(num_rows), partial);
   k_bn_bwd_finalize<<<1, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
   k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(
       dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
@@ -426,34 +434,62 @@ __global__ __launch_bounds__(256) void k_output_heads_bwd_rows(const float* __re
   }
 }
 
-// Head parameter grads: dW[k][c] = sum_p dl[p][k] * feats[p][c], db[k] = sum_p dl[p][k]; block partials then reduce.
-#define HEAD_PTS_PER_BLOCK 2048
+// Head parameter grads: dW[k][c] = sum_p dl[p][k] * feats[p][c], db[k] = sum_p dl[p][k].  Thread = (point lane,
+// channel quad); block partials [nblk][NC][M+1] then an ordered reduction (deterministic).
+#define HEAD_PTS_PER_BLOCK 1024
+#define HEAD_MAXNC 32
 __global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restrict__ dl, const float* __restrict__ feats, int N,
                                                              int M, int NC, float* __restrict__ partial) {
-  // thread = (class k, channel c) pairs strided; each thread loops over the block's points (L1-friendly: all threads
-  // read the same point rows).
-  const int pbeg = blockIdx.x * HEAD_PTS_PER_BLOCK, pend = min(N, pbeg + HEAD_PTS_PER_BLOCK);
-  const int nout = NC * (M + 1);
-  for (int i = threadIdx.x; i < nout; i += 256) {
-    const int k = i / (M + 1), c = i - k * (M + 1);
-    float acc = 0.f;
-    if (c < M) {
-      for (int p = pbeg; p < pend; ++p) acc = fmaf(dl[(int64_t)p * NC + k], feats[(int64_t)p * M + c], acc);
-    } else {
-      for (int p = pbeg; p < pend; ++p) acc += dl[(int64_t)p * NC + k];
+  extern __shared__ float red[];  // [PL][NC][M+1]
+  const int MQ = M >> 2, PL = 256 / MQ;
+  const int cq = threadIdx.x % MQ, pl = threadIdx.x / MQ;
+  const int p0 = blockIdx.x * HEAD_PTS_PER_BLOCK, p1 = min(N, p0 + HEAD_PTS_PER_BLOCK);
+  float acc[HEAD_MAXNC][4];
+  float accb[HEAD_MAXNC];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXNC; ++k) { acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f; accb[k] = 0.f; }
+  if (pl < PL)
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const float4 v = *reinterpret_cast<const float4*>(feats + (int64_t)p * M + cq * 4);
+#pragma unroll
+      for (int k = 0; k < HEAD_MAXNC; ++k)
+        if (k < NC) {
+          const float g = dl[(int64_t)p * NC + k];
+          acc[k][0] = fmaf(g, v.x, acc[k][0]); acc[k][1] = fmaf(g, v.y, acc[k][1]);
+          acc[k][2] = fmaf(g, v.z, acc[k][2]); acc[k][3] = fmaf(g, v.w, acc[k][3]);
+          if (cq == 0) accb[k] += g;
+        }
     }
-    partial[(int64_t)blockIdx.x * nout + i] = acc;
+  const int stride = NC * (M + 1);
+  if (pl < PL) {
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXNC; ++k)
+      if (k < NC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl * stride + k * (M + 1) + cq * 4 + j] = acc[k][j];
+        if (cq == 0) red[pl * stride + k * (M + 1) + M] = accb[k];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < stride; i += 256) {
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * stride + i];
+    partial[(int64_t)blockIdx.x * stride + i] = s;
   }
 }
-__global__ void k_head_wgrad_reduce(const float* __restrict__ partial, int nblk, int M, int NC, float* __restrict__ dw,
-                                    float* __restrict__ db, int accumulate) {
+__global__ __launch_bounds__(256) void k_head_wgrad_reduce(const float* __restrict__ partial, int nblk, int M, int NC,
+                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate) {
   const int nout = NC * (M + 1);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wv; i < nout; i += gridDim.x * 4) {
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * nout + i];
-    const int k = i / (M + 1), c = i - k * (M + 1);
-    float* dst = (c < M) ? &dw[k * M + c] : &db[k];
-    *dst = (accumulate ? *dst : 0.f) + (float)s;
+    for (int b = lane; b < nblk; b += 64) s += (double)partial[(int64_t)b * nout + i];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+      const int k = i / (M + 1), c = i - k * (M + 1);
+      float* dst = (c < M) ? &dw[k * M + c] : &db[k];
+      *dst = (accumulate ? *dst : 0.f) + (float)s;
+    }
   }
 }
 
@@ -468,7 +504,8 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
                                          int32_t num_classes, float* dy, int32_t ld_dy, float* dw1, float* db1,
                                          float* dw2, float* db2, int32_t accumulate, void* ws, size_t ws_bytes,
                                          void* stream) {
-  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || num_classes <= 0 || num_classes > 64 || ld_dy < M)
+  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || (M & 3) || 256 % (M >> 2) != 0 || num_classes <= 0 ||
+      num_classes > HEAD_MAXNC || ld_dy < M)
     return MOPA_ERR_ARG;
   if (ws_bytes < mopa_output_layer_heads_bwd_workspace_bytes(n_points, M, num_classes)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -476,13 +513,15 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
       dfeats, dl1, dl2, w1, w2, row_start, row_points, num_rows, M, num_classes, dy, ld_dy);
   const int nblk = (int)cdiv64(n_points, HEAD_PTS_PER_BLOCK);
   float* partial = (float*)ws;
+  const size_t hsh = (size_t)(256 / (M >> 2)) * num_classes * (M + 1) * sizeof(float);
+  if (hsh > 64 * 1024) return MOPA_ERR_ARG;
   if (dl1 && dw1) {
-    k_head_wgrad_partial<<<nblk, 256, 0, st>>>(dl1, feats, n_points, M, num_classes, partial);
-    k_head_wgrad_reduce<<<1, 256, 0, st>>>(partial, nblk, M, num_classes, dw1, db1, accumulate);
+    k_head_wgrad_partial<<<nblk, 256, hsh, st>>>(dl1, feats, n_points, M, num_classes, partial);
+    k_head_wgrad_reduce<<<16, 256, 0, st>>>(partial, nblk, M, num_classes, dw1, db1, accumulate);
   }
   if (dl2 && dw2) {
-    k_head_wgrad_partial<<<nblk, 256, 0, st>>>(dl2, feats, n_points, M, num_classes, partial);
-    k_head_wgrad_reduce<<<1, 256, 0, st>>>(partial, nblk, M, num_classes, dw2, db2, accumulate);
+    k_head_wgrad_partial<<<nblk, 256, hsh, st>>>(dl2, feats, n_points, M, num_classes, partial);
+    k_head_wgrad_reduce<<<16, 256, 0, st>>>(partial, nblk, M, num_classes, dw2, db2, accumulate);
   }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

@@ -209,7 +209,7 @@ def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
     idx = [np.stack([rng.integers(0, H, 300), rng.integers(0, W, 300)], 1) for _ in range(B)]
     model = _build_2d(10).train()
     out = model({"img": img, "img_indices": idx})
-    P = {k: det_tensor(k, v.shape) for k, v in net2d.param_shapes(10, True).items()}
+    P = {k: det_tensor(k, v) for k, v in net2d.param_shapes(10, True).items()}
     ref = net2d.net2dseg_forward(P, img, idx, training=True, dropout_p=0.0)
     for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
         _close(out[k], ref[k], rtol=1e-3, atol=2e-4)
