@@ -53,14 +53,14 @@ class ConvTimer:
         inner = sparse3d.spconv_fwd
         timer = self
 
-        def wrapped(nbr, x, w, out, w_flip=False):
+        def wrapped(nbr, x, w, out, w_flip=False, rb=None):
             if not timer.enabled:
-                return inner(nbr, x, w, out, w_flip)
+                return inner(nbr, x, w, out, w_flip, rb)
             K, A_out = nbr.shape
             R = timer.rules.get((K, A_out, x.rows))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            inner(nbr, x, w, out, w_flip)
+            inner(nbr, x, w, out, w_flip, rb)
             e.record()
             if R is not None:
                 # gather R*Cin*4 + each output row once A*Cout*4 + int32 rule pair R*8 + weights

@@ -27,8 +27,13 @@ SIGNATURES = {
     "mopa_rulebook_updown": ("i", "ppiippp"),
     "mopa_points_csr_workspace_bytes": ("z", "l"),
     "mopa_points_csr": ("i", "piipppzp"),
+    "mopa_scan_workspace_bytes": ("z", "l"),
+    "mopa_scan_exclusive_i32": ("i", "ppippzp"),
     # ---- sparse conv (spconv.hip)
     "mopa_spconv_fwd": ("i", "piipiipiipip"),
+    "mopa_rulebook_groups_count": ("i", "piipp"),
+    "mopa_rulebook_groups_fill": ("i", "piippppp"),
+    "mopa_spconv_fwd_grouped": ("i", "ppppiipiipiipip"),
     "mopa_spconv_transpose_weight": ("i", "piiipp"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),

@@ -168,6 +168,16 @@ static int scan_exclusive(const int* in, int* out, int n_cap, const int* n_dev, 
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
+MOPA_API size_t mopa_scan_workspace_bytes(int64_t n) { return align_up((size_t)(cdiv64(n, SCAN_ITEMS) + 16) * sizeof(int), 256); }
+
+// out[i] = sum_{j<i} in[j] (int32), *total = sum of all n inputs (device scalar).  in/out may not alias.
+MOPA_API int mopa_scan_exclusive_i32(const int32_t* in, int32_t* out, int32_t n, int32_t* total, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  if (n <= 0) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_scan_workspace_bytes(n)) return MOPA_ERR_WORKSPACE;
+  return scan_exclusive(in, out, n, nullptr, (int*)ws, total, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- row assignment
 __global__ void k_assign_rows(const uint64_t* __restrict__ keys, const int* __restrict__ flags,
                               const int* __restrict__ scan, const int* __restrict__ slot_of, int n_host,

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
                               float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = wv; c < C; c += 4) {
+  for (int c = blockIdx.x * 4 + wv; c < C; c += gridDim.x * 4) {
     float mean, var;
     if (training) {
       double s = 0.0, ss = 0.0;
@@ -141,7 +141,7 @@ MOPA_API int mopa_bn_act_fwd(const float* x, int32_t ldx, float* y, int32_t ldy,
     if (RL < 1) return MOPA_ERR_ARG;
     k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, bn_rows_per_block(num_rows), partial);
   }
-  k_bn_finalize<<<1, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
+  k_bn_finalize<<<(C + 3) / 4, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
                                    eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
   k_bn_relu_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
                                                                                   stats + C, leak, res, ld_res, act);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                           float* __restrict__ coef) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = wv; c < C; c += 4) {
+  for (int c = blockIdx.x * 4 + wv; c < C; c += gridDim.x * 4) {
     double s = 0.0, ss = 0.0;
     for (int b = lane; b < nblk; b += 64) {
       s += (double)partial[(int64_t)b * 2 * C + c];
@@ -303,7 +303,7 @@ MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int
   const int RL = 256 / (C >> 2);
   k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask,
                                                                           ld_ym, act, bn_rows_per_block(num_rows), partial);
-  k_bn_bwd_finalize<<<1, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
+  k_bn_bwd_finalize<<<(C + 3) / 4, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
   k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(
       dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
       ld_dres, accumulate_dres);

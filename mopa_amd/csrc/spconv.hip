@@ -17,53 +17,66 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define TM 64  // output rows per wave-tile
-
 // ----------------------------------------------------------------------------------------------
-// Forward / backward-data.  One wave per tile of 64 output rows; per filter offset the wave
-// compacts the valid rules (ballot), gathers 16 input rows at a time straight into the MFMA A-operand
-// layout with 16-byte loads, multiplies by W[o] and adds the 16 result rows into the tile's LDS
-// accumulator (within one offset every output row occurs at most once, so no atomics).  Each output row is
-// written to HBM exactly once.
+// Forward / backward-data.  One wave per (tile of TMR output rows, group of 16*NTW output columns).  The wave first
+// stages its slice of the rule table (K x TMR int32) in LDS with all loads in flight at once, then per filter offset:
+// ballot-compacts the valid rules, gathers 16 input rows at a time straight into the MFMA A-operand layout with
+// 16-byte loads, multiplies by its column slice of W[o] and adds the 16 result rows into the tile's LDS accumulator
+// (within one offset every output row occurs at most once, so no atomics).  Each output element is written to HBM
+// exactly once.  Splitting the columns over grid.y keeps the deep, short levels (a few thousand rows x 96-192
+// channels) from serialising 27 x Cin/4 x Cout/16 MFMAs in a handful of waves; the row gathers are then repeated per
+// column group but come from L2.
 //
 // Operand mapping (k and n are permuted consistently so every global load is contiguous per lane):
-//   lane l: r = l&15, q = l>>4.   A[i=r][k] = in[pair r][16*kk + 4*q + s]   (one float4 per kk)
-//                                 B[k][j=r] = W[o][16*kk + 4*q + s][r*NT + t]  (NT contiguous floats)
-//   D tile t: lane holds rows 4*q+j (j<4), i.e. pairs, column r*NT + t.
-template <int NT, bool ALIGNED>
+//   lane l: r = l&15, q = l>>4.   A[i=r][k] = in[pair r][16*kk + 4*q + s]          (one float4 per kk)
+//                                 B[k][j=r] = W[o][16*kk + 4*q + s][c0 + r*NTW + t]  (NTW contiguous floats)
+//   D tile t: lane holds rows 4*q+j (j<4), i.e. pairs, column c0 + r*NTW + t.
+template <int NTW, int TMR, bool ALIGNED>
 __global__ __launch_bounds__(64) void k_spconv_fwd(const int* __restrict__ nbr, int K, int A_out,
                                                     const float* __restrict__ in, int ld_in, int cin,
                                                     const float* __restrict__ W, int cout, int w_flip,
                                                     float* __restrict__ out, int ld_out) {
-  constexpr int CP = NT * 16;      // padded Cout
+  constexpr int CP = NTW * 16;     // columns of this group
   constexpr int LD = CP + 4;       // LDS row stride (floats); +4 keeps 16-B alignment, breaks pow2 strides
-  __shared__ __attribute__((aligned(16))) float acc[TM * LD];
-  __shared__ int l_in[TM];
-  __shared__ int l_out[TM];
+  constexpr int SUB = TMR / 64;    // 64-row sub-blocks per tile
+  __shared__ __attribute__((aligned(16))) float acc[TMR * LD];
+  __shared__ int l_nbr[27 * TMR];
+  __shared__ int l_in[TMR];
+  __shared__ int l_out[TMR];
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * TM;
+  const int row0 = blockIdx.x * TMR;
+  const int c0 = blockIdx.y * CP;
   const int cin16 = (cin + 15) >> 4;
 
-  for (int i = lane; i < TM * LD; i += 64) acc[i] = 0.f;
+  for (int o = 0; o < K; ++o)
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      const int row = row0 + sb * 64 + lane;
+      l_nbr[o * TMR + sb * 64 + lane] = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
+    }
+  for (int i = lane; i < TMR * LD; i += 64) acc[i] = 0.f;
   __syncthreads();
 
   for (int o = 0; o < K; ++o) {
-    const int row = row0 + lane;
-    const int nb = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
-    const unsigned long long bal = __ballot(nb >= 0);
-    if (bal == 0) continue;  // wave-uniform
-    const int n_o = __popcll(bal);
-    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-    if (nb >= 0) { l_in[pos] = nb; l_out[pos] = lane; }
+    int n_o = 0;
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      const int nb = l_nbr[o * TMR + sb * 64 + lane];
+      const unsigned long long bal = __ballot(nb >= 0);
+      const int pos = n_o + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      if (nb >= 0) { l_in[pos] = nb; l_out[pos] = sb * 64 + lane; }
+      n_o += __popcll(bal);
+    }
+    if (n_o == 0) continue;  // wave-uniform
     __syncthreads();
-    const float* __restrict__ wo = W + (int64_t)(w_flip ? K - 1 - o : o) * cin * cout;
+    const float* __restrict__ wo = W + (int64_t)(w_flip ? K - 1 - o : o) * cin * cout + c0 + r * NTW;
     for (int g0 = 0; g0 < n_o; g0 += 16) {
       const int p = g0 + r;
       const int irow = (p < n_o) ? l_in[p] : -1;
       const float* __restrict__ arow = in + (int64_t)(irow < 0 ? 0 : irow) * ld_in;
-      f32x4 d[NT];
+      f32x4 d[NTW];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int kk = 0; kk < cin16; ++kk) {
         const int kb = kk * 16 + q * 4;
         float a[4];
@@ -76,59 +89,76 @@ __global__ __launch_bounds__(64) void k_spconv_fwd(const int* __restrict__ nbr, 
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          float b[NT];
-          const float* __restrict__ wr = wo + (int64_t)(kb + s) * cout + r * NT;
+          float b[NTW];
+          const float* __restrict__ wr = wo + (int64_t)(kb + s) * cout;
           if (ALIGNED) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = wr[t];
+            for (int t = 0; t < NTW; ++t) b[t] = wr[t];
           } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = (kb + s < cin && r * NT + t < cout) ? wr[t] : 0.f;
+            for (int t = 0; t < NTW; ++t) b[t] = (kb + s < cin && c0 + r * NTW + t < cout) ? wr[t] : 0.f;
           }
 #pragma unroll
-          for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t], d[t], 0, 0, 0);
+          for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t], d[t], 0, 0, 0);
         }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pr = g0 + q * 4 + j;
         if (pr < n_o) {
-          float* ap = acc + l_out[pr] * LD + r * NT;
+          float* ap = acc + l_out[pr] * LD + r * NTW;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) ap[t] += d[t][j];
+          for (int t = 0; t < NTW; ++t) ap[t] += d[t][j];
         }
       }
     }
     __syncthreads();
   }
   __syncthreads();
-  // write the tile: each output row exactly once, contiguous per row
+  // write the tile's column group: each output element exactly once
   if (ALIGNED) {
-    constexpr int V = CP / 4;  // float4 per row
-    for (int i = lane; i < TM * V; i += 64) {
+    constexpr int V = CP / 4;  // float4 per row of this group
+    for (int i = lane; i < TMR * V; i += 64) {
       const int rr = i / V, c4 = i - rr * V;
       if (row0 + rr < A_out)
-        *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + c4 * 4) =
+        *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + c0 + c4 * 4) =
             *reinterpret_cast<const float4*>(acc + rr * LD + c4 * 4);
     }
   } else {
-    for (int i = lane; i < TM * CP; i += 64) {
+    for (int i = lane; i < TMR * CP; i += 64) {
       const int rr = i / CP, c = i - rr * CP;
-      if (row0 + rr < A_out && c < cout) out[(int64_t)(row0 + rr) * ld_out + c] = acc[rr * LD + c];
+      if (row0 + rr < A_out && c0 + c < cout) out[(int64_t)(row0 + rr) * ld_out + c0 + c] = acc[rr * LD + c];
     }
   }
 }
 
-template <int NT>
+// Column-group width (in 16-column tiles) and row-tile height.  NTW must divide NT (vector B loads); columns are
+// split further whenever a launch would otherwise hold fewer than ~2k waves.  128-row tiles only where a 64-row tile
+// sees < 16 rules per offset on average (the sparse shallow levels), so MFMA row groups are better filled.
+static void fwd_plan(int K, int A_out, int cout, int* ntw, int* tmr) {
+  const int NT = (cout + 15) / 16;
+  // measured (profiles/r1_*): tiles >= ~1500 already fill the chip with one wave per tile and all columns (the row
+  // gathers are not repeated); below that the per-wave serial chain over the offsets dominates and the columns are
+  // split across waves.
+  const int64_t tiles = cdiv64(A_out, 64);
+  int best = 1;
+  for (int c = 4; c >= 1; --c)
+    if (NT % c == 0 && (tiles >= 1500 || tiles * (NT / c) >= 1024)) { best = c; break; }
+  *ntw = best;
+  *tmr = 64;
+}
+
+template <int NTW, int TMR>
 static int launch_fwd(const int* nbr, int K, int A_out, const float* in, int ld_in, int cin, const float* W,
                       int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
-  const int grid = (A_out + TM - 1) / TM;
+  const int NT = (cout + 15) / 16;
+  dim3 grid((A_out + TMR - 1) / TMR, (NT + NTW - 1) / NTW);
   const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
                        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)W) % 16 == 0);
   if (aligned)
-    k_spconv_fwd<NT, true><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_fwd<NTW, TMR, true><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
   else
-    k_spconv_fwd<NT, false><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_fwd<NTW, TMR, false><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
@@ -136,14 +166,298 @@ static int launch_fwd(const int* nbr, int K, int A_out, const float* in, int ld_
 MOPA_API int mopa_spconv_fwd(const int32_t* nbr, int32_t K, int32_t num_out, const float* in, int32_t ld_in,
                              int32_t cin, const float* weight, int32_t cout, int32_t w_flip, float* out,
                              int32_t ld_out, void* stream) {
-  if (K <= 0 || num_out <= 0 || cin <= 0 || cout <= 0 || cout > 192 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
+  if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  switch ((cout + 15) / 16) {
-#define CASE(N) case N: return launch_fwd<N>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
-    CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12);
-#undef CASE
+  int ntw, tmr;
+  fwd_plan(K, num_out, cout, &ntw, &tmr);
+#define GO(N, T) return launch_fwd<N, T>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
+  if (tmr == 128) {
+    if (ntw == 1) GO(1, 128);
+    if (ntw == 2) GO(2, 128);
   }
+  switch (ntw) {
+    case 1: GO(1, 64);
+    case 2: GO(2, 64);
+    case 3: GO(3, 64);
+    default: GO(4, 64);
+  }
+#undef GO
+}
+
+// ----------------------------------------------------------------------------------------------
+// Grouped rulebook: the rule table compacted ONCE per geometry into MFMA-ready groups, so that the convolution
+// kernel has no ballot / LDS-list / barrier chain per offset and can prefetch its gathers.
+//   tile t (64 consecutive output rows) owns groups grp_start[t] .. grp_start[t+1]-1, ordered by filter offset;
+//   group g: grp_o[g] = filter offset, grp_in[g][16] = input rows (-1 = padding), grp_out[g][16] = output row within
+//   the tile (0..63, -1 = padding).  Every (offset, tile) with n valid rules contributes ceil(n/16) groups.
+__global__ __launch_bounds__(64) void k_rb_count(const int* __restrict__ nbr, int K, int A_out, int* __restrict__ tile_groups) {
+  const int row = blockIdx.x * 64 + threadIdx.x;
+  int ng = 0;
+  for (int o = 0; o < K; ++o) {
+    const int nb = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
+    ng += (__popcll(__ballot(nb >= 0)) + 15) >> 4;
+  }
+  if (threadIdx.x == 0) tile_groups[blockIdx.x] = ng;
+}
+
+__global__ __launch_bounds__(64) void k_rb_fill(const int* __restrict__ nbr, int K, int A_out, const int* __restrict__ grp_start,
+                                                 int* __restrict__ grp_o, int* __restrict__ grp_in, int* __restrict__ grp_out) {
+  const int lane = threadIdx.x, row = blockIdx.x * 64 + lane;
+  int g = grp_start[blockIdx.x];
+  for (int o = 0; o < K; ++o) {
+    const int nb = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
+    const unsigned long long bal = __ballot(nb >= 0);
+    const int n = __popcll(bal);
+    if (n == 0) continue;
+    const int ng = (n + 15) >> 4;
+    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+    if (nb >= 0) { grp_in[(int64_t)g * 16 + pos] = nb; grp_out[(int64_t)g * 16 + pos] = lane; }
+    if (lane < ng * 16 - n) { grp_in[(int64_t)g * 16 + n + lane] = -1; grp_out[(int64_t)g * 16 + n + lane] = -1; }
+    if (lane < ng) grp_o[g + lane] = o;
+    g += ng;
+  }
+}
+
+MOPA_API int mopa_rulebook_groups_count(const int32_t* nbr, int32_t K, int32_t num_out, int32_t* tile_groups, void* stream) {
+  if (K <= 0 || num_out <= 0) return MOPA_ERR_ARG;
+  k_rb_count<<<(num_out + 63) / 64, 64, 0, (hipStream_t)stream>>>(nbr, K, num_out, tile_groups);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+MOPA_API int mopa_rulebook_groups_fill(const int32_t* nbr, int32_t K, int32_t num_out, const int32_t* grp_start, int32_t* grp_o,
+                                       int32_t* grp_in, int32_t* grp_out, void* stream) {
+  if (K <= 0 || num_out <= 0) return MOPA_ERR_ARG;
+  k_rb_fill<<<(num_out + 63) / 64, 64, 0, (hipStream_t)stream>>>(nbr, K, num_out, grp_start, grp_o, grp_in, grp_out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Block kernel on the grouped rulebook: 4 waves = 4 consecutive 64-row tiles walk the filter offsets in lockstep;
+// the block stages the column slice W[o][:, c0:c0+16*NTW] of each offset ONCE in LDS (double-buffered, next offset's
+// global loads in flight during the current offset's MFMAs), so the MFMA B operand is a conflict-free ds_read instead
+// of a dependent L2 load per MFMA, and the L1 path only carries the row gathers.  Each wave still owns its tile's LDS
+// accumulator (no atomics); one barrier per offset.  Rows of the next group are gathered while the current group
+// is multiplied (C16 = Cin/16 in 1..4: whole rows in registers; C16 = 0: any Cin, chunk-pipelined).
+#define SPB_WAVES 4
+// NA = capacity of the per-group row registers in 16-channel chunks (1,2,3,4 exact fits; 8 and 12 cover any Cin up to
+// 128 / 192 with a guard), so the whole next group is always in flight during the current group's MFMAs.
+template <int NTW, int NA, bool ALIGNED>
+__global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+                                                                const int* __restrict__ grp_in, const int* __restrict__ grp_out,
+                                                                int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
+                                                                const float* __restrict__ W, int cout, int w_flip,
+                                                                float* __restrict__ out, int ld_out) {
+  constexpr int CP = NTW * 16;
+  constexpr int LD = CP + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cinp = (cin + 15) & ~15;
+  float* wbuf = smem;                         // [2][cinp][CP]
+  float* accs = smem + 2 * cinp * CP;         // [SPB_WAVES][64][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int ntiles = (A_out + 63) >> 6;
+  const int tile = blockIdx.x * SPB_WAVES + wv;
+  const int row0 = tile * 64;
+  const int c0 = blockIdx.y * CP;
+  const int cin16 = cinp >> 4;
+  float* acc = accs + wv * 64 * LD;
+  for (int i = lane; i < 64 * LD; i += 64) acc[i] = 0.f;
+
+  int g = 0, gend = 0;
+  if (tile < ntiles) { g = grp_start[tile]; gend = grp_start[tile + 1]; }
+  // record pipeline: (offset, input row, output rows) of group g ("c") and g+1 ("n"); g+2 is loaded in the loop
+  const int4 none = make_int4(-1, -1, -1, -1);
+  int o_c = K, o_n = K, irow_c = -1, irow_n = -1;
+  int4 ol_c = none, ol_n = none;
+  if (g < gend) {
+    o_c = grp_o[g]; irow_c = grp_in[(int64_t)g * 16 + r];
+    ol_c = *reinterpret_cast<const int4*>(grp_out + (int64_t)g * 16 + q * 4);
+  }
+  if (g + 1 < gend) {
+    o_n = grp_o[g + 1]; irow_n = grp_in[(int64_t)(g + 1) * 16 + r];
+    ol_n = *reinterpret_cast<const int4*>(grp_out + (int64_t)(g + 1) * 16 + q * 4);
+  }
+  float4 a_c[NA], a_n[NA];
+  auto gather = [&](int irow, float4* a) {
+#pragma unroll
+    for (int kk = 0; kk < NA; ++kk) {
+      const int kb = kk * 16 + q * 4;
+      if (ALIGNED) {
+        a[kk] = (irow >= 0 && kk < cin16) ? *reinterpret_cast<const float4*>(in + (int64_t)irow * ld_in + kb)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float* ar = in + (int64_t)(irow < 0 ? 0 : irow) * ld_in;
+        a[kk].x = (irow >= 0 && kb + 0 < cin) ? ar[kb + 0] : 0.f;
+        a[kk].y = (irow >= 0 && kb + 1 < cin) ? ar[kb + 1] : 0.f;
+        a[kk].z = (irow >= 0 && kb + 2 < cin) ? ar[kb + 2] : 0.f;
+        a[kk].w = (irow >= 0 && kb + 3 < cin) ? ar[kb + 3] : 0.f;
+      }
+    }
+  };
+  gather(irow_c, a_c);
+
+  // weight staging (issue-early / write-late): element e = tid + 256*i of the [cinp][CP] slice.  The global loads of
+  // offset o+1 are issued before the MFMAs of offset o and land in registers; they are written to the other LDS
+  // buffer only after the compute loop, just before the barrier, so their L2 latency hides under the MFMAs.
+  constexpr int WREG = (NA * 16 * CP + 64 * SPB_WAVES - 1) / (64 * SPB_WAVES);
+  const int wel = cinp * CP;
+  float wreg[WREG];
+  auto stage_load = [&](int o) {
+    const float* src = W + (int64_t)(w_flip ? K - 1 - o : o) * cin * cout + c0;
+#pragma unroll
+    for (int i = 0; i < WREG; ++i) {
+      const int e = tid + 64 * SPB_WAVES * i;
+      const int k = e / CP, c = e - k * CP;
+      wreg[i] = (e < wel && k < cin && c0 + c < cout) ? src[(int64_t)k * cout + c] : 0.f;
+    }
+  };
+  auto stage_write = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < WREG; ++i) {
+      const int e = tid + 64 * SPB_WAVES * i;
+      if (e < wel) dst[e] = wreg[i];
+    }
+  };
+  stage_load(0);
+  stage_write(wbuf);
+  __syncthreads();
+
+  for (int o = 0; o < K; ++o) {
+    const int cur = o & 1;
+    if (o + 1 < K) stage_load(o + 1);
+    const float* __restrict__ wl = wbuf + cur * wel + r * NTW;
+    while (__builtin_amdgcn_readfirstlane(o_c) == o) {  // this wave's groups of offset o (wave-uniform)
+      int o_nn = K, irow_nn = -1;
+      int4 ol_nn = none;
+      if (g + 2 < gend) {
+        o_nn = grp_o[g + 2]; irow_nn = grp_in[(int64_t)(g + 2) * 16 + r];
+        ol_nn = *reinterpret_cast<const int4*>(grp_out + (int64_t)(g + 2) * 16 + q * 4);
+      }
+      gather(irow_n, a_n);  // next group's rows in flight during this group's MFMAs
+      f32x4 d[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < NA; ++kk) {
+        if (kk < cin16) {
+          const float av[4] = {a_c[kk].x, a_c[kk].y, a_c[kk].z, a_c[kk].w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float* bp = wl + (kk * 16 + q * 4 + s) * CP;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bp[t], d[t], 0, 0, 0);
+          }
+        }
+      }
+      const int ol[4] = {ol_c.x, ol_c.y, ol_c.z, ol_c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ol[j] >= 0) {
+          float* ap = acc + ol[j] * LD + r * NTW;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) ap[t] += d[t][j];
+        }
+      ++g;
+      o_c = o_n; o_n = o_nn;
+      irow_c = irow_n; irow_n = irow_nn;
+      ol_c = ol_n; ol_n = ol_nn;
+#pragma unroll
+      for (int kk = 0; kk < NA; ++kk) a_c[kk] = a_n[kk];
+    }
+    if (o + 1 < K) stage_write(wbuf + (cur ^ 1) * wel);
+    __syncthreads();
+  }
+  if (tile >= ntiles) return;
+  if (ALIGNED) {
+    constexpr int V = CP / 4;
+    for (int i = lane; i < 64 * V; i += 64) {
+      const int rr = i / V, c4 = i - rr * V;
+      if (row0 + rr < A_out)
+        *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + c0 + c4 * 4) =
+            *reinterpret_cast<const float4*>(acc + rr * LD + c4 * 4);
+    }
+  } else {
+    for (int i = lane; i < 64 * CP; i += 64) {
+      const int rr = i / CP, c = i - rr * CP;
+      if (row0 + rr < A_out && c0 + c < cout) out[(int64_t)(row0 + rr) * ld_out + c0 + c] = acc[rr * LD + c];
+    }
+  }
+}
+
+static inline size_t blk_lds_bytes(int ntw, int cin) {
+  const int cp = ntw * 16, cinp = (cin + 15) & ~15;
+  return (size_t)(2 * cinp * cp + SPB_WAVES * 64 * (cp + 4)) * sizeof(float);
+}
+
+// Columns per block: the widest of 64/32/16 that divides Cout's 16-column tiles, fits 64 KB of LDS and still leaves
+// >= 512 blocks (2 per CU) when the layer allows it.
+static int blk_plan(int A_out, int cin, int cout) {
+  const int NT = (cout + 15) / 16;
+  const int64_t tiles4 = cdiv64(cdiv64(A_out, 64), SPB_WAVES);
+  int best = 1;
+  const int cand[3] = {4, 2, 1};
+  for (int i = 0; i < 3; ++i) {
+    const int c = cand[i];
+    if (NT % c) continue;
+    if (blk_lds_bytes(c, cin) > 64 * 1024) continue;
+    best = c;
+    if (tiles4 * (NT / c) >= 512) break;
+  }
+  return best;
+}
+
+template <int NTW, int NA>
+static int launch_blk(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
+                      int cin, const float* W, int cout, int w_flip, float* out, int ld_out, bool aligned, hipStream_t st) {
+  const int NT = (cout + 15) / 16;
+  dim3 grid((unsigned)cdiv64(cdiv64(A_out, 64), SPB_WAVES), (NT + NTW - 1) / NTW);
+  const size_t lds = blk_lds_bytes(NTW, cin);
+  if (aligned)
+    k_spconv_blk<NTW, NA, true><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+  else
+    k_spconv_blk<NTW, NA, false><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
+template <int NTW>
+static int dispatch_blk_c(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in,
+                          int ld_in, int cin, const float* W, int cout, int w_flip, float* out, int ld_out, bool aligned,
+                          hipStream_t st) {
+#define RB(C) return launch_blk<NTW, C>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out, aligned, st)
+  const int c16 = (cin + 15) / 16;
+  if (c16 <= 4) {
+    switch (c16) {
+      case 1: RB(1);
+      case 2: RB(2);
+      case 3: RB(3);
+      default: RB(4);
+    }
+  }
+  if (c16 <= 8) RB(8);
+  if (c16 <= 12) RB(12);
   return MOPA_ERR_ARG;
+#undef RB
+}
+
+// Same contract as mopa_spconv_fwd, on the grouped rulebook of the table (mopa_rulebook_groups_{count,fill}).
+MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* grp_o, const int32_t* grp_in,
+                                     const int32_t* grp_out, int32_t K, int32_t num_out, const float* in, int32_t ld_in,
+                                     int32_t cin, const float* weight, int32_t cout, int32_t w_flip, float* out,
+                                     int32_t ld_out, void* stream) {
+  if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
+                       (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
+  if (cin > 192) return MOPA_ERR_ARG;
+  const int ntw = aligned ? blk_plan(num_out, cin, cout) : 1;
+  if (blk_lds_bytes(ntw, cin) > 64 * 1024 || cin > 192) return MOPA_ERR_ARG;
+#define GO(N) return dispatch_blk_c<N>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st)
+  switch (ntw) {
+    case 1: GO(1);
+    case 2: GO(2);
+    default: GO(4);
+  }
+#undef GO
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -232,27 +546,42 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad(const int* __restrict__ nbr
     }
 }
 
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, int nchunks, int64_t n, float* __restrict__ dw,
-                               int accumulate) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = accumulate ? dw[i] : 0.f;
-    for (int c = 0; c < nchunks; ++c) s += slabs[(int64_t)c * n + i];
-    dw[i] = s;
+// dw[i] (+)= sum_c slabs[c][i].  16 chunk-lanes per element sum strided chunks, then a fixed-order LDS reduction:
+// deterministic, and short even with ~1000 chunks.
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int nchunks, int64_t n, float* __restrict__ dw,
+                                                       int accumulate) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (i < n)
+    for (int c = cl; c < nchunks; c += 16) s += slabs[(int64_t)c * n + i];
+  red[cl][el] = s;
+  __syncthreads();
+  if (cl == 0 && i < n) {
+    float t = accumulate ? dw[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][el];
+    dw[i] = t;
   }
 }
 
-static void wgrad_plan(int K, int A_out, int cin, int* mu, int* mblocks, int* nchunks, int* rows_per_chunk) {
+static void wgrad_plan(int K, int A_out, int cin, int cout, int* mu, int* mblocks, int* nchunks, int* rows_per_chunk) {
   const int mt = (cin + 15) / 16;
   int m = 1;
   for (int c = 4; c >= 1; --c)
     if (mt % c == 0) { m = c; break; }
   *mu = m;
   *mblocks = mt / m;
-  int64_t per = (int64_t)K * (*mblocks);
-  int nc = (int)cdiv64(1536, per);          // aim for ~1.5k waves
-  int maxc = (int)cdiv64(A_out, 512);       // at least 512 rows per chunk
-  if (nc > maxc) nc = maxc;
-  if (nc > 64) nc = 64;
+  // Many short chunks: each wave walks its rows 64 at a time with a dependent ballot/compact/gather chain, so the
+  // latency is hidden by wave count, not by the loop.  Bounded by the slab traffic (<= 32 MB) and >= 256 rows/chunk.
+  const int64_t per = (int64_t)K * (*mblocks);
+  int64_t nc = cdiv64(16384, per);
+  const int64_t max_rows = cdiv64(A_out, 256);
+  const int64_t max_slab = (32ll << 20) / ((int64_t)K * cin * cout * 4) + 1;
+  if (nc > max_rows) nc = max_rows;
+  if (nc > max_slab) nc = max_slab;
+  if (nc > 2048) nc = 2048;
   if (nc < 1) nc = 1;
   int rpc = (int)cdiv64(cdiv64(A_out, nc), 64) * 64;
   *nchunks = (int)cdiv64(A_out, rpc);
@@ -261,7 +590,7 @@ static void wgrad_plan(int K, int A_out, int cin, int* mu, int* mblocks, int* nc
 
 MOPA_API size_t mopa_spconv_wgrad_workspace_bytes(int32_t K, int32_t num_out, int32_t cin, int32_t cout) {
   int mu, mb, nc, rpc;
-  wgrad_plan(K, num_out, cin, &mu, &mb, &nc, &rpc);
+  wgrad_plan(K, num_out, cin, cout, &mu, &mb, &nc, &rpc);
   return align_up((size_t)nc * K * cin * cout * sizeof(float), 256);
 }
 
@@ -285,7 +614,7 @@ MOPA_API int mopa_spconv_bwd_weight(const int32_t* nbr, int32_t K, int32_t num_o
   if (ws_bytes < mopa_spconv_wgrad_workspace_bytes(K, num_out, cin, cout)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int mu, mb, nc, rpc;
-  wgrad_plan(K, num_out, cin, &mu, &mb, &nc, &rpc);
+  wgrad_plan(K, num_out, cin, cout, &mu, &mb, &nc, &rpc);
   dim3 grid(K, nc, mb);
   float* slabs = (float*)ws;
   const int nt = (cout + 15) / 16;
@@ -298,7 +627,7 @@ MOPA_API int mopa_spconv_bwd_weight(const int32_t* nbr, int32_t K, int32_t num_o
   }
   if (rc) return rc;
   const int64_t n = (int64_t)K * cin * cout;
-  k_reduce_slabs<<<stream_grid(n, 256), 256, 0, st>>>(slabs, nc, n, dweight, accumulate);
+  k_reduce_slabs<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, nc, n, dweight, accumulate);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

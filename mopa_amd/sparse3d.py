@@ -92,12 +92,37 @@ class Geometry3D:
             call("mopa_rulebook_updown", ptr(keys[l]), ptr(item_row[l + 1]), A[l], A[l + 1], ptr(ch), ptr(up), st)
             self.ch.append(ch)
             self.up.append(up)
+        # grouped rulebooks (MFMA-ready 16-rule groups per 64-row tile) for every table: count -> scan -> ONE more
+        # host sync for the group totals -> fill.  Built once per geometry, used by every layer's fwd and bwd-data.
+        self._rb = {}
+        tables = list(self.nbr27) + list(self.ch) + list(self.up)
+        starts = []
+        for t in tables:
+            K, Ao = t.shape
+            ntile = (Ao + 63) // 64
+            tg = torch.empty(ntile, **i32)
+            gs = torch.empty(ntile + 1, **i32)
+            call("mopa_rulebook_groups_count", ptr(t), K, Ao, ptr(tg), st)
+            ws = _ws(query("mopa_scan_workspace_bytes", ntile), device)
+            call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
+            starts.append(gs)
+        totals = torch.stack([gs[-1] for gs in starts]).cpu().tolist()  # second (and last) host sync
+        for t, gs, ng in zip(tables, starts, totals):
+            K, Ao = t.shape
+            go = torch.empty(max(ng, 1), **i32)
+            gi = torch.empty(max(ng, 1) * 16, **i32)
+            gout = torch.empty(max(ng, 1) * 16, **i32)
+            call("mopa_rulebook_groups_fill", ptr(t), K, Ao, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
+            self._rb[t.data_ptr()] = (gs, go, gi, gout)
         self.row_start = torch.empty(A[0] + 1, **i32)
         self.row_points = torch.empty(N, **i32)
         wsb = query("mopa_points_csr_workspace_bytes", A[0])
         ws = _ws(wsb, device)
         call("mopa_points_csr", ptr(self.point_row), N, A[0], ptr(self.row_start), ptr(self.row_points), ptr(ws),
              ws.numel(), st)
+
+    def rulebook(self, table: torch.Tensor):
+        return self._rb.get(table.data_ptr())
 
     @property
     def num_rules(self):
@@ -133,10 +158,19 @@ def new_view(rows, C, device, ld=None):
     return View(torch.empty(rows, ld or C, dtype=torch.float32, device=device), 0, C)
 
 
-def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False):
+def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False, rb=None):
+    """out = sum_o x[nbr[o]] @ w[o].  `rb` = the table's grouped rulebook (Geometry3D.rulebook(nbr)) selects the
+    prefetching kernel; without it the kernel compacts the dense table on the fly."""
     K, A_out = nbr.shape
     assert out.rows == A_out and w.shape == (K, x.C, out.C), (nbr.shape, x.C, out.C, w.shape)
-    call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, x.C, ptr(w), out.C, int(w_flip), out.p, out.ld, stream())
+    # measured on MI355X (profiles/r1_*): with >= 1500 64-row tiles one wave per tile on the dense table already fills
+    # the chip (high occupancy hides its per-offset chain); below that the grouped block kernel wins by 2-3x.
+    if rb is not None and (A_out + 63) // 64 < 1500:
+        gs, go, gi, gout = rb
+        call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, x.C, ptr(w), out.C,
+             int(w_flip), out.p, out.ld, stream())
+    else:
+        call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, x.C, ptr(w), out.C, int(w_flip), out.p, out.ld, stream())
 
 
 def spconv_transpose_weight(w: torch.Tensor) -> torch.Tensor:
@@ -217,7 +251,7 @@ class SCNNetFunction(torch.autograd.Function):
             return y
 
         def conv(name, table, x: View, out: View, kind):
-            spconv_fwd(table, x, P[name + ".weight"], out)
+            spconv_fwd(table, x, P[name + ".weight"], out, rb=geom.rulebook(table))
             tape.append(("conv", name, table, x, out, kind))
             return out
 
@@ -328,11 +362,13 @@ class SCNNetFunction(torch.autograd.Function):
                 wt = spconv_transpose_weight(w)
                 dx = new_view(x.rows, x.C, dev)
                 if ckind[0] == "subm":      # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
-                    spconv_fwd(table, dout, wt, dx, w_flip=True)
+                    spconv_fwd(table, dout, wt, dx, w_flip=True, rb=geom.rulebook(table))
                 elif ckind[0] == "down":    # rules reversed = the up table of the same level
-                    spconv_fwd(geom.up[ckind[1]], dout, wt, dx)
+                    rt = geom.up[ckind[1]]
+                    spconv_fwd(rt, dout, wt, dx, rb=geom.rulebook(rt))
                 else:                        # deconv: reversed rules = the children table
-                    spconv_fwd(geom.ch[ckind[1]], dout, wt, dx)
+                    rt = geom.ch[ckind[1]]
+                    spconv_fwd(rt, dout, wt, dx, rb=geom.rulebook(rt))
                 gmap[key(x)] = dx
             elif kind == "join":
                 # dec-block BN produced d(join) for all 2P columns; expose its halves under the keys of the

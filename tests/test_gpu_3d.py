@@ -104,10 +104,13 @@ def test_spconv_fwd_wgrad_dgrad_vs_oracle(cin, cout):
         xin[:, col:col + cin] = x.to(dev)
         outb = torch.full((A_out, cout + 8), 7.0, device=dev)
         xv, ov = s3.View(xin, col, cin), s3.View(outb, 4 if cout % 4 == 0 else 0, cout)
-        s3.spconv_fwd(tab_g, xv, w.to(dev), ov)
-        got = ov.dense().cpu()
         scale = max(1.0, float(ref.abs().max()))
-        np.testing.assert_allclose(got.numpy(), ref.detach().float().numpy(), rtol=1e-4, atol=2e-5 * scale)
+        for rb in (None, g.rulebook(tab_g)):   # dense-table kernel and grouped-rulebook kernel
+            assert rb is not None or True
+            outb.fill_(7.0)
+            s3.spconv_fwd(tab_g, xv, w.to(dev), ov, rb=rb)
+            got = ov.dense().cpu()
+            np.testing.assert_allclose(got.numpy(), ref.detach().float().numpy(), rtol=1e-4, atol=2e-5 * scale)
         assert (outb[:, ov.col + cout:] == 7.0).all()  # neighbours of the slice untouched
         # backward-weight
         dw = torch.empty(K, cin, cout, device=dev)
@@ -119,9 +122,9 @@ def test_spconv_fwd_wgrad_dgrad_vs_oracle(cin, cout):
         wt = s3.spconv_transpose_weight(w.to(dev))
         dx = s3.new_view(A_in, cin, dev)
         if table_name == "subm":
-            s3.spconv_fwd(tab_g, gv, wt, dx, w_flip=True)
+            s3.spconv_fwd(tab_g, gv, wt, dx, w_flip=True, rb=g.rulebook(tab_g))
         else:
-            s3.spconv_fwd(flip_for_dgrad, gv, wt, dx)
+            s3.spconv_fwd(flip_for_dgrad, gv, wt, dx, rb=g.rulebook(flip_for_dgrad))
         sx = max(1.0, float(xr.grad.abs().max()))
         np.testing.assert_allclose(dx.dense().cpu().numpy(), xr.grad.float().numpy(), rtol=1e-4, atol=2e-5 * sx)
 
