@@ -208,46 +208,58 @@ MOPA_API int mopa_conv2d_igemm(const float* in, const float* weight, const float
 
 // ----------------------------------------------------------------------------------------------
 // Backward-weight: dW[tap][ci][co] = sum_m A[m][tap][ci] * dY[m][co]   (same index map as above; dY plays "out").
-// Block = one 64x64 (ci, co) tile of one tap over a slice of the pixels; pixels are the GEMM K dimension, staged
-// 16 at a time.  Slice partials go to slabs [split][taps*Cin*Cout] and are summed in order by k_reduce (determinism).
+// Block = a 64x64 (ci, co) tile of NTAP horizontally adjacent taps (one filter row: the dY tile is staged once and
+// reused by all of them) over a slice of the pixels; pixels are the GEMM K dimension, staged 16 at a time; each
+// thread owns NTAP x 4 x 4 outputs.  Slice partials go to slabs [split][taps*Cin*Cout] and are summed in a fixed
+// order by k_reduce_slabs2 (deterministic, no float atomics).
 #define WBK 16
-template <int WM>  // 64, or 16 for the stem's 16-wide tap trick
+template <int WM, int NTAP>  // WM: 64, or 16 for the stem's 16-wide tap trick; NTAP: taps per block (divides TW)
 __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ in, const float* __restrict__ dy,
                                                        float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
   constexpr int WN = 64;
   constexpr int MT = WM / 16;  // micro rows per thread (ty has 16 values)
-  __shared__ __attribute__((aligned(16))) float As[2][WBK][WM + 4];
+  __shared__ __attribute__((aligned(16))) float As[2][NTAP][WBK][WM + 4];
   __shared__ __attribute__((aligned(16))) float Bs[2][WBK][WN + 4];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  const int tap = blockIdx.x;
+  const int tap0 = blockIdx.x * NTAP;
   const int tiles_n = g.Cout / WN;
   const int ci0 = (blockIdx.y / tiles_n) * WM, co0 = (blockIdx.y % tiles_n) * WN;
-  const int tyy = tap / g.TW, txx = tap - tyy * g.TW;
+  const int tyy = tap0 / g.TW, txx0 = tap0 - tyy * g.TW;
   const int M = g.B * g.OHl * g.OWl;
   const int mbeg = blockIdx.z * m_per_split, mend = min(M, mbeg + m_per_split);
   // staging: pixel k = t / 16, 4-float group = t % 16 (covers 64 floats per pixel row)
   const int sk = t >> 4, sq = t & 15;
-  float acc[MT][4];
+  float acc[NTAP][MT][4];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int n = 0; n < NTAP; ++n)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  float4 ra, rb;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[n][i][j] = 0.f;
+  float4 ra[NTAP], rb;
   auto load_tile = [&](int mb) {
     const int m = mb + sk;
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = ra;
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NTAP; ++n) ra[n] = rb;
     if (m < mend) {
       const int b = m / (g.OHl * g.OWl), r = m - b * g.OHl * g.OWl;
       const int oy = r / g.OWl, ox = r - oy * g.OWl;
-      const int iy = oy * g.IS + g.IY0 + tyy * g.IDY, ix = ox * g.IS + g.IX0 + txx * g.IDX;
-      if (sq * 4 < WM && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
-        ra = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + ci0 + sq * 4);
+      const int iy = oy * g.IS + g.IY0 + tyy * g.IDY;
+#pragma unroll
+      for (int n = 0; n < NTAP; ++n) {
+        const int ix = ox * g.IS + g.IX0 + (txx0 + n) * g.IDX;
+        if (sq * 4 < WM && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+          ra[n] = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + ci0 + sq * 4);
+      }
       rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + co0 + sq * 4);
     }
   };
   auto store_tile = [&](int buf) {
-    if (sq * 4 < WM) *reinterpret_cast<float4*>(&As[buf][sk][sq * 4]) = ra;
+    if (sq * 4 < WM) {
+#pragma unroll
+      for (int n = 0; n < NTAP; ++n) *reinterpret_cast<float4*>(&As[buf][n][sk][sq * 4]) = ra[n];
+    }
     *reinterpret_cast<float4*>(&Bs[buf][sk][sq * 4]) = rb;
   };
   int buf = 0;
@@ -259,20 +271,23 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
   for (int mb = mbeg; mb < mend; mb += WBK) {
     const bool more = mb + WBK < mend;
     if (more) load_tile(mb + WBK);
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < WBK; ++k) {
       const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][k][tx * 4]);
-      float a[MT];
-      if (MT == 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][k][ty * 4]);
-        a[0] = a4.x; a[1 % MT] = a4.y; a[2 % MT] = a4.z; a[3 % MT] = a4.w;
-      } else {
-        a[0] = As[buf][k][ty];
-      }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        acc[i][0] = fmaf(a[i], b4.x, acc[i][0]); acc[i][1] = fmaf(a[i], b4.y, acc[i][1]);
-        acc[i][2] = fmaf(a[i], b4.z, acc[i][2]); acc[i][3] = fmaf(a[i], b4.w, acc[i][3]);
+      for (int n = 0; n < NTAP; ++n) {
+        float a[MT];
+        if (MT == 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][n][k][ty * 4]);
+          a[0] = a4.x; a[1 % MT] = a4.y; a[2 % MT] = a4.z; a[3 % MT] = a4.w;
+        } else {
+          a[0] = As[buf][n][k][ty];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[n][i][0] = fmaf(a[i], b4.x, acc[n][i][0]); acc[n][i][1] = fmaf(a[i], b4.y, acc[n][i][1]);
+          acc[n][i][2] = fmaf(a[i], b4.z, acc[n][i][2]); acc[n][i][3] = fmaf(a[i], b4.w, acc[n][i][3]);
+        }
       }
     }
     if (more) {
@@ -282,26 +297,42 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
     }
   }
   const int64_t wsz = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
-  float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)tap * g.Cin + ci0) * g.Cout + co0;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int ci = (MT == 4) ? ty * 4 + i : ty;
-    *reinterpret_cast<float4*>(dst + (int64_t)ci * g.Cout + tx * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  for (int n = 0; n < NTAP; ++n) {
+    float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)(tap0 + n) * g.Cin + ci0) * g.Cout + co0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ci = (MT == 4) ? ty * 4 + i : ty;
+      *reinterpret_cast<float4*>(dst + (int64_t)ci * g.Cout + tx * 4) = make_float4(acc[n][i][0], acc[n][i][1], acc[n][i][2], acc[n][i][3]);
+    }
   }
 }
 
-__global__ void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw, int accumulate) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = accumulate ? dw[i] : 0.f;
-    for (int c = 0; c < nsplit; ++c) s += slabs[(int64_t)c * n + i];
-    dw[i] = s;
+// dw[i] (+)= sum_c slabs[c][i]: 16 chunk-lanes per element + fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
+                                                        int accumulate) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (i < n)
+    for (int c = cl; c < nsplit; c += 16) s += slabs[(int64_t)c * n + i];
+  red[cl][el] = s;
+  __syncthreads();
+  if (cl == 0 && i < n) {
+    float t = accumulate ? dw[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][el];
+    dw[i] = t;
   }
 }
+
+static int wgrad_ntap(const ConvGeom& g) { return (g.Cin >= 64 && g.TW % 3 == 0) ? 3 : 1; }
 
 static void wgrad_split(const ConvGeom& g, int* nsplit, int* m_per_split) {
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
   const int wm = g.Cin >= 64 ? 64 : 16;
-  const int64_t tiles = (int64_t)g.TH * g.TW * (g.Cin / wm) * (g.Cout / 64);
+  const int64_t tiles = (int64_t)(g.TH * g.TW / wgrad_ntap(g)) * (g.Cin / wm) * (g.Cout / 64);
   int64_t ns = cdiv64(2048, tiles);
   const int64_t maxs = cdiv64(M, 256);
   if (ns > maxs) ns = maxs;
@@ -332,14 +363,19 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
   hipStream_t st = (hipStream_t)stream;
   float* slabs = (float*)ws;
   if (g.Cin >= 64) {
-    dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
-    k_conv2d_wgrad<64><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    if (wgrad_ntap(g) == 3) {
+      dim3 grid(g.TH * g.TW / 3, (g.Cin / 64) * (g.Cout / 64), ns);
+      k_conv2d_wgrad<64, 3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    } else {
+      dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
+      k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    }
   } else {
     dim3 grid(g.TH * g.TW, g.Cout / 64, ns);
-    k_conv2d_wgrad<16><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    k_conv2d_wgrad<16, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
   }
   const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
-  k_reduce_slabs2<<<stream_grid(n, 256), 256, 0, st>>>(slabs, ns, n, dweight, accumulate);
+  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
