@@ -195,11 +195,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # (only differs from LOCAL_RANK in the single-GPU plumbing test below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI by default; MOPA_BENCH_BACKEND=gloo lets two ranks share one GPU to test the multi-process
+        # plumbing on a 1-GPU box (RCCL refuses two ranks on one device).
+        backend = os.environ.get("MOPA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mopa_amd import synth
     from mopa_amd.common.utils.loss import seg_ce, xm_kl
@@ -330,9 +338,14 @@ def main():
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
         roof = sp
         k2 = timer2d.summary() if joint else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if joint and os.path.exists(tpath):                                  # of this same command (profiles/traffic.py)
+            traffic = json.load(open(tpath)).get("k_conv2d_igemm", {}).get("hbm_bytes_per_launch")
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r1_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
                     "kernel": "k_conv2d_igemm (fp32 vector FMA; fwd + bwd-data + convT)",
                     "launches_per_step": k2["launches"] // args.steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}

@@ -368,6 +368,10 @@ MOPA_API int mopa_input_layer_bwd(const float* dout, int32_t ld_dout, const int3
 // ------------------------------------------------------------------------------------------ OutputLayer + heads
 // feats[p] = y[point_row[p]] (A.3);  logit_h[p] = feats[p] @ W_h^T + b_h for h = 1,2 (xmuda_arch.py:116,124).
 // 16 lanes per point (lane = feature channel group); M = feature width (multiple of 4, <= 64), NC <= 32 classes.
+// M/4 lanes cooperate on one point: each lane moves one float4 of the row (the gather reads the row once, coalesced,
+// and writes feats once) and holds the partial dot products of its 4 channels with every class row of W1 / W2; a
+// shuffle tree over the M/4 lanes finishes the logits.  M/4 must be a power of two <= 16 (M = 16: SCN, M = 64: 2D).
+#define OH_MAXNC 16
 __global__ __launch_bounds__(256) void k_output_heads_fwd(const float* __restrict__ y, int ld, const int* __restrict__ point_row,
                                                            int N, int M, int NC, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ w2,
@@ -378,19 +382,36 @@ __global__ __launch_bounds__(256) void k_output_heads_fwd(const float* __restric
   for (int i = threadIdx.x; i < nw; i += 256) { lw[i] = w1[i]; if (w2) lw[nw + NC + i] = w2[i]; }
   for (int i = threadIdx.x; i < NC; i += 256) { lw[nw + i] = b1[i]; if (w2) lw[2 * nw + NC + i] = b2[i]; }
   __syncthreads();
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
-    const float* __restrict__ src = y + (int64_t)point_row[p] * ld;
-    for (int c = 0; c < M; c += 4)
-      *reinterpret_cast<float4*>(feats + (int64_t)p * M + c) = *reinterpret_cast<const float4*>(src + c);
-    for (int k = 0; k < NC; ++k) {
-      float a1 = lw[nw + k], a2 = w2 ? lw[2 * nw + NC + k] : 0.f;
-      for (int c = 0; c < M; ++c) {
-        const float fv = src[c];  // L1-resident row
-        a1 = fmaf(fv, lw[k * M + c], a1);
-        if (w2) a2 = fmaf(fv, lw[nw + NC + k * M + c], a2);
+  const int MQ = M >> 2;             // lanes per point
+  const int PPB = 256 / MQ;          // points per block iteration
+  const int cq = threadIdx.x % MQ, pl = threadIdx.x / MQ;
+  for (int p0 = blockIdx.x * PPB; p0 < N; p0 += gridDim.x * PPB) {
+    const int p = p0 + pl;
+    const bool ok = p < N;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      v = *reinterpret_cast<const float4*>(y + (int64_t)point_row[p] * ld + cq * 4);
+      *reinterpret_cast<float4*>(feats + (int64_t)p * M + cq * 4) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < OH_MAXNC; ++k) {
+      if (k < NC) {
+        const float* wr = lw + k * M + cq * 4;
+        float a1 = fmaf(v.x, wr[0], fmaf(v.y, wr[1], fmaf(v.z, wr[2], v.w * wr[3])));
+        float a2 = 0.f;
+        if (w2) {
+          const float* wr2 = lw + nw + NC + k * M + cq * 4;
+          a2 = fmaf(v.x, wr2[0], fmaf(v.y, wr2[1], fmaf(v.z, wr2[2], v.w * wr2[3])));
+        }
+        for (int o = MQ >> 1; o > 0; o >>= 1) {
+          a1 += __shfl_xor(a1, o, 64);
+          a2 += __shfl_xor(a2, o, 64);
+        }
+        if (ok && cq == 0) {
+          logit1[(int64_t)p * NC + k] = a1 + lw[nw + k];
+          if (w2) logit2[(int64_t)p * NC + k] = a2 + lw[2 * nw + NC + k];
+        }
       }
-      logit1[(int64_t)p * NC + k] = a1;
-      if (w2) logit2[(int64_t)p * NC + k] = a2;
     }
   }
 }
@@ -399,10 +420,12 @@ MOPA_API int mopa_output_layer_heads_fwd(const float* y, int32_t ld_y, const int
                                          int32_t M, int32_t num_classes, const float* w1, const float* b1,
                                          const float* w2, const float* b2, float* feats, float* logit1, float* logit2,
                                          void* stream) {
-  if (n_points <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > 64 || ld_y < M || (ld_y & 3))
+  const int mq = M >> 2;
+  if (n_points <= 0 || M <= 0 || M > 64 || (M & 3) || (mq & (mq - 1)) != 0 || num_classes <= 0 || num_classes > OH_MAXNC ||
+      ld_y < M || (ld_y & 3))
     return MOPA_ERR_ARG;
   const size_t sh = (size_t)(2 * num_classes * M + 2 * num_classes) * sizeof(float);
-  k_output_heads_fwd<<<stream_grid(n_points, 256), 256, sh, (hipStream_t)stream>>>(
+  k_output_heads_fwd<<<stream_grid((int64_t)n_points * mq, 256), 256, sh, (hipStream_t)stream>>>(
       y, ld_y, point_row, n_points, M, num_classes, w1, b1, w2, b2, feats, logit1, logit2);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
