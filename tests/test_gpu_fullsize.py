@@ -1,0 +1,129 @@
+"""Full BASELINE-size checks through size-independent properties (the oracle is too slow / large there).
+
+Config 5 shape (A2D2->KITTI stress: 64 beams x 1875 azimuths = 120,000 pts/scan) for the integer geometry, the
+nuScenes shape (34,880 pts, 302x480) for the networks.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(c):
+    return (c[:, 3] << 36) | (c[:, 0] << 24) | (c[:, 1] << 12) | c[:, 2]
+
+
+def test_geometry_invariants_at_120k_points_per_scan():
+    from mopa_amd import synth
+    from mopa_amd.sparse3d import Geometry3D
+    scans = [synth.voxelize(synth.lidar_points(50 + i, synth.KITTI)) for i in range(4)]
+    coords = torch.cat([torch.cat([torch.from_numpy(c), torch.full((len(c), 1), i, dtype=torch.int64)], 1)
+                        for i, c in enumerate(scans)])
+    assert coords.shape[0] == 4 * 120_000
+    g = Geometry3D(coords, 7, 4096, "cuda")
+    cd = coords.cuda()
+    keys = _pack(cd)
+    pr = g.point_row.long()
+    # (a) every point maps to the row that holds its own key; rows are exactly the distinct keys
+    assert torch.equal(g.row_keys[0][pr], keys)
+    assert g.num_active[0] == torch.unique(keys).numel()
+    # (b) first-seen numbering: the first point of row r comes before the first point of row r+1
+    first = torch.full((g.num_active[0],), coords.shape[0], dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, pr, torch.arange(coords.shape[0], device="cuda"), "amin")
+    assert bool((first[1:] > first[:-1]).all())
+    rs = g.row_start.long()
+    assert int(rs[-1]) == coords.shape[0] and bool((rs[1:] > rs[:-1]).all())
+    for l in range(7):
+        nbr = g.nbr27[l].long()
+        A = g.num_active[l]
+        assert bool((nbr[13] == torch.arange(A, device="cuda")).all())          # centre offset = identity
+        for o in (0, 5, 12, 20):                                                 # symmetry used by backward-data
+            i = torch.nonzero(nbr[o] >= 0).squeeze(1)
+            assert bool((nbr[26 - o][nbr[o][i]] == i).all())
+        # grouped rulebook == dense table as a multiset of (offset, in, out) rules
+        gs, go, gi, gout = g.rulebook(g.nbr27[l])
+        ngrp = int(gs[-1])
+        tile = torch.bucketize(torch.arange(ngrp, device="cuda"), gs[1:].long(), right=True)
+        o_e = go[:ngrp].long().repeat_interleave(16)
+        in_e, out_e = gi[:ngrp * 16].long(), gout[:ngrp * 16].long()
+        ok = in_e >= 0
+        rule = (o_e[ok] * A + tile.repeat_interleave(16)[ok] * 64 + out_e[ok]) * (A + 1) + in_e[ok]
+        oo, ii = torch.nonzero(nbr >= 0, as_tuple=True)
+        ref = (oo * A + ii) * (A + 1) + nbr[oo, ii]
+        assert torch.equal(torch.sort(rule).values, torch.sort(ref).values)
+    for l in range(6):
+        par, ch, up = g.parent[l].long(), g.ch[l].long(), g.up[l].long()
+        Af = g.num_active[l]
+        k = g.row_keys[l]
+        octant = ((k >> 24) & 1) * 4 + ((k >> 12) & 1) * 2 + (k & 1)
+        ar = torch.arange(Af, device="cuda")
+        assert bool((ch[octant, par] == ar).all())                               # child table inverts parent
+        assert bool((up[octant, ar] == par).all()) and int((up >= 0).sum()) == Af
+        assert g.num_active[l + 1] == torch.unique(par).numel() and int((ch >= 0).sum()) == Af
+        kc = (k & ~0xFFFFFFFFF) | ((k & 0xFFFFFFFFF & ~0x001001001) >> 1)
+        assert torch.equal(g.row_keys[l + 1][par], kc)                           # parent key = halved coordinates
+
+
+def test_sparse_conv_linearity_and_locality_full_size():
+    """conv(a*x + b*y) == a*conv(x) + b*conv(y); a one-hot input row only reaches its <= 27 neighbours."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd import synth
+    b = synth.make_batch(8, H=16, W=16)
+    g = s3.Geometry3D(b["x"][0], 3, 4096, "cuda")
+    A = g.num_active[0]
+    torch.manual_seed(0)
+    w = torch.randn(27, 32, 48, device="cuda") * 0.1
+    x, y = torch.randn(A, 32, device="cuda"), torch.randn(A, 32, device="cuda")
+
+    def conv(t):
+        out = s3.new_view(A, 48, "cuda")
+        s3.spconv_fwd(g.nbr27[0], s3.View(t.contiguous()), w, out, rb=g.rulebook(g.nbr27[0]))
+        return out.dense()
+
+    lhs, rhs = conv(2.0 * x - 3.0 * y), 2.0 * conv(x) - 3.0 * conv(y)
+    assert float((lhs - rhs).abs().max()) <= 1e-4 * float(rhs.abs().max())
+    e = torch.zeros(A, 32, device="cuda")
+    j = A // 3
+    e[j, 5] = 1.0
+    hit = torch.nonzero(conv(e).abs().sum(1) > 0).squeeze(1)
+    nb = g.nbr27[0].long()
+    allowed = torch.nonzero((nb == j).any(0)).squeeze(1)
+    assert set(hit.tolist()) <= set(allowed.tolist()) and hit.numel() <= 27
+
+
+def test_joint_training_step_reduces_the_loss_full_size():
+    """A few FlatAdam steps on ONE fixed nuScenes-shape batch (2 scans) must lower CE + KL + SAM loss."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import mask_cons_loss, seg_ce, softmax_lastdim, xm_kl
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    from mopa_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    cfg = default_cfg()
+    m2, iou2 = build_model_2d(cfg)
+    m3, iou3 = build_model_3d(cfg)
+    m2, m3 = m2.cuda().train(), m3.cuda().train()
+    o2, o3 = FlatAdam(m2.parameters(), lr=1e-3), FlatAdam(m3.parameters(), lr=1e-3)
+    b = synth.make_batch(2)
+    lab = b["seg_label"].cuda()
+    losses = []
+    for it in range(6):
+        o2.zero_grad(); o3.zero_grad()
+        p2, p3 = m2(b), m3(b)
+        assert p2["seg_logit_all"].shape == (2, 302, 480, 5) and p2["feats"].shape == (2 * 34880, 64)
+        assert p3["feats"].shape == (2 * 34880, 16)
+        l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"]) + \
+            0.01 * mask_cons_loss(softmax_lastdim(p2["seg_logit_all"]), b["sam_mask_ls"], True)
+        l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
+        l2.backward(); l3.backward()
+        o2.step(); o3.step()
+        losses.append(float(l2) + float(l3))
+        iou2.update_dict(p2, {"seg_label": lab}); iou3.update_dict(p3, {"seg_label": lab})
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert int(iou2.mat.sum()) == 6 * int((lab != -100).sum())
+    # eval path of the EMA teacher: one image, one index array (train_xmuda_mopa.py:270-273)
+    m2.eval()
+    with torch.no_grad():
+        e = m2({"img": b["img"][:1], "img_indices": [b["img_indices"][0]]})
+    assert e["seg_logit"].shape == (34880, 5) and torch.isfinite(e["seg_logit"]).all()
