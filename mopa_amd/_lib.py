@@ -27,6 +27,8 @@ SIGNATURES = {
     "mopa_rulebook_updown": ("i", "ppiippp"),
     "mopa_points_csr_workspace_bytes": ("z", "l"),
     "mopa_points_csr": ("i", "piipppzp"),
+    "mopa_voxelize_workspace_bytes": ("z", ""),
+    "mopa_voxelize": ("i", "pifipilpppzp"),
     "mopa_scan_workspace_bytes": ("z", "l"),
     "mopa_scan_exclusive_i32": ("i", "ppippzp"),
     # ---- sparse conv (spconv.hip)

@@ -390,3 +390,86 @@ MOPA_API int mopa_points_csr(const int32_t* point_row, int32_t n_points, int32_t
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
+
+// ---------------------------------------------------------------- device voxeliser
+// coords = trunc( float( double( rint(p * scale) - min_p rint(p * scale) ) + offset ) ),  offset_a = clip(full_scale -
+// max_a - 0.001f, 0) * u_a  -- the arithmetic of augment_and_scale_3d after its rotation
+// (mopa/data/utils/augmentation_3d.py:48-59) followed by the dataset's int64 cast and in-range filter
+// (mopa/data/nuscenes/nuscenes_dataloader.py:419-424).  Output rows are [x, y, z, batch] int64 = the collate layout
+// (mopa/data/collate.py:183-185); keep[i] = 0 marks points the dataset would drop.  Bit-exact with the reference
+// (fixture G4) for a given set of (already rotated) points and translation draws u.
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_vox_init(int* __restrict__ mm) {
+  if (threadIdx.x < 3) { mm[threadIdx.x] = 0x7FFFFFFF; mm[3 + threadIdx.x] = (int)0x80000000; }
+}
+__global__ __launch_bounds__(256) void k_vox_minmax(const float* __restrict__ pts, int n, float scale, int* __restrict__ mm) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float r = rintf(pts[3 * (int64_t)i + a] * scale);
+      lo[a] = fminf(lo[a], r);
+      hi[a] = fmaxf(hi[a], r);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {  // min / max are order-independent: integer atomics on the ordered bit pattern
+      atomicMin(&mm[a], f2ord(lo[a]));
+      atomicMax(&mm[3 + a], f2ord(hi[a]));
+    }
+  }
+}
+__global__ void k_vox_coords(const float* __restrict__ pts, int n, float scale, int full_scale, const int* __restrict__ mm,
+                             double u0, double u1, double u2, int transl, int64_t batch, int64_t* __restrict__ coords,
+                             unsigned char* __restrict__ keep) {
+  const double u[3] = {u0, u1, u2};
+  float mn[3];
+  double off[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = ord2f(mm[a]);
+    const float mx = ord2f(mm[3 + a]) - mn[a];                    // max of the min-shifted coordinates (exact)
+    float t = (float)full_scale - mx;                             // float32 like numpy's weak-scalar arithmetic
+    t = t - 0.001f;
+    t = fmaxf(t, 0.f);
+    off[a] = transl ? (double)t * u[a] : 0.0;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float c = rintf(pts[3 * (int64_t)i + a] * scale) - mn[a];
+      if (transl) c = (float)((double)c + off[a]);
+      const int64_t ci = (int64_t)c;
+      coords[4 * (int64_t)i + a] = ci;
+      ok = ok && ci >= 0 && ci < full_scale;
+    }
+    coords[4 * (int64_t)i + 3] = batch;
+    keep[i] = ok ? 1 : 0;
+  }
+}
+
+MOPA_API size_t mopa_voxelize_workspace_bytes(void) { return 256; }
+
+// points [n][3] fp32 (already rotated / scaled by the augmentation), u_host: the 3 uniform draws of the translation.
+MOPA_API int mopa_voxelize(const float* points, int32_t n, float scale, int32_t full_scale, const double* u_host,
+                           int32_t transl, int64_t batch_index, int64_t* coords /*[n][4]*/, uint8_t* keep /*[n]*/, void* ws,
+                           size_t ws_bytes, void* stream) {
+  if (n <= 0 || full_scale <= 0 || (transl && !u_host)) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_voxelize_workspace_bytes()) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* mm = (int*)ws;
+  k_vox_init<<<1, 64, 0, st>>>(mm);
+  k_vox_minmax<<<stream_grid(n, 256), 256, 0, st>>>(points, n, scale, mm);
+  k_vox_coords<<<stream_grid(n, 256), 256, 0, st>>>(points, n, scale, full_scale, mm, transl ? u_host[0] : 0.0,
+                                                    transl ? u_host[1] : 0.0, transl ? u_host[2] : 0.0, transl, batch_index,
+                                                    coords, keep);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

@@ -175,18 +175,31 @@ def gen_g3():
 
 # ----------------------------------------------------------------------------- G4
 def gen_g4():
+    """Voxeliser pins.  Besides the reference's outputs we record the reference's own rotated points and the three
+    uniform draws it used for the translation (replayed from the same seed), so that a device voxeliser can be
+    checked bit-exactly on the stages after the rotation."""
     from mopa.data.utils.augmentation_3d import augment_and_scale_3d  # reference
 
     save = {}
     for k in range(3):
         rng = np.random.Generator(np.random.PCG64(40 + k))
         pts = (rng.standard_normal((500, 3)) * np.array([20, 20, 1.5])).astype(np.float32)
+        kw = dict(noisy_rot=0.1 * (k > 0), flip_y=0.5 * (k > 0), rot_z=6.2831 * (k > 1), transl=k > 0)
         np.random.seed(k)
-        coords, _ = augment_and_scale_3d(pts, 20, 4096, noisy_rot=0.1 * (k > 0), flip_y=0.5 * (k > 0),
-                                         rot_z=6.2831 * (k > 1), transl=k > 0)
+        coords, aug = augment_and_scale_3d(pts, 20, 4096, **kw)
+        # replay the draws of augmentation_3d.py:26-59 in order to capture the translation's rand(3)
+        np.random.seed(k)
+        if kw["noisy_rot"] > 0:
+            np.random.randn(3, 3)
+        if kw["flip_y"] > 0:
+            np.random.randint(0, 2)
+        if kw["rot_z"] > 0:
+            np.random.rand()
+        u = np.random.rand(3) if kw["transl"] else np.zeros(3)
         ci = coords.astype(np.int64)  # nuscenes_dataloader.py:419
         keep = (ci.min(1) >= 0) & (ci.max(1) < 4096)  # :422-424
         save[f"points{k}"], save[f"coords{k}"], save[f"keep{k}"] = pts, ci, keep
+        save[f"aug_points{k}"], save[f"u{k}"], save[f"transl{k}"] = np.asarray(aug, np.float32), u, np.asarray(kw["transl"])
     np.savez_compressed(os.path.join(OUT, "g4_voxelize.npz"), **save)
     print("G4 ok")
 
@@ -237,4 +250,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_stubs()
-    gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g7()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+    else:
+        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g7()

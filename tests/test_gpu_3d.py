@@ -263,3 +263,27 @@ def test_net3dseg_duplicate_points_and_extra_feature_rows():
     assert out["feats"].shape == (c.shape[0], 16)
     half = c.shape[0] // 2
     assert torch.equal(out["feats"][:half], out["feats"][half:])
+
+
+def test_device_voxelizer_bit_exact_with_reference(golden_dir):
+    """G4: coords of augment_and_scale_3d (+ int64 cast, range filter) from the reference's rotated points."""
+    import os
+    from mopa_amd.voxelize import collate_scans, voxelize_scan
+    from oracle.voxelize import voxel_coords
+    g = dict(np.load(os.path.join(golden_dir, "g4_voxelize.npz")))
+    for k in range(3):
+        u = g[f"u{k}"] if bool(g[f"transl{k}"]) else None
+        coords, keep = voxelize_scan(torch.from_numpy(g[f"aug_points{k}"]).cuda(), 20, 4096, u, batch_index=k)
+        assert np.array_equal(coords[:, :3].cpu().numpy(), g[f"coords{k}"][g[f"keep{k}"]])
+        assert np.array_equal(keep.cpu().numpy(), g[f"keep{k}"]) and bool((coords[:, 3] == k).all())
+    # out-of-field points are dropped, full-size synthetic scan agrees with the oracle, collate layout
+    from mopa_amd import synth
+    pts = synth.lidar_points(3)
+    big = pts.copy()
+    big[:7] *= 400.0  # > 1 km away: outside the 4096-voxel field at 5 cm
+    c, keep = voxelize_scan(torch.from_numpy(big).cuda(), 20)
+    ci, kref = voxel_coords(big, 20)
+    assert np.array_equal(keep.cpu().numpy(), kref) and np.array_equal(c[:, :3].cpu().numpy(), ci[kref]) and not kref.all()
+    x = collate_scans([torch.from_numpy(synth.lidar_points(s)).cuda() for s in (0, 1)], 20)
+    ref = synth.make_batch(2, H=8, W=8)["x"][0]
+    assert torch.equal(x[0].cpu(), ref) and x[1].shape == (ref.shape[0], 1)

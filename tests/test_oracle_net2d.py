@@ -81,3 +81,11 @@ def test_g5_segiou(golden_dir):
     mat = losses.seg_iou_update(None, logit, gt, 5)
     mat = losses.seg_iou_update(mat, logit.flip(0), gt, 5)
     assert (mat.numpy() == g["iou_mat"]).all()
+
+
+def test_g4_voxel_coords(golden_dir):
+    from oracle.voxelize import voxel_coords
+    g = _load(golden_dir, "g4_voxelize.npz")
+    for k in range(3):
+        ci, keep = voxel_coords(g[f"aug_points{k}"], 20, 4096, g[f"u{k}"] if bool(g[f"transl{k}"]) else None)
+        assert np.array_equal(ci, g[f"coords{k}"]) and np.array_equal(keep, g[f"keep{k}"])
