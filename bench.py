@@ -33,8 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="joint", choices=["joint", "3d"])
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--workload", default="joint", choices=["joint", "3d", "mopa"],
+                    help="joint = BASELINE configs[2] (default), 3d = configs[1], mopa = configs[3] per-GPU step")
+    ap.add_argument("--batch", type=int, default=None, help="scans per domain per GPU (default 8; 4 for mopa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -210,13 +211,16 @@ def main():
             dist.init_process_group(backend)
 
     from mopa_amd import synth
-    from mopa_amd.common.utils.loss import seg_ce, xm_kl
+    from mopa_amd.common.utils.loss import mask_cons_loss, seg_ce, softmax_lastdim, xm_kl
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_2d, build_model_3d
     from mopa_amd.optim import FlatAdam
     from mopa_amd.sparse3d import Geometry3D
 
-    joint = args.workload == "joint"
+    joint = args.workload in ("joint", "mopa")
+    mopa = args.workload == "mopa"
+    if args.batch is None:
+        args.batch = 4 if mopa else 8
     torch.manual_seed(1 + rank)
     cfg = default_cfg(num_classes=5, dual_head=True)
     model3d, _ = build_model_3d(cfg)
@@ -255,6 +259,28 @@ def main():
             bt["img"] = torch.stack([torch.from_numpy(r.random((3, H, W), dtype=np.float32)) for _, _, r in scans]).to(dev)
             idx = [np.stack([r.integers(0, H, len(c)), r.integers(0, W, len(c))], 1) for c, _, r in scans]
             bt["pix"] = model2d.pack_indices(idx, H, W, dev)
+        if mopa and j == 1:
+            # target-domain extras of the MoPA iteration: pseudo labels (train_xmuda_mopa.py:450-469), SAM masks (:472-480)
+            # and the VGI-style third 3D batch: each scan + one 500-point object cluster, re-voxelised (:483-576)
+            n = locs.shape[0]
+            r0 = scans[0][2]
+            for key in ("pl2d", "pl3d"):
+                pl = r0.integers(0, 5, n).astype(np.int64)
+                pl[r0.random(n) < 0.5] = -100
+                bt[key] = torch.from_numpy(pl).to(dev)
+            bt["sam"] = [torch.from_numpy(synth.sam_mask(r, H, W)).to(dev) for _, _, r in scans]
+            vl, vlab = [], []
+            for i, (c, _, r) in enumerate(scans):
+                centre = c[r.integers(0, len(c))]
+                obj = centre[None, :] + r.integers(-15, 16, (500, 3))
+                cc = np.clip(np.concatenate([c, obj]), 0, 4095)
+                vl.append(torch.cat([torch.from_numpy(cc), torch.full((len(cc), 1), i, dtype=torch.int64)], 1))
+                lab = np.concatenate([r.integers(0, 5, len(c)), np.full(500, 1)]).astype(np.int64)
+                lab[:len(c)][r.random(len(c)) < 0.5] = -100
+                vlab.append(torch.from_numpy(lab))
+            vl = torch.cat(vl)
+            bt["vgi_locs"], bt["vgi_feats"] = vl.to(dev), torch.ones(vl.shape[0], 1, device=dev)
+            bt["vgi_label"] = torch.cat(vlab).to(dev)
         batches.append(bt)
 
     timer = ConvTimer()
@@ -281,6 +307,13 @@ def main():
         if supervised:
             l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
             l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+        elif mopa:
+            l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
+            l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
+            l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
+            gv = Geometry3D(b["vgi_locs"], 7, 4096, dev)                      # third 3D pass on the VGI-style batch
+            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]], "geometry_3d": gv})
+            l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
         l2.backward()
         l3.backward()
         return l2.detach() + l3.detach()
@@ -349,7 +382,10 @@ def main():
                     "kernel": "k_conv2d_igemm (fp32 vector FMA; fwd + bwd-data + convT)",
                     "launches_per_step": k2["launches"] // args.steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}
-        wl = ("Full xMUDA 2D+3D joint step + xModalKL (BASELINE configs[2]): "
+        wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
+              f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
+              "third 3D pass on the VGI-style batch (each target scan + a 500-pt cluster), backward, Adam") if mopa else (
+              "Full xMUDA 2D+3D joint step + xModalKL (BASELINE configs[2]): "
               f"{B} source + {B} target scans/GPU per step, Net2DSeg(UNetResNet34, 302x480) + Net3DSeg(SCN UNet, 34,880 pts), "
               "CE + cross-modal KL, backward, Adam") if joint else (
               "Net3DSeg SCN-UNet only (BASELINE configs[1]): geometry+fwd+CE+bwd+Adam, "
