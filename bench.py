@@ -297,11 +297,13 @@ def main():
             timer.rules[(8, g.num_active[l], g.num_active[l + 1])] = g.num_active[l]   # up / conv-dgrad
         del g
 
+    from mopa_amd.step import DualStream
+    dual = DualStream(dev)  # 3D branch (small latency-bound kernels) on a second HIP stream, overlapping the 2D GEMMs
+
     def half(b, lam_xm, supervised):
         """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
-        geom = Geometry3D(b["locs"], 7, 4096, dev)
-        o3 = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
-        o2 = model2d({"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None})
+        o2, o3 = dual.forward(model2d, model3d, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
+                              {"x": [b["locs"], b["feats"]]})
         l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
         l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
         if supervised:
@@ -311,8 +313,7 @@ def main():
             l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
             l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
-            gv = Geometry3D(b["vgi_locs"], 7, 4096, dev)                      # third 3D pass on the VGI-style batch
-            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]], "geometry_3d": gv})
+            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]]})                # third 3D pass on the VGI-style batch
             l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
         l2.backward()
         l3.backward()
@@ -330,6 +331,8 @@ def main():
             out = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
             loss = seg_ce(out["seg_logit"], b["label"], cw) + seg_ce(out["seg_logit2"], b["label"], cw)
             loss.backward()
+        if joint:
+            dual.join()  # 3D backward done before its gradients are reduced / applied
         for o in opts:
             o.all_reduce()
         for o in opts:

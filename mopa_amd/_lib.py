@@ -125,13 +125,14 @@ def query(name: str, *args) -> int:
 
 
 class _Workspace:
-    """One growing scratch buffer per device; kernels on a stream run in order, so it is shared."""
+    """One growing scratch buffer per (device, stream): kernels on one stream run in order, so they can share it;
+    the 2D and 3D branches may run on different streams and must not."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -1,0 +1,31 @@
+"""Step helpers for the joint 2D+3D iteration (the caller-side loop stays the user's, like the reference's train scripts).
+
+``DualStream`` runs the two networks of one domain concurrently: they are independent until the losses (each
+cross-modal KL detaches the other modality, ``mopa/train/train_xmuda_mopa.py:389-398``), the 3D branch is a chain of
+small latency-bound kernels and the 2D branch of large FMA-bound ones, so a second HIP stream hides most of the 3D time.
+Autograd replays every node on the stream it was recorded on, so the 3D backward overlaps the 2D backward too.
+Results are bit-identical to sequential execution (same kernels, same per-network order; checked in tests).
+"""
+from __future__ import annotations
+
+import torch
+
+
+class DualStream:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+
+    def forward(self, model_2d, model_3d, batch_2d: dict, batch_3d: dict):
+        """-> (preds_2d, preds_3d); both are safe to use on the current stream when this returns."""
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            preds_3d = model_3d(batch_3d)
+        preds_2d = model_2d(batch_2d)
+        main.wait_stream(self.side)
+        return preds_2d, preds_3d
+
+    def join(self):
+        """Call after the backward passes, before reducing / applying the 3D network's gradients."""
+        torch.cuda.current_stream(self.device).wait_stream(self.side)

@@ -127,3 +127,36 @@ def test_joint_training_step_reduces_the_loss_full_size():
     with torch.no_grad():
         e = m2({"img": b["img"][:1], "img_indices": [b["img_indices"][0]]})
     assert e["seg_logit"].shape == (34880, 5) and torch.isfinite(e["seg_logit"]).all()
+
+
+def test_dual_stream_is_bit_identical_to_sequential():
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import seg_ce, xm_kl
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    from mopa_amd.step import DualStream
+    b = synth.make_batch(2, H=64, W=96)
+    lab = b["seg_label"].cuda()
+
+    def run(dual):
+        torch.manual_seed(0)
+        cfg = default_cfg()
+        m2, m3 = build_model_2d(cfg)[0].cuda().train(), build_model_3d(cfg)[0].cuda().train()
+        m2.net_2d.dropout.p = 0.0
+        if dual is None:
+            p2, p3 = m2(b), m3(b)
+        else:
+            p2, p3 = dual.forward(m2, m3, b, b)
+        l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"])
+        l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
+        l2.backward()
+        l3.backward()
+        if dual is not None:
+            dual.join()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for m in (m2, m3) for p in m.parameters()], float(l2), float(l3)
+
+    g_seq, a2, a3 = run(None)
+    g_dual, b2, b3 = run(DualStream("cuda"))
+    assert a2 == b2 and a3 == b3
+    assert all(torch.equal(x, y) for x, y in zip(g_seq, g_dual))
