@@ -40,7 +40,6 @@ __global__ __launch_bounds__(64) void k_spconv_fwd(const int* __restrict__ nbr, 
   constexpr int LD = CP + 4;       // LDS row stride (floats); +4 keeps 16-B alignment, breaks pow2 strides
   constexpr int SUB = TMR / 64;    // 64-row sub-blocks per tile
   __shared__ __attribute__((aligned(16))) float acc[TMR * LD];
-  __shared__ int l_nbr[27 * TMR];
   __shared__ int l_in[TMR];
   __shared__ int l_out[TMR];
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
@@ -48,20 +47,32 @@ __global__ __launch_bounds__(64) void k_spconv_fwd(const int* __restrict__ nbr, 
   const int c0 = blockIdx.y * CP;
   const int cin16 = (cin + 15) >> 4;
 
-  for (int o = 0; o < K; ++o)
-#pragma unroll
-    for (int sb = 0; sb < SUB; ++sb) {
-      const int row = row0 + sb * 64 + lane;
-      l_nbr[o * TMR + sb * 64 + lane] = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
-    }
   for (int i = lane; i < TMR * LD; i += 64) acc[i] = 0.f;
   __syncthreads();
 
+  // rule-table entries of the NEXT offset are fetched while the current offset is processed (the table streams from
+  // HBM exactly once; unconditional clamped loads keep the outstanding-load count path-independent)
+  int nb_next[SUB];
+#pragma unroll
+  for (int sb = 0; sb < SUB; ++sb) {
+    const int row = row0 + sb * 64 + lane;
+    const int v = nbr[row < A_out ? row : A_out - 1];
+    nb_next[sb] = (row < A_out) ? v : -1;
+  }
   for (int o = 0; o < K; ++o) {
+    int nb_cur[SUB];
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      nb_cur[sb] = nb_next[sb];
+      const int row = row0 + sb * 64 + lane;
+      const int on = o + 1 < K ? o + 1 : K - 1;
+      const int v = nbr[(int64_t)on * A_out + (row < A_out ? row : A_out - 1)];
+      nb_next[sb] = (row < A_out) ? v : -1;
+    }
     int n_o = 0;
 #pragma unroll
     for (int sb = 0; sb < SUB; ++sb) {
-      const int nb = l_nbr[o * TMR + sb * 64 + lane];
+      const int nb = nb_cur[sb];
       const unsigned long long bal = __ballot(nb >= 0);
       const int pos = n_o + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
       if (nb >= 0) { l_in[pos] = nb; l_out[pos] = sb * 64 + lane; }
@@ -506,9 +517,12 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad(const int* __restrict__ nbr
 
   const int rbeg = chunk * rows_per_chunk;
   const int rend = min(A_out, rbeg + rows_per_chunk);
+  const int* __restrict__ nrow = nbr + (int64_t)o * A_out;
+  int nb_next = nrow[min(rbeg + lane, A_out - 1)];
   for (int base = rbeg; base < rend; base += 64) {
     const int row = base + lane;
-    const int nb = (row < rend) ? nbr[(int64_t)o * A_out + row] : -1;
+    const int nb = (row < rend) ? nb_next : -1;
+    nb_next = nrow[min(row + 64, A_out - 1)];  // next block's entries in flight during this block's MFMAs
     const unsigned long long bal = __ballot(nb >= 0);
     if (bal == 0) continue;
     const int n = __popcll(bal);
