@@ -372,6 +372,9 @@ def main():
                   "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_fwd (fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
+        if sp and joint:
+            sp["note"] = ("launch times include contention: the 3D branch runs on a second stream concurrently with the 2D "
+                          "branch; `--workload 3d` gives the isolated figure")
         roof = sp
         k2 = timer2d.summary() if joint else None
         traffic = None
