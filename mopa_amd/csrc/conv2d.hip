@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
   }
 }
 
-// Tile choice, from measurements on MI355X at the network's own shapes (scratch/bench_igemm.py, B=8):
+// Tile choice, from measurements on MI355X at the network's own shapes (profiles/bench_igemm.py, B=8):
 //   M >= 200k pixels: 256x64 (8x8 register tile) 68-82 TF/s; with Cout % 128 == 0 and M >= 1M: 128x128 84 TF/s;
 //   M <  200k pixels (layer2-4, decoder stages 3-5): 64x64 (4x4 register tile) fills the 256 CUs -- 50-69 TF/s
 //   where the large tiles reach 34-60 (4,560 pixels x 512 channels is 144 blocks of 256x64 on 256 CUs).
