@@ -31,99 +31,115 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   lane l: r = l&15, q = l>>4.   A[i=r][k] = in[pair r][16*kk + 4*q + s]          (one float4 per kk)
 //                                 B[k][j=r] = W[o][16*kk + 4*q + s][c0 + r*NTW + t]  (NTW contiguous floats)
 //   D tile t: lane holds rows 4*q+j (j<4), i.e. pairs, column c0 + r*NTW + t.
-template <int NTW, int TMR, bool ALIGNED>
+template <int NTW, int NA, bool ALIGNED>
 __global__ __launch_bounds__(64) void k_spconv_fwd(const int* __restrict__ nbr, int K, int A_out,
                                                     const float* __restrict__ in, int ld_in, int cin,
                                                     const float* __restrict__ W, int cout, int w_flip,
                                                     float* __restrict__ out, int ld_out) {
+  constexpr int TMR = 64;
   constexpr int CP = NTW * 16;     // columns of this group
   constexpr int LD = CP + 4;       // LDS row stride (floats); +4 keeps 16-B alignment, breaks pow2 strides
-  constexpr int SUB = TMR / 64;    // 64-row sub-blocks per tile
   __shared__ __attribute__((aligned(16))) float acc[TMR * LD];
-  __shared__ int l_in[TMR];
-  __shared__ int l_out[TMR];
+  __shared__ int l_in[2][TMR];     // compacted rules of the current / next offset (double-buffered)
+  __shared__ int l_out[2][TMR];
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * TMR;
   const int c0 = blockIdx.y * CP;
   const int cin16 = (cin + 15) >> 4;
+  const int row = row0 + lane;
+  const int rowc = row < A_out ? row : A_out - 1;
 
   for (int i = lane; i < TMR * LD; i += 64) acc[i] = 0.f;
-  __syncthreads();
 
-  // rule-table entries of the NEXT offset are fetched while the current offset is processed (the table streams from
-  // HBM exactly once; unconditional clamped loads keep the outstanding-load count path-independent)
-  int nb_next[SUB];
+  // Software pipeline over the filter offsets.  While offset o is multiplied, (1) the rule-table entries of offset
+  // o+2 stream in, (2) offset o+1 is ballot-compacted into the other LDS list, (3) the rows of the next 16-rule group
+  // (of this offset, or the first of offset o+1) are gathered into registers -- so each step of the per-wave chain
+  // costs MFMA + LDS-accumulate time, not an L2/HBM round trip.  All loads are unconditional (clamped + masked).
+  auto gather = [&](int irow, float4* a) {
+    const float* ar = in + (int64_t)(irow < 0 ? 0 : irow) * ld_in;
 #pragma unroll
-  for (int sb = 0; sb < SUB; ++sb) {
-    const int row = row0 + sb * 64 + lane;
-    const int v = nbr[row < A_out ? row : A_out - 1];
-    nb_next[sb] = (row < A_out) ? v : -1;
-  }
+    for (int kk = 0; kk < NA; ++kk) {
+      const int kb = kk * 16 + q * 4;
+      if (ALIGNED) {
+        const float4 v = *reinterpret_cast<const float4*>(ar + (kk < cin16 ? kb : q * 4));
+        const bool ok = irow >= 0 && kk < cin16;
+        a[kk] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      } else {
+        a[kk].x = (irow >= 0 && kb + 0 < cin) ? ar[kb + 0] : 0.f;
+        a[kk].y = (irow >= 0 && kb + 1 < cin) ? ar[kb + 1] : 0.f;
+        a[kk].z = (irow >= 0 && kb + 2 < cin) ? ar[kb + 2] : 0.f;
+        a[kk].w = (irow >= 0 && kb + 3 < cin) ? ar[kb + 3] : 0.f;
+      }
+    }
+  };
+  auto compact = [&](int nb, int buf) -> int {
+    const unsigned long long bal = __ballot(nb >= 0);
+    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+    if (nb >= 0) { l_in[buf][pos] = nb; l_out[buf][pos] = lane; }
+    return __popcll(bal);
+  };
+  auto table = [&](int o) -> int {   // entry of offset o for this lane's row (clamped, masked)
+    const int oc = o < K ? o : K - 1;
+    const int v = nbr[(int64_t)oc * A_out + rowc];
+    return (o < K && row < A_out) ? v : -1;
+  };
+
+  int nb1 = table(1);                       // offset 1 in flight
+  int n_cur = compact(table(0), 0);         // offset 0 compacted
+  __syncthreads();
+  float4 a_c[NA], a_n[NA];
+  gather(n_cur > r ? l_in[0][r] : -1, a_n); // first group of offset 0
   for (int o = 0; o < K; ++o) {
-    int nb_cur[SUB];
-#pragma unroll
-    for (int sb = 0; sb < SUB; ++sb) {
-      nb_cur[sb] = nb_next[sb];
-      const int row = row0 + sb * 64 + lane;
-      const int on = o + 1 < K ? o + 1 : K - 1;
-      const int v = nbr[(int64_t)on * A_out + (row < A_out ? row : A_out - 1)];
-      nb_next[sb] = (row < A_out) ? v : -1;
-    }
-    int n_o = 0;
-#pragma unroll
-    for (int sb = 0; sb < SUB; ++sb) {
-      const int nb = nb_cur[sb];
-      const unsigned long long bal = __ballot(nb >= 0);
-      const int pos = n_o + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (nb >= 0) { l_in[pos] = nb; l_out[pos] = sb * 64 + lane; }
-      n_o += __popcll(bal);
-    }
-    if (n_o == 0) continue;  // wave-uniform
+    const int cur = o & 1;
+    const int nb2 = table(o + 2);
+    const int n_next = compact(nb1, cur ^ 1);   // safe: list cur^1 was last read two offsets ago (barrier below)
+    nb1 = nb2;
     __syncthreads();
     const float* __restrict__ wo = W + (int64_t)(w_flip ? K - 1 - o : o) * cin * cout + c0 + r * NTW;
-    for (int g0 = 0; g0 < n_o; g0 += 16) {
-      const int p = g0 + r;
-      const int irow = (p < n_o) ? l_in[p] : -1;
-      const float* __restrict__ arow = in + (int64_t)(irow < 0 ? 0 : irow) * ld_in;
+    for (int g0 = 0; g0 < n_cur; g0 += 16) {
+#pragma unroll
+      for (int kk = 0; kk < NA; ++kk) a_c[kk] = a_n[kk];
+      // prefetch: next group of this offset, or the first group of the next offset
+      {
+        const int p = g0 + 16 + r;
+        int irow;
+        if (g0 + 16 < n_cur) irow = p < n_cur ? l_in[cur][p] : -1;
+        else irow = r < n_next ? l_in[cur ^ 1][r] : -1;
+        gather(irow, a_n);
+      }
       f32x4 d[NTW];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kk = 0; kk < cin16; ++kk) {
-        const int kb = kk * 16 + q * 4;
-        float a[4];
-        if (ALIGNED) {
-          float4 v = (irow >= 0) ? *reinterpret_cast<const float4*>(arow + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-          a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-        } else {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) a[s] = (irow >= 0 && kb + s < cin) ? arow[kb + s] : 0.f;
-        }
+      for (int kk = 0; kk < NA; ++kk) {
+        if (NA <= 4 || kk < cin16) {
+          const float av[4] = {a_c[kk].x, a_c[kk].y, a_c[kk].z, a_c[kk].w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float b[NTW];
-          const float* __restrict__ wr = wo + (int64_t)(kb + s) * cout;
-          if (ALIGNED) {
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const int k = kk * 16 + q * 4 + s2;
+            float bw[NTW];
+            const float* __restrict__ wr = wo + (int64_t)(ALIGNED ? k : (k < cin ? k : 0)) * cout;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) b[t] = wr[t];
-          } else {
+            for (int t = 0; t < NTW; ++t) bw[t] = (ALIGNED || (k < cin && c0 + r * NTW + t < cout)) ? wr[t] : 0.f;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) b[t] = (kb + s < cin && c0 + r * NTW + t < cout) ? wr[t] : 0.f;
+            for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
           }
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t], d[t], 0, 0, 0);
         }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pr = g0 + q * 4 + j;
-        if (pr < n_o) {
-          float* ap = acc + l_out[pr] * LD + r * NTW;
+        if (pr < n_cur) {
+          float* ap = acc + l_out[cur][pr] * LD + r * NTW;
 #pragma unroll
           for (int t = 0; t < NTW; ++t) ap[t] += d[t][j];
         }
       }
     }
-    __syncthreads();
+    if (n_cur == 0) {  // nothing consumed a_n's slot: (re)issue the first group of the next offset
+      gather(r < n_next ? l_in[cur ^ 1][r] : -1, a_n);
+    }
+    n_cur = n_next;
   }
   __syncthreads();
   // write the tile's column group: each output element exactly once
@@ -159,40 +175,51 @@ static void fwd_plan(int K, int A_out, int cout, int* ntw, int* tmr) {
   *tmr = 64;
 }
 
-template <int NTW, int TMR>
+template <int NTW, int NA>
 static int launch_fwd(const int* nbr, int K, int A_out, const float* in, int ld_in, int cin, const float* W,
-                      int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
+                      int cout, int w_flip, float* out, int ld_out, bool aligned, hipStream_t st) {
   const int NT = (cout + 15) / 16;
-  dim3 grid((A_out + TMR - 1) / TMR, (NT + NTW - 1) / NTW);
-  const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
-                       (((uintptr_t)in | (uintptr_t)out | (uintptr_t)W) % 16 == 0);
+  dim3 grid((A_out + 63) / 64, (NT + NTW - 1) / NTW);
   if (aligned)
-    k_spconv_fwd<NTW, TMR, true><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_fwd<NTW, NA, true><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
   else
-    k_spconv_fwd<NTW, TMR, false><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_fwd<NTW, NA, false><<<grid, 64, 0, st>>>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
+template <int NTW>
+static int dispatch_fwd(const int* nbr, int K, int A_out, const float* in, int ld_in, int cin, const float* W, int cout,
+                        int w_flip, float* out, int ld_out, bool aligned, hipStream_t st) {
+#define FW(C) return launch_fwd<NTW, C>(nbr, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out, aligned, st)
+  switch ((cin + 15) / 16) {
+    case 1: FW(1);
+    case 2: FW(2);
+    case 3: FW(3);
+    case 4: FW(4);
+    default: break;
+  }
+  if (cin <= 128) FW(8);
+  FW(12);
+#undef FW
 }
 
 // out[A_out][cout] (row stride ld_out) = sum_o in[nbr[o][.]] @ W[w_flip ? K-1-o : o]
 MOPA_API int mopa_spconv_fwd(const int32_t* nbr, int32_t K, int32_t num_out, const float* in, int32_t ld_in,
                              int32_t cin, const float* weight, int32_t cout, int32_t w_flip, float* out,
                              int32_t ld_out, void* stream) {
-  if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
+  if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cin > 192 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
+                       (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
   int ntw, tmr;
   fwd_plan(K, num_out, cout, &ntw, &tmr);
-#define GO(N, T) return launch_fwd<N, T>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
-  if (tmr == 128) {
-    if (ntw == 1) GO(1, 128);
-    if (ntw == 2) GO(2, 128);
-  }
+  if (!aligned) ntw = 1;
   switch (ntw) {
-    case 1: GO(1, 64);
-    case 2: GO(2, 64);
-    case 3: GO(3, 64);
-    default: GO(4, 64);
+    case 1: return dispatch_fwd<1>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st);
+    case 2: return dispatch_fwd<2>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st);
+    case 3: return dispatch_fwd<3>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st);
+    default: return dispatch_fwd<4>(nbr, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st);
   }
-#undef GO
 }
 
 // ----------------------------------------------------------------------------------------------
