@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
                                                                 const int* __restrict__ grp_in, const int* __restrict__ grp_out,
                                                                 int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
                                                                 const float* __restrict__ W, int cout, int w_flip,
-                                                                float* __restrict__ out, int ld_out) {
+                                                                float* __restrict__ out, int ld_out, int osplit) {
   constexpr int CP = NTW * 16;
   constexpr int LD = CP + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -301,8 +301,26 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
   float* acc = accs + wv * 64 * LD;
   for (int i = lane; i < 64 * LD; i += 64) acc[i] = 0.f;
 
+  // blockIdx.z owns the filter offsets [o_beg, o_end): short levels have too few tiles to fill the chip, so the 27-step
+  // chain is cut into `osplit` independent pieces that write partial outputs (summed in order by k_sum_partials).
+  const int o_beg = (int)((int64_t)blockIdx.z * K / osplit), o_end = (int)((int64_t)(blockIdx.z + 1) * K / osplit);
+  if (osplit > 1) out += (int64_t)blockIdx.z * A_out * ld_out;
   int g = 0, gend = 0;
-  if (tile < ntiles) { g = grp_start[tile]; gend = grp_start[tile + 1]; }
+  if (tile < ntiles) {
+    const int gb = grp_start[tile], ge = grp_start[tile + 1];
+    g = gb; gend = ge;
+    if (osplit > 1) {  // groups are sorted by offset: first group with o >= o_beg / o >= o_end (ballot scan, <= 2 rounds)
+      int first = ge, last = ge;
+      for (int b0 = gb; b0 < ge; b0 += 64) {
+        const int oo = (b0 + lane < ge) ? grp_o[b0 + lane] : K;
+        const unsigned long long m1 = __ballot(oo >= o_beg), m2 = __ballot(oo >= o_end);
+        if (first == ge && m1) first = b0 + __builtin_ctzll(m1);
+        if (last == ge && m2) last = b0 + __builtin_ctzll(m2);
+      }
+      g = first < last ? first : last;
+      gend = last;
+    }
+  }
   // record pipeline: (offset, input row, output rows) of group g ("c") and g+1 ("n"); g+2 is loaded in the loop
   const int4 none = make_int4(-1, -1, -1, -1);
   int o_c = K, o_n = K, irow_c = -1, irow_n = -1;
@@ -356,13 +374,13 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
       if (e < wel) dst[e] = wreg[i];
     }
   };
-  stage_load(0);
-  stage_write(wbuf);
+  stage_load(o_beg);
+  stage_write(wbuf + (o_beg & 1) * wel);
   __syncthreads();
 
-  for (int o = 0; o < K; ++o) {
+  for (int o = o_beg; o < o_end; ++o) {
     const int cur = o & 1;
-    if (o + 1 < K) stage_load(o + 1);
+    if (o + 1 < o_end) stage_load(o + 1);
     const float* __restrict__ wl = wbuf + cur * wel + r * NTW;
     while (__builtin_amdgcn_readfirstlane(o_c) == o) {  // this wave's groups of offset o (wave-uniform)
       int o_nn = K, irow_nn = -1;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
 #pragma unroll
       for (int kk = 0; kk < NA; ++kk) a_c[kk] = a_n[kk];
     }
-    if (o + 1 < K) stage_write(wbuf + (cur ^ 1) * wel);
+    if (o + 1 < o_end) stage_write(wbuf + (cur ^ 1) * wel);
     __syncthreads();
   }
   if (tile >= ntiles) return;
@@ -419,6 +437,22 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
       const int rr = i / CP, c = i - rr * CP;
       if (row0 + rr < A_out && c0 + c < cout) out[(int64_t)(row0 + rr) * ld_out + c0 + c] = acc[rr * LD + c];
     }
+  }
+}
+
+// out[row][c] = sum_z part[z][row][c] (fixed order: deterministic)
+__global__ void k_sum_partials(const float* __restrict__ part, int nsplit, int A_out, int cout, int ld, float* __restrict__ out,
+                               int ld_out) {
+  const int CQ = cout >> 2;
+  const int64_t total = (int64_t)A_out * CQ;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)z * A_out + row) * ld + cq * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)row * ld_out + cq * 4) = s;
   }
 }
 
@@ -444,24 +478,42 @@ static int blk_plan(int A_out, int cin, int cout) {
   return best;
 }
 
+// Offsets are split over grid.z when the launch would otherwise hold < ~1000 blocks (and a workspace is given).
+static int blk_osplit(int K, int A_out, int cout, int ntw) {
+  const int NT = (cout + 15) / 16;
+  const int64_t blocks = cdiv64(cdiv64(A_out, 64), SPB_WAVES) * ((NT + ntw - 1) / ntw);
+  int64_t s = cdiv64(3072, blocks);
+  if (s > 9) s = 9;
+  const int64_t cap_bytes = (48ll << 20) / ((int64_t)A_out * cout * 4 + 1);  // partial copies stay below ~48 MB
+  if (s > cap_bytes) s = cap_bytes;
+  if (s > K / 2) s = K / 2;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 template <int NTW, int NA>
 static int launch_blk(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
-                      int cin, const float* W, int cout, int w_flip, float* out, int ld_out, bool aligned, hipStream_t st) {
+                      int cin, const float* W, int cout, int w_flip, float* out, int ld_out, bool aligned, float* part,
+                      int osplit, hipStream_t st) {
   const int NT = (cout + 15) / 16;
-  dim3 grid((unsigned)cdiv64(cdiv64(A_out, 64), SPB_WAVES), (NT + NTW - 1) / NTW);
+  dim3 grid((unsigned)cdiv64(cdiv64(A_out, 64), SPB_WAVES), (NT + NTW - 1) / NTW, osplit);
   const size_t lds = blk_lds_bytes(NTW, cin);
+  float* dst = osplit > 1 ? part : out;
+  const int ldd = osplit > 1 ? cout : ld_out;
   if (aligned)
-    k_spconv_blk<NTW, NA, true><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_blk<NTW, NA, true><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, dst, ldd, osplit);
   else
-    k_spconv_blk<NTW, NA, false><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out);
+    k_spconv_blk<NTW, NA, false><<<grid, 64 * SPB_WAVES, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, dst, ldd, osplit);
+  if (osplit > 1)
+    k_sum_partials<<<stream_grid((int64_t)A_out * (cout >> 2), 256), 256, 0, st>>>(part, osplit, A_out, cout, cout, out, ld_out);
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
 template <int NTW>
 static int dispatch_blk_c(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in,
                           int ld_in, int cin, const float* W, int cout, int w_flip, float* out, int ld_out, bool aligned,
-                          hipStream_t st) {
-#define RB(C) return launch_blk<NTW, C>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out, aligned, st)
+                          float* part, int osplit, hipStream_t st) {
+#define RB(C) return launch_blk<NTW, C>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, cout, w_flip, out, ld_out, aligned, part, osplit, st)
   const int c16 = (cin + 15) / 16;
   if (c16 <= 4) {
     switch (c16) {
@@ -477,19 +529,27 @@ static int dispatch_blk_c(const int* gs, const int* go, const int* gi, const int
 #undef RB
 }
 
+MOPA_API size_t mopa_spconv_grouped_workspace_bytes(int32_t K, int32_t num_out, int32_t cout) {
+  return align_up((size_t)9 * num_out * cout * sizeof(float), 256);  // upper bound: 9 partial copies of the output
+}
+
 // Same contract as mopa_spconv_fwd, on the grouped rulebook of the table (mopa_rulebook_groups_{count,fill}).
+// ws (optional, mopa_spconv_grouped_workspace_bytes) lets short levels split the filter offsets over more blocks.
 MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* grp_o, const int32_t* grp_in,
                                      const int32_t* grp_out, int32_t K, int32_t num_out, const float* in, int32_t ld_in,
                                      int32_t cin, const float* weight, int32_t cout, int32_t w_flip, float* out,
-                                     int32_t ld_out, void* stream) {
+                                     int32_t ld_out, void* ws, size_t ws_bytes, void* stream) {
   if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
                        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
   if (cin > 192) return MOPA_ERR_ARG;
   const int ntw = aligned ? blk_plan(num_out, cin, cout) : 1;
-  if (blk_lds_bytes(ntw, cin) > 64 * 1024 || cin > 192) return MOPA_ERR_ARG;
-#define GO(N) return dispatch_blk_c<N>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, st)
+  if (blk_lds_bytes(ntw, cin) > 64 * 1024) return MOPA_ERR_ARG;
+  int osplit = (aligned && ws) ? blk_osplit(K, num_out, cout, ntw) : 1;
+  if (osplit > 1 && ws_bytes < (size_t)osplit * num_out * cout * sizeof(float)) osplit = 1;
+  float* part = (float*)ws;
+#define GO(N) return dispatch_blk_c<N>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, aligned, part, osplit, st)
   switch (ntw) {
     case 1: GO(1);
     case 2: GO(2);

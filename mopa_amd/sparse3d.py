@@ -167,8 +167,9 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
     # the chip (high occupancy hides its per-offset chain); below that the grouped block kernel wins by 2-3x.
     if rb is not None and (A_out + 63) // 64 < 1500:
         gs, go, gi, gout = rb
+        ws = _ws(query("mopa_spconv_grouped_workspace_bytes", K, A_out, out.C), w.device)
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, x.C, ptr(w), out.C,
-             int(w_flip), out.p, out.ld, stream())
+             int(w_flip), out.p, out.ld, ptr(ws), ws.numel(), stream())
     else:
         call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, x.C, ptr(w), out.C, int(w_flip), out.p, out.ld, stream())
 
