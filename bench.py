@@ -408,7 +408,7 @@ def main():
             "roofline_sparse_conv": sp,
         }
         print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s", file=sys.stderr, flush=True)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only
             t_cpu = time.perf_counter()
             line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d) if joint else cpu_baseline_3d(model3d)
             print(f"[bench] cpu baseline took {time.perf_counter() - t_cpu:.1f}s", file=sys.stderr, flush=True)
