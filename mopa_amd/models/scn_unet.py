@@ -32,6 +32,15 @@ class _SparseConvParams(nn.Module):
         # SCN init: normal(0, sqrt(2 / (nIn * filter_volume)))  (Appendix A.4/A.5)
         self.weight = nn.Parameter(torch.randn(K, n_in, n_out) * math.sqrt(2.0 / (n_in * K)))
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # SparseConvNet checkpoints store (filter_volume, nIn, nOut) or, in other releases, (filter_volume, 1, nIn, nOut)
+        # (SURVEY.md A.4/A.7); both map onto this module's (K, Cin, Cout) without touching the values.
+        key = prefix + "weight"
+        w = state_dict.get(key)
+        if w is not None and w.dim() == 4 and w.shape[1] == 1 and tuple(w.shape[0:1] + w.shape[2:]) == tuple(self.weight.shape):
+            state_dict[key] = w.reshape(self.weight.shape)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
 
 class _BNParams(nn.Module):
     def __init__(self, c):

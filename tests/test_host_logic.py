@@ -88,3 +88,16 @@ def test_voxelizer_matches_golden(golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "g4_voxelize.npz")))
     # case 0 of G4 is augment_and_scale_3d without augmentation == synth.voxelize
     assert np.array_equal(synth.voxelize(g["points0"], 20), g["coords0"])
+
+
+def test_scn_checkpoint_weight_layouts_load():
+    """state_dict round trip, and SparseConvNet's 4-D (filter_volume, 1, nIn, nOut) weight layout."""
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    m, _ = build_model_3d(default_cfg())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd4 = {k: (v.unsqueeze(1) if (k.endswith(".weight") and v.dim() == 3) else v) for k, v in sd.items()}
+    m2, _ = build_model_3d(default_cfg())
+    m2.load_state_dict(sd4)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
