@@ -160,3 +160,33 @@ def test_dual_stream_is_bit_identical_to_sequential():
     g_dual, b2, b3 = run(DualStream("cuda"))
     assert a2 == b2 and a3 == b3
     assert all(torch.equal(x, y) for x, y in zip(g_seq, g_dual))
+
+
+def test_single_head_ten_classes_and_empty_image_indices():
+    """DUAL_HEAD False / NUM_CLASSES 10 (a2d2_semantic_kitti configs) and an image without any projected point."""
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    from oracle import net2d, scn3d
+    from oracle.params import det_tensor
+    cfg = default_cfg(num_classes=10, dual_head=False)
+    cfg.MODEL_3D.SCN.num_planes = 3
+    m2, m3 = build_model_2d(cfg)[0], build_model_3d(cfg)[0]
+    for m in (m2, m3):
+        m.load_state_dict({k: det_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    m2, m3 = m2.cuda().eval(), m3.cuda().eval()
+    rng = np.random.Generator(np.random.PCG64(4))
+    img = torch.from_numpy(rng.random((2, 3, 33, 50), dtype=np.float32))
+    idx = [np.stack([rng.integers(0, 33, 150), rng.integers(0, 50, 150)], 1), np.zeros((0, 2), np.int64)]
+    coords = np.concatenate([rng.integers(0, 40, (500, 3)), rng.integers(0, 2, (500, 1))], 1).astype(np.int64)
+    with torch.no_grad():
+        o2 = m2({"img": img, "img_indices": idx})
+        o3 = m3({"x": [torch.from_numpy(coords), torch.ones(500, 1)]})
+    assert set(o2) == {"feats", "seg_logit", "seg_logit_all"} and set(o3) == {"feats", "seg_logit"}
+    assert o2["seg_logit"].shape == (150, 10) and o2["seg_logit_all"].shape == (2, 33, 50, 10) and o3["seg_logit"].shape == (500, 10)
+    P2 = {k: det_tensor(k, v) for k, v in net2d.param_shapes(10, False).items()}
+    r2 = net2d.net2dseg_forward(P2, img, idx, dual_head=False, training=False)
+    P3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
+    r3 = scn3d.net3dseg_forward(P3, scn3d.Geometry(coords, 3), torch.ones(500, 1), dual_head=False, training=False, num_planes=3)
+    for got, ref in ((o2["seg_logit"], r2["seg_logit"]), (o2["seg_logit_all"], r2["seg_logit_all"]), (o3["seg_logit"], r3["seg_logit"])):
+        r = ref.detach().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), r, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(r).max()))
