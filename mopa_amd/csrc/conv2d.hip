@@ -327,7 +327,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__
   }
 }
 
-static int wgrad_ntap(const ConvGeom& g) { return (g.Cin >= 64 && g.TW % 3 == 0) ? 3 : 1; }
+static int wgrad_ntap(const ConvGeom& g) {
+  if (g.Cin >= 64 && g.TW % 3 == 0) return 3;
+  if (g.Cin == 16 && g.TW == 2) return 2;  // stem: both 16-wide taps of a filter row share the dY tile
+  return 1;
+}
 
 static void wgrad_split(const ConvGeom& g, int* nsplit, int* m_per_split) {
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
@@ -370,6 +374,9 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
       dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
       k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     }
+  } else if (wgrad_ntap(g) == 2) {
+    dim3 grid(g.TH * g.TW / 2, g.Cout / 64, ns);
+    k_conv2d_wgrad<16, 2><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
   } else {
     dim3 grid(g.TH * g.TW, g.Cout / 64, ns);
     k_conv2d_wgrad<16, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
