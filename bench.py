@@ -51,24 +51,24 @@ class ConvTimer:
 
     def install(self):
         from mopa_amd import sparse3d
-        inner = sparse3d.spconv_fwd
+        inner = sparse3d.spconv_launch
         timer = self
 
-        def wrapped(nbr, x, w, out, w_flip=False, rb=None):
+        def wrapped(nbr, x, w, out, w_flip, rb, packed):
             if not timer.enabled:
-                return inner(nbr, x, w, out, w_flip, rb)
+                return inner(nbr, x, w, out, w_flip, rb, packed)
             K, A_out = nbr.shape
             R = timer.rules.get((K, A_out, x.rows))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            inner(nbr, x, w, out, w_flip, rb)
+            inner(nbr, x, w, out, w_flip, rb, packed)
             e.record()
             if R is not None:
                 # gather R*Cin*4 + each output row once A*Cout*4 + int32 rule pair R*8 + weights
                 nbytes = R * x.C * 4 + A_out * out.C * 4 + R * 8 + K * x.C * out.C * 4
                 timer.records.append((s, e, nbytes, 2 * R * x.C * out.C))
 
-        sparse3d.spconv_fwd = wrapped
+        sparse3d.spconv_launch = wrapped
 
     def summary(self):
         if not self.records:
@@ -369,7 +369,7 @@ def main():
         sp = None
         if ks:
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_fwd (fwd + bwd-data)",
+                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_pipe / k_spconv_blk / k_spconv_fwd (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
         t3 = os.path.join(ROOT, "profiles", "r1_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d`

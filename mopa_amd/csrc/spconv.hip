@@ -14,6 +14,7 @@
 // Data layout: features row-major [rows][ld] fp32 (ld >= C lets a layer read/write a channel slice of a wider
 // JoinTable buffer); weights [K][Cin][Cout] fp32.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -271,6 +272,50 @@ MOPA_API int mopa_rulebook_groups_fill(const int32_t* nbr, int32_t K, int32_t nu
 }
 
 // ----------------------------------------------------------------------------------------------
+// Weight packing for k_spconv_pipe: wp[o][kc][lane][s2][t] = Wc[o][16*kc + 4*(lane>>4) + s2][(lane&15)*NTW + t] where Wc
+// is the [K][cin_c][cout_c] weight of the convolution to run: w itself, or (transpose) w[o]^T for backward-data.
+__global__ void k_pack_w(const float* __restrict__ w, int K, int cin_w, int cout_w, int transpose, float* __restrict__ wp) {
+  const int cin_c = transpose ? cout_w : cin_w, cout_c = transpose ? cin_w : cout_w;
+  const int ntw = cout_c >> 4;
+  const int64_t n = (int64_t)K * cin_c * cout_c;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rem = i;
+    const int t = (int)(rem % ntw); rem /= ntw;
+    const int s2 = (int)(rem & 3); rem >>= 2;
+    const int lane = (int)(rem & 63); rem >>= 6;
+    const int nkc = cin_c >> 4;
+    const int kc = (int)(rem % nkc);
+    const int o = (int)(rem / nkc);
+    const int k = kc * 16 + (lane >> 4) * 4 + s2, c = (lane & 15) * ntw + t;
+    wp[i] = transpose ? w[((int64_t)o * cin_w + c) * cout_w + k] : w[((int64_t)o * cin_w + k) * cout_w + c];
+  }
+}
+
+// 1 when mopa_spconv_fwd_grouped runs this shape on the pipelined wave kernel, which takes packed weights
+// (w_flip bit 1); cin / cout are those of the convolution to run (swapped for backward-data).
+static int pipe_eligible(int K, int64_t num_out, int cin, int cout) {
+  static const int force_path = getenv("MOPA_SPCONV_PATH") ? atoi(getenv("MOPA_SPCONV_PATH")) : 0;  // tuning only
+  if (cin % 16 || cout % 16 || cout > 64 || cin > 192) return 0;
+  // measured (profiles/bench_spconv.py): 1.2-1.5x over the dense-table kernel on the 27-offset tables of the long levels;
+  // the 8-offset down/up tables (one rule per row and offset) stay on the dense-table kernel.
+  return force_path == 1 || (force_path == 0 && K == 27 && cdiv64(num_out, 64) >= 1500);
+}
+MOPA_API int mopa_spconv_grouped_wants_packed(int32_t K, int32_t num_out, int32_t cin, int32_t cout) {
+  return pipe_eligible(K, num_out, cin, cout);
+}
+
+// wp (K*cin*cout floats) = packed form of w [K][cin][cout] (transpose = 0) or of its per-offset transpose (1).
+MOPA_API int mopa_spconv_pack_weight(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t transpose, float* wp,
+                                     void* stream) {
+  const int cin_c = transpose ? cout : cin, cout_c = transpose ? cin : cout;
+  if (K <= 0 || cin_c <= 0 || cout_c <= 0 || cin_c % 16 || cout_c % 16 || cout_c > 64) return MOPA_ERR_ARG;
+  const int64_t n = (int64_t)K * cin * cout;
+  k_pack_w<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, K, cin, cout, transpose, wp);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Block kernel on the grouped rulebook: 4 waves = 4 consecutive 64-row tiles walk the filter offsets in lockstep;
 // the block stages the column slice W[o][:, c0:c0+16*NTW] of each offset ONCE in LDS (double-buffered, next offset's
 // global loads in flight during the current offset's MFMAs), so the MFMA B operand is a conflict-free ds_read instead
@@ -440,6 +485,158 @@ __global__ __launch_bounds__(64 * SPB_WAVES) void k_spconv_blk(const int* __rest
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Pipelined wave kernel on the grouped rulebook, for the long shallow levels (>= ~1500 tiles, Cout <= 64) where the
+// bytes are.  One wave = one 64-row tile, all output columns (Cout == 16*NTW).  The work is a flat stream of units
+// (group g, 16-channel chunk kc); every unit is 1 row-gather float4 + 4 weight loads per lane, 4*NTW MFMAs and one
+// read-add-write of the 16 result rows into the tile's LDS accumulator.
+//  * The weights come pre-packed (mopa_spconv_pack_weight) so that a unit's 16 x Cout chunk of W[o] is one contiguous
+//    block in which every lane's MFMA B operands are 16*NTW consecutive bytes: 1 + NTW fully coalesced 16-byte loads
+//    per lane and unit (the [K][Cin][Cout] layout needs 4 strided loads; they were 35% of the kernel time).
+//  * D units are kept in flight in a statically named register ring (the loop is unrolled by D, every load is
+//    unconditional and in-bounds), so the compiler's vmcnt counting stays exact and a wave waits for HBM/L2 about once
+//    per D units instead of three times per filter offset.
+//  * Per-wave serial latency is what bounds these levels (rocprofv3 SQ counters in profiles/: issue stalls, not memory
+//    waits), so a unit has ONE exposed LDS round trip: the group metadata of the next unit is already in registers,
+//    and the accumulator rows are read before the unit's MFMAs and written after them.
+//  * Metadata is staged through LDS as ready-made offsets (input row -> float4 offset, output row -> byte offset of
+//    its accumulator row, filter offset -> byte offset of W[o]); padding rules and the ring's look-ahead past the
+//    tile's last group are rewritten to (input row 0 -> accumulator row 64), a sink row that is never written out,
+//    which removes every data-dependent branch and select (ds_add_f32 for the accumulation was 5x slower).
+//  * LDS per wave is sized so that a whole level is resident at once (16 / 12 / 8 waves per CU at 16 / 32 / 48-64
+//    columns): with one equal-length wave per tile a second, partial round would double the kernel time.
+// Summation order: filter offsets ascending, 16-channel chunks ascending, k ascending within a chunk (a chunk's partial
+// product is added to the accumulator row before the next chunk's; k_spconv_fwd / k_spconv_blk add a whole group's
+// product at once, so results agree to rounding, not bit for bit, when Cin > 16).
+template <int N> struct FVec;
+template <> struct FVec<1> { typedef float T; };
+template <> struct FVec<2> { typedef float2 T; };
+template <> struct FVec<3> { struct T { float x, y, z; }; };
+template <> struct FVec<4> { typedef float4 T; };
+
+template <int NTW, int D, int MU>  // MU: groups consumed per metadata chunk
+__global__ __launch_bounds__(64, (NTW == 1 ? 4 : NTW == 2 ? 3 : 2)) void k_spconv_pipe(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+                                                     const int* __restrict__ grp_in, const int* __restrict__ grp_out,
+                                                     int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
+                                                     const float* __restrict__ W, int w_flip,
+                                                     float* __restrict__ out, int ld_out) {
+  constexpr int CP = NTW * 16;  // == Cout
+  constexpr int LD = CP + 4;
+  constexpr int MS = MU + 4;  // groups staged per chunk; the ring's look-ahead (up to 2D-1 units) is clamped to the last one
+  static_assert(65 * LD * 4 < 65536 && MS % 4 == 0, "metadata packing");
+  typedef typename FVec<NTW>::T BT;
+  __shared__ __attribute__((aligned(16))) float acc[65 * LD];  // row 64: sink of padding / look-ahead rules
+  __shared__ __attribute__((aligned(16))) unsigned m_in[MS * 16];         // input row * (ld_in / 4): float4 offset
+  __shared__ __attribute__((aligned(16))) unsigned short m_out[MS * 16];  // accumulator row * LD * 4: byte offset
+  __shared__ unsigned m_w[MS];                                            // byte offset of the group's W[o]
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, ntiles = gridDim.x;
+  const int row0 = tile * 64;
+  const int gb = grp_start[tile], ge = grp_start[tile + 1], G = grp_start[ntiles];
+  const int nkc = cin >> 4;
+  const unsigned ld4 = (unsigned)ld_in >> 2;
+  for (int i = lane; i < 65 * LD; i += 64) acc[i] = 0.f;
+  const unsigned b_lane = (unsigned)(lane * NTW * 16);  // this lane's 4 x NTW floats inside a packed 16 x CP weight chunk
+  const float4* __restrict__ a_lane = reinterpret_cast<const float4*>(in) + q;
+  char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
+
+  float4 A[D];
+  float4 B[D][NTW];  // packed chunk: [s2][t] -> 4 * NTW floats per lane, NTW 16-byte loads
+
+  for (int cb = gb; cb < ge; cb += MU) {
+    // stage the metadata of groups [cb, cb + MS); reads past this tile's groups stay inside the arrays
+    for (int e = lane * 4; e < MS * 16; e += 256) {
+      const int src = min(cb * 16 + e, G * 16 - 4);
+      const int4 vi = *reinterpret_cast<const int4*>(grp_in + src);
+      const int4 vo = *reinterpret_cast<const int4*>(grp_out + src);
+      const bool dead = cb + (e >> 4) >= ge || (e >> 4) >= MU;  // look-ahead groups: loaded, never accumulated
+      uint4 wi;
+      wi.x = (unsigned)max(vi.x, 0) * ld4; wi.y = (unsigned)max(vi.y, 0) * ld4;
+      wi.z = (unsigned)max(vi.z, 0) * ld4; wi.w = (unsigned)max(vi.w, 0) * ld4;
+      const unsigned o0 = (unsigned)((dead || vo.x < 0) ? 64 : vo.x) * (LD * 4), o1 = (unsigned)((dead || vo.y < 0) ? 64 : vo.y) * (LD * 4);
+      const unsigned o2 = (unsigned)((dead || vo.z < 0) ? 64 : vo.z) * (LD * 4), o3 = (unsigned)((dead || vo.w < 0) ? 64 : vo.w) * (LD * 4);
+      *reinterpret_cast<uint4*>(m_in + e) = wi;
+      *reinterpret_cast<uint2*>(m_out + e) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+    }
+    if (lane < MS) {
+      const int o = grp_o[min(cb + lane, G - 1)];
+      m_w[lane] = (unsigned)((w_flip ? K - 1 - o : o) * cin * CP * 4);
+    }
+    __syncthreads();
+    const int ng = min(MU, ge - cb);
+    const int U = ng * nkc;
+
+    int ig = 0, ikc = 0, cg = 0, ckc = 0;
+    unsigned io_n = m_in[r], wo_n = m_w[0];          // metadata of the next unit to issue ...
+    uint2 mo_n = *reinterpret_cast<const uint2*>(m_out + q * 4);  // ... and of the next unit to consume
+#define SPP_ISSUE(S)                                                                                              \
+  {                                                                                                               \
+    const unsigned woff_ = __builtin_amdgcn_readfirstlane(wo_n) + (unsigned)(ikc * 16 * CP * 4);                  \
+    const char* wp_ = reinterpret_cast<const char*>(W) + woff_;                                                   \
+    A[S] = a_lane[(uint64_t)io_n + (unsigned)(ikc * 4)];                                                          \
+    _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                            \
+      B[S][v_] = *reinterpret_cast<const float4*>(wp_ + b_lane + v_ * 16);                                        \
+    if (++ikc == nkc) { ikc = 0; ig = min(ig + 1, MS - 1); }                                                      \
+    io_n = m_in[ig * 16 + r];                                                                                     \
+    wo_n = m_w[ig];                                                                                               \
+  }
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      SPP_ISSUE(s);
+      __builtin_amdgcn_sched_barrier(0);  // keep the ring in issue order: the loop's counted vmcnt relies on it
+    }
+    // U is rounded up to whole rings: the extra units are look-ahead groups (sink row)
+    for (int u = 0; u < U; u += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const unsigned ol[4] = {mo_n.x & 0xffffu, mo_n.x >> 16, mo_n.y & 0xffffu, mo_n.y >> 16};
+        BT v[4];  // the 4 rows of a lane are distinct output rows (or the sink): read all, then write all
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const BT*>(acc_lane + ol[j]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the 4 accumulator reads in flight under the MFMAs
+        f32x4 d[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+          const float av[4] = {A[s].x, A[s].y, A[s].z, A[s].w};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const float* bw = reinterpret_cast<const float*>(&B[s][0]) + s2 * NTW;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
+          }
+        }
+        if (++ckc == nkc) { ckc = 0; ++cg; }
+        mo_n = *reinterpret_cast<const uint2*>(m_out + cg * 16 + q * 4);
+        SPP_ISSUE(s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float* vf = reinterpret_cast<float*>(&v[j]);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) vf[t] += d[t][j];
+          *reinterpret_cast<BT*>(acc_lane + ol[j]) = v[j];
+        }
+      }
+    }
+#undef SPP_ISSUE
+    __syncthreads();
+  }
+  constexpr int V = CP / 4;
+  for (int i = lane; i < 64 * V; i += 64) {
+    const int rr = i / V, c4 = i - rr * V;
+    if (row0 + rr < A_out)
+      *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + c4 * 4) =
+          *reinterpret_cast<const float4*>(acc + rr * LD + c4 * 4);
+  }
+}
+
+template <int NTW, int D, int MU>
+static int launch_pipe(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
+                       int cin, const float* W, int w_flip, float* out, int ld_out, hipStream_t st) {
+  k_spconv_pipe<NTW, D, MU><<<(unsigned)cdiv64(A_out, 64), 64, 0, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, W, w_flip, out, ld_out);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
 // out[row][c] = sum_z part[z][row][c] (fixed order: deterministic)
 __global__ void k_sum_partials(const float* __restrict__ part, int nsplit, int A_out, int cout, int ld, float* __restrict__ out,
                                int ld_out) {
@@ -544,6 +741,21 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
   const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
                        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
   if (cin > 192) return MOPA_ERR_ARG;
+  // long levels: one pipelined wave per tile (k_spconv_pipe, packed weights); short levels: 4-wave blocks with
+  // LDS-staged weights.  w_flip bit 0 = mirrored filter offsets, bit 1 = weight is packed (mopa_spconv_pack_weight).
+  const int packed = (w_flip >> 1) & 1;
+  w_flip &= 1;
+  if (packed) {
+    if (!aligned || !pipe_eligible(K, num_out, cin, cout)) return MOPA_ERR_ARG;
+#define PP(N, DD, MU) return launch_pipe<N, DD, MU>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, w_flip, out, ld_out, st)
+    switch (cout / 16) {
+      case 1: PP(1, 6, 40);   // LDS 9.6 KB -> 16 waves / CU
+      case 2: PP(2, 6, 32);   // 13.0 KB -> 12
+      case 3: PP(3, 6, 40);   // 17.9 KB ->  8
+      default: PP(4, 4, 28);  // 20.9 KB ->  7
+    }
+#undef PP
+  }
   const int ntw = aligned ? blk_plan(num_out, cin, cout) : 1;
   if (blk_lds_bytes(ntw, cin) > 64 * 1024) return MOPA_ERR_ARG;
   int osplit = (aligned && ws) ? blk_osplit(K, num_out, cout, ntw) : 1;

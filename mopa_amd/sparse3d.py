@@ -158,20 +158,41 @@ def new_view(rows, C, device, ld=None):
     return View(torch.empty(rows, ld or C, dtype=torch.float32, device=device), 0, C)
 
 
-def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False, rb=None):
-    """out = sum_o x[nbr[o]] @ w[o].  `rb` = the table's grouped rulebook (Geometry3D.rulebook(nbr)) selects the
-    prefetching kernel; without it the kernel compacts the dense table on the fly."""
+def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False, rb=None,
+               w_transposed: bool = False):
+    """out = sum_o x[nbr[o]] @ Wc[o] with Wc = w ([K][Cin][Cout]) or, for backward-data (`w_transposed`), the
+    per-offset transpose of the layer weight w ([K][Cout][Cin]).  `rb` = the table's grouped rulebook
+    (Geometry3D.rulebook(nbr)) selects the prefetching kernels; without it the kernel compacts the dense table on the
+    fly.  The weight is re-laid out per call as the chosen kernel wants it (packed / transposed): one tiny kernel."""
     K, A_out = nbr.shape
-    assert out.rows == A_out and w.shape == (K, x.C, out.C), (nbr.shape, x.C, out.C, w.shape)
-    # measured on MI355X (profiles/r1_*): with >= 1500 64-row tiles one wave per tile on the dense table already fills
-    # the chip (high occupancy hides its per-offset chain); below that the grouped block kernel wins by 2-3x.
-    if rb is not None and (A_out + 63) // 64 < 1500:
+    cin, cout = x.C, out.C
+    assert out.rows == A_out and w.shape == ((K, cout, cin) if w_transposed else (K, cin, cout)), (nbr.shape, cin, cout, w.shape)
+    packed = rb is not None and bool(query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout))
+    if packed:
+        wk = torch.empty(K * cin * cout, dtype=w.dtype, device=w.device)
+        call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], int(w_transposed), ptr(wk), stream())
+    else:
+        wk = spconv_transpose_weight(w) if w_transposed else w
+    spconv_launch(nbr, x, wk, out, w_flip, rb, packed)
+
+
+def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_flip: bool, rb, packed: bool):
+    """The convolution launch itself, on a weight already laid out for the kernel that runs (bench.py times this)."""
+    K, A_out = nbr.shape
+    cin, cout = x.C, out.C
+    # measured on MI355X (profiles/r1_*): long levels run one pipelined wave per tile on packed weights; short ones the
+    # 4-wave block kernel with LDS-staged weights (2-3x faster than the dense-table wave kernel there).
+    if packed:
         gs, go, gi, gout = rb
-        ws = _ws(query("mopa_spconv_grouped_workspace_bytes", K, A_out, out.C), w.device)
-        call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, x.C, ptr(w), out.C,
+        call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
+             int(w_flip) | 2, out.p, out.ld, 0, 0, stream())
+    elif rb is not None and (A_out + 63) // 64 < 1500:
+        gs, go, gi, gout = rb
+        ws = _ws(query("mopa_spconv_grouped_workspace_bytes", K, A_out, cout), wk.device)
+        call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
              int(w_flip), out.p, out.ld, ptr(ws), ws.numel(), stream())
     else:
-        call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, x.C, ptr(w), out.C, int(w_flip), out.p, out.ld, stream())
+        call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, cin, ptr(wk), cout, int(w_flip), out.p, out.ld, stream())
 
 
 def spconv_transpose_weight(w: torch.Tensor) -> torch.Tensor:
@@ -360,16 +381,15 @@ class SCNNetFunction(torch.autograd.Function):
                 spconv_bwd_weight(table, x, dout, gbuf(name + ".weight"))
                 if name == spec.prefix + "1" and not ctx.feats_needs_grad:
                     continue
-                wt = spconv_transpose_weight(w)
                 dx = new_view(x.rows, x.C, dev)
                 if ckind[0] == "subm":      # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
-                    spconv_fwd(table, dout, wt, dx, w_flip=True, rb=geom.rulebook(table))
+                    spconv_fwd(table, dout, w, dx, w_flip=True, rb=geom.rulebook(table), w_transposed=True)
                 elif ckind[0] == "down":    # rules reversed = the up table of the same level
                     rt = geom.up[ckind[1]]
-                    spconv_fwd(rt, dout, wt, dx, rb=geom.rulebook(rt))
+                    spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
                 else:                        # deconv: reversed rules = the children table
                     rt = geom.ch[ckind[1]]
-                    spconv_fwd(rt, dout, wt, dx, rb=geom.rulebook(rt))
+                    spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
                 gmap[key(x)] = dx
             elif kind == "join":
                 # dec-block BN produced d(join) for all 2P columns; expose its halves under the keys of the

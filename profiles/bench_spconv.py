@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-level timing of the sparse-conv forward kernels at the bench geometry (8 synthetic nuScenes-shape scans).
+
+For every UNet level and the layer shapes the network uses there (C->C, 2C->C, and the K=8 down/up convs) this runs
+the dense-table wave kernel (mopa_spconv_fwd) and the grouped-rulebook entry point (mopa_spconv_fwd_grouped: the
+pipelined wave kernel on long levels, the 4-wave block kernel on short ones), checks that both give the same bits,
+and prints us per launch plus algorithmic GB/s (in + out rows once, dense rule table once).
+
+Usage: python profiles/bench_spconv.py [levels=7] [reps=20]     (MOPA_SPCONV_PATH=1|2 forces pipe|block kernel)
+"""
+import sys
+import torch
+
+sys.path.insert(0, ".")
+from mopa_amd import sparse3d as s3, synth  # noqa: E402
+from mopa_amd._lib import call, ptr, stream  # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    b = synth.make_batch(8, H=16, W=16)
+    g = s3.Geometry3D(b["x"][0], L, 4096, "cuda")
+    torch.manual_seed(0)
+    m = 16
+    print(f"{'level':>5} {'table':>6} {'rows':>8} {'rules':>9} {'cin':>4} {'cout':>4} {'wave us':>9} {'grouped us':>10} "
+          f"{'alg GB/s':>9} {'TF/s':>6} same")
+    for l in range(L):
+        C = m * (l + 1)
+        cases = [("subm", g.nbr27[l], C, C), ("subm", g.nbr27[l], 2 * C, C)]
+        if l + 1 < L:
+            cases.append(("down", g.ch[l], C, C + m))      # Convolution k2s2: out rows = level l+1
+            cases.append(("up", g.up[l], C + m, C))        # Deconvolution k2s2: out rows = level l
+        for name, tab, cin, cout in cases:
+            K, Ao = tab.shape
+            Ain = int(tab.max().item()) + 1
+            rules = int((tab >= 0).sum().item())
+            x = torch.randn(Ain, cin, device="cuda")
+            w = torch.randn(K, cin, cout, device="cuda") * 0.1
+            o1, o2 = s3.new_view(Ao, cout, "cuda"), s3.new_view(Ao, cout, "cuda")
+            xv = s3.View(x)
+            rb = g.rulebook(tab)
+            gs, go, gi, gout = rb
+            ws = torch.empty(max(1, s3.query("mopa_spconv_grouped_workspace_bytes", K, Ao, cout)), dtype=torch.uint8, device="cuda")
+
+            def wave():
+                call("mopa_spconv_fwd", ptr(tab), K, Ao, xv.p, xv.ld, cin, ptr(w), cout, 0, o1.p, o1.ld, stream())
+
+            packed = s3.query("mopa_spconv_grouped_wants_packed", K, Ao, cin, cout)
+            wp = torch.empty_like(w)
+            if packed:
+                call("mopa_spconv_pack_weight", ptr(w), K, cin, cout, 0, ptr(wp), stream())
+
+            def grouped():
+                call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin,
+                     ptr(wp if packed else w), cout, 2 if packed else 0, o2.p, o2.ld, ptr(ws), ws.numel(), stream())
+
+            tw, tg = timed(wave, reps), timed(grouped, reps)
+            same = torch.equal(o1.t, o2.t)
+            err = float((o1.t - o2.t).abs().max())
+            alg = (Ain * cin + Ao * cout + K * Ao) * 4
+            print(f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {alg / tg / 1e3:>9.0f} "
+                  f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,13 @@ def test_spconv_fwd_wgrad_dgrad_vs_oracle(cin, cout):
             s3.spconv_fwd(flip_for_dgrad, gv, wt, dx, rb=g.rulebook(flip_for_dgrad))
         sx = max(1.0, float(xr.grad.abs().max()))
         np.testing.assert_allclose(dx.dense().cpu().numpy(), xr.grad.float().numpy(), rtol=1e-4, atol=2e-5 * sx)
+        # same through the layer-weight form (the op transposes / packs as its kernel needs)
+        dx2 = s3.new_view(A_in, cin, dev)
+        if table_name == "subm":
+            s3.spconv_fwd(tab_g, gv, w.to(dev), dx2, w_flip=True, rb=g.rulebook(tab_g), w_transposed=True)
+        else:
+            s3.spconv_fwd(flip_for_dgrad, gv, w.to(dev), dx2, rb=g.rulebook(flip_for_dgrad), w_transposed=True)
+        assert torch.equal(dx2.t, dx.t)
 
 
 @pytest.mark.parametrize("C,rows", [(16, 5000), (48, 777), (192, 300), (32, 1)])
