@@ -859,6 +859,127 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad(const int* __restrict__ nbr
     }
 }
 
+// Pipelined form of the same computation for 16-aligned channel counts.  The wave alternates two phases:
+//   1. scan: batches of 8 x 64 entries of its offset's table row (all loads in flight at once), ballot-compacted into an
+//      LDS list of (input row, output row) element offsets until the list holds ~1000 rules or the chunk ends;
+//   2. multiply: a flat stream of k-steps (4 rules each) over the list with D k-steps of row loads in flight in a
+//      statically named register ring (unconditional, in-bounds loads; rules past the end are masked on the A operand),
+// so the wave waits for memory about once per D k-steps instead of once per k-step.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int N> struct UVec;
+template <> struct UVec<1> { typedef float T; };
+template <> struct UVec<2> { typedef f2u T; };
+template <> struct UVec<3> { typedef f3u T; };
+template <> struct UVec<4> { typedef f4u T; };
+#define WG2_CAP 1024
+#define WG2_TB 8
+template <int MU, int NT, int D>
+__global__ __launch_bounds__(64) void k_spconv_wgrad2(const int* __restrict__ nbr, int A_out, int rows_per_chunk,
+                                                       const float* __restrict__ in, int ld_in, int cin,
+                                                       const float* __restrict__ dout, int ld_do, int cout,
+                                                       float* __restrict__ slabs, int K) {
+  constexpr int NT0 = NT > 4 ? 4 : NT, NT1 = NT > 4 ? NT - 4 : 1;
+  __shared__ unsigned l_in[WG2_CAP + 64];   // element offset of the rule's input row (row * ld_in)
+  __shared__ unsigned l_out[WG2_CAP + 64];  // element offset of its output-gradient row
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int o = blockIdx.x, chunk = blockIdx.y, mb = blockIdx.z;
+  f32x4 acc[MU][NT];
+#pragma unroll
+  for (int u = 0; u < MU; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(A_out, rbeg + rows_per_chunk);
+  const int* __restrict__ nrow = nbr + (int64_t)o * A_out;
+  const float* __restrict__ a_lane = in + mb * 16 * MU + r * MU;
+  const float* __restrict__ b_lane = dout + r * NT;
+
+  typename UVec<MU>::T A[D];
+  typename UVec<NT0>::T B0[D];
+  typename UVec<NT1>::T B1[D];
+
+  int row = rbeg;
+  while (row < rend) {
+    // ---- phase 1: compact rules into the list
+    int n = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // phase-2 reads of the previous list are done
+    while (row < rend && n <= WG2_CAP - 64 * WG2_TB) {
+      int nb[WG2_TB];
+#pragma unroll
+      for (int i = 0; i < WG2_TB; ++i) nb[i] = nrow[min(row + 64 * i + lane, A_out - 1)];
+#pragma unroll
+      for (int i = 0; i < WG2_TB; ++i) {
+        const int rr = row + 64 * i + lane;
+        const bool ok = rr < rend && nb[i] >= 0;
+        const unsigned long long bal = __ballot(ok);
+        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+        if (ok) { l_in[pos] = (unsigned)nb[i] * (unsigned)ld_in; l_out[pos] = (unsigned)rr * (unsigned)ld_do; }
+        n += __popcll(bal);
+      }
+      row += 64 * WG2_TB;
+    }
+    l_in[n + lane] = 0u;   // padding read by the last k-step and by the ring's look-ahead: row 0, masked below
+    l_out[n + lane] = 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS writes are ordered before its later reads
+    const int U = (n + 3) >> 2;
+    const int plast = n + 63;
+
+    // ---- phase 2: ring over the k-steps
+    int ip = q;  // list position of this lane's rule in the next k-step to issue
+    unsigned ai = l_in[ip], bi = l_out[ip];
+#define WG2_ISSUE(S)                                                                     \
+  {                                                                                      \
+    A[S] = *reinterpret_cast<const typename UVec<MU>::T*>(a_lane + ai);                  \
+    B0[S] = *reinterpret_cast<const typename UVec<NT0>::T*>(b_lane + bi);                \
+    if (NT > 4) B1[S] = *reinterpret_cast<const typename UVec<NT1>::T*>(b_lane + bi + 4); \
+    ip = min(ip + 4, plast);                                                             \
+    ai = l_in[ip];                                                                       \
+    bi = l_out[ip];                                                                      \
+  }
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      WG2_ISSUE(s);
+      __builtin_amdgcn_sched_barrier(0);  // keep the ring in issue order: the loop's counted vmcnt relies on it
+    }
+    int cp = q;
+    for (int u = 0; u < U; u += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const bool ok = cp < n;
+        cp += 4;
+        float a[MU], b[NT];
+        {
+          const float* af = reinterpret_cast<const float*>(&A[s]);
+          const float* b0 = reinterpret_cast<const float*>(&B0[s]);
+          const float* b1 = reinterpret_cast<const float*>(&B1[s]);
+#pragma unroll
+          for (int m = 0; m < MU; ++m) a[m] = ok ? af[m] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b[t] = t < 4 ? b0[t < 4 ? t : 0] : b1[t >= 4 ? t - 4 : 0];
+        }
+#pragma unroll
+        for (int m = 0; m < MU; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
+        WG2_ISSUE(s);
+      }
+    }
+#undef WG2_ISSUE
+  }
+  float* __restrict__ sl = slabs + ((int64_t)chunk * K + o) * cin * cout;
+  const int cbase = mb * 16 * MU;
+#pragma unroll
+  for (int u = 0; u < MU; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = cbase + (4 * q + j) * MU + u;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sl[(int64_t)ci * cout + r * NT + t] = acc[u][t][j];
+    }
+}
+
 // dw[i] (+)= sum_c slabs[c][i].  16 chunk-lanes per element sum strided chunks, then a fixed-order LDS reduction:
 // deterministic, and short even with ~1000 chunks.
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int nchunks, int64_t n, float* __restrict__ dw,
@@ -909,7 +1030,17 @@ MOPA_API size_t mopa_spconv_wgrad_workspace_bytes(int32_t K, int32_t num_out, in
 
 template <int MU>
 static int launch_wgrad(int nt, dim3 grid, hipStream_t st, const int* nbr, int A_out, int rpc, const float* in,
-                        int ld_in, int cin, const float* dout, int ld_do, int cout, float* slabs, int K) {
+                        int ld_in, int cin, const float* dout, int ld_do, int cout, float* slabs, int K, bool aligned) {
+  constexpr int DD = MU <= 2 ? 8 : 6;
+  if (aligned) {
+    switch (nt) {
+#define CASE(N) case N: k_spconv_wgrad2<MU, N, (MU + N <= 6 ? 8 : DD)><<<grid, 64, 0, st>>>(nbr, A_out, rpc, in, ld_in, cin, dout, ld_do, cout, slabs, K); break
+      CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7);
+#undef CASE
+      default: return MOPA_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+  }
   switch (nt) {
 #define CASE(N) case N: k_spconv_wgrad<MU, N><<<grid, 64, 0, st>>>(nbr, A_out, rpc, in, ld_in, cin, dout, ld_do, cout, slabs, K); break
     CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7);
@@ -931,12 +1062,15 @@ MOPA_API int mopa_spconv_bwd_weight(const int32_t* nbr, int32_t K, int32_t num_o
   dim3 grid(K, nc, mb);
   float* slabs = (float*)ws;
   const int nt = (cout + 15) / 16;
+  // pipelined kernel: whole 16-channel tiles, 32-bit element offsets (row * ld < 2^32) and 4-byte aligned rows
+  const bool aligned = cin % 16 == 0 && cout % 16 == 0 && (int64_t)num_out * ld_dout < (1ll << 32) &&
+                       (int64_t)num_out * 8 * ld_in < (1ll << 32) && (((uintptr_t)in | (uintptr_t)dout) & 3) == 0;
   int rc;
   switch (mu) {
-    case 1: rc = launch_wgrad<1>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K); break;
-    case 2: rc = launch_wgrad<2>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K); break;
-    case 3: rc = launch_wgrad<3>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K); break;
-    default: rc = launch_wgrad<4>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K); break;
+    case 1: rc = launch_wgrad<1>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K, aligned); break;
+    case 2: rc = launch_wgrad<2>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K, aligned); break;
+    case 3: rc = launch_wgrad<3>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K, aligned); break;
+    default: rc = launch_wgrad<4>(nt, grid, st, nbr, num_out, rpc, in, ld_in, cin, dout, ld_dout, cout, slabs, K, aligned); break;
   }
   if (rc) return rc;
   const int64_t n = (int64_t)K * cin * cout;
