@@ -39,7 +39,7 @@ SIGNATURES = {
     "mopa_spconv_fwd_grouped": ("i", "ppppiipiipiipipzp"),
     "mopa_spconv_transpose_weight": ("i", "piiipp"),
     "mopa_spconv_grouped_wants_packed": ("i", "iiii"),
-    "mopa_spconv_pack_weight": ("i", "piiiipp"),
+    "mopa_spconv_pack_weight": ("i", "piiiiipp"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
     # ---- row ops (rows.hip)

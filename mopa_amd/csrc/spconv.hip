@@ -272,45 +272,70 @@ MOPA_API int mopa_rulebook_groups_fill(const int32_t* nbr, int32_t K, int32_t nu
 }
 
 // ----------------------------------------------------------------------------------------------
-// Weight packing for k_spconv_pipe: wp[o][kc][lane][s2][t] = Wc[o][16*kc + 4*(lane>>4) + s2][(lane&15)*NTW + t] where Wc
+// Weight packing for the pipelined kernels, in column groups of NTW 16-column tiles:
+//   wp[cg][o][kc][lane][s2][t] = Wc[o][16*kc + 4*(lane>>4) + s2][cg*16*NTW + (lane&15)*NTW + t]  where Wc
 // is the [K][cin_c][cout_c] weight of the convolution to run: w itself, or (transpose) w[o]^T for backward-data.
-__global__ void k_pack_w(const float* __restrict__ w, int K, int cin_w, int cout_w, int transpose, float* __restrict__ wp) {
+__global__ void k_pack_w(const float* __restrict__ w, int K, int cin_w, int cout_w, int transpose, int ntw, float* __restrict__ wp) {
   const int cin_c = transpose ? cout_w : cin_w, cout_c = transpose ? cin_w : cout_w;
-  const int ntw = cout_c >> 4;
-  const int64_t n = (int64_t)K * cin_c * cout_c;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t rem = i;
-    const int t = (int)(rem % ntw); rem /= ntw;
-    const int s2 = (int)(rem & 3); rem >>= 2;
-    const int lane = (int)(rem & 63); rem >>= 6;
-    const int nkc = cin_c >> 4;
-    const int kc = (int)(rem % nkc);
-    const int o = (int)(rem / nkc);
-    const int k = kc * 16 + (lane >> 4) * 4 + s2, c = (lane & 15) * ntw + t;
+  const int nkc = cin_c >> 4, cp = ntw * 16;
+  const int n = K * cin_c * cout_c;   // < 2^31
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int rem = i;
+    const int t = rem % ntw; rem /= ntw;
+    const int s2 = rem & 3; rem >>= 2;
+    const int lane = rem & 63; rem >>= 6;
+    const int kc = rem % nkc; rem /= nkc;
+    const int o = rem % K;
+    const int cg = rem / K;
+    const int k = kc * 16 + (lane >> 4) * 4 + s2, c = cg * cp + (lane & 15) * ntw + t;
     wp[i] = transpose ? w[((int64_t)o * cin_w + c) * cout_w + k] : w[((int64_t)o * cin_w + k) * cout_w + c];
   }
 }
 
-// 1 when mopa_spconv_fwd_grouped runs this shape on the pipelined wave kernel, which takes packed weights
-// (w_flip bit 1); cin / cout are those of the convolution to run (swapped for backward-data).
-static int pipe_eligible(int K, int64_t num_out, int cin, int cout) {
+// Which kernel mopa_spconv_fwd_grouped runs for a shape (cin / cout are those of the convolution to run, i.e. swapped
+// for backward-data) and the column-group width NTW its packed weights need (w_flip bit 1).  0 = unpacked weights.
+enum { SP_BLK = 0, SP_PIPE = 1, SP_T4 = 2 };
+static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
   static const int force_path = getenv("MOPA_SPCONV_PATH") ? atoi(getenv("MOPA_SPCONV_PATH")) : 0;  // tuning only
-  if (cin % 16 || cout % 16 || cout > 64 || cin > 192) return 0;
-  // measured (profiles/bench_spconv.py): 1.2-1.5x over the dense-table kernel on the 27-offset tables of the long levels;
-  // the 8-offset down/up tables (one rule per row and offset) stay on the dense-table kernel.
-  return force_path == 1 || (force_path == 0 && K == 27 && cdiv64(num_out, 64) >= 1500);
+  *ntw = 0;
+  if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || K != 27 || force_path == 2) return SP_BLK;
+  const int64_t tiles = cdiv64(num_out, 64);
+  const int nt = cout / 16;
+  if (force_path == 1) {
+    if (cout > 64) return SP_BLK;
+    *ntw = nt;
+    return SP_PIPE;
+  }
+  // measured (profiles/bench_spconv.py, us per launch, dense-table / block / pipe / t4):  L0 16->16 46/47/30/45,
+  // L1 32->32 80/100/75/66, L2 96->48 216/240/168/117, L3 64->64 93/110/108/64, L3 128->64 229/199/207/116,
+  // L4 160->80 632/169/-/122, L5 96->96 115/52/-/37.
+  if (force_path == 0 && cout == 16 && tiles >= 1500) {  // 16-channel units are too thin to split four ways
+    *ntw = 1;
+    return SP_PIPE;
+  }
+  // 4 waves per (tile, column group): column groups of 2 tiles when they divide Cout, else 3, else 1
+  const int w = nt % 2 == 0 ? 2 : nt % 3 == 0 ? 3 : 1;
+  if (force_path == 4 || tiles * (nt / w) >= 256) {
+    *ntw = w;
+    return SP_T4;
+  }
+  return SP_BLK;
 }
 MOPA_API int mopa_spconv_grouped_wants_packed(int32_t K, int32_t num_out, int32_t cin, int32_t cout) {
-  return pipe_eligible(K, num_out, cin, cout);
+  int ntw;
+  packed_plan(K, num_out, cin, cout, &ntw);
+  return ntw;
 }
 
-// wp (K*cin*cout floats) = packed form of w [K][cin][cout] (transpose = 0) or of its per-offset transpose (1).
-MOPA_API int mopa_spconv_pack_weight(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t transpose, float* wp,
-                                     void* stream) {
+// wp (K*cin*cout floats) = packed form, for column groups of `ntw` 16-column tiles (mopa_spconv_grouped_wants_packed),
+// of w [K][cin][cout] (transpose = 0) or of its per-offset transpose (1).
+MOPA_API int mopa_spconv_pack_weight(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t transpose, int32_t ntw,
+                                     float* wp, void* stream) {
   const int cin_c = transpose ? cout : cin, cout_c = transpose ? cin : cout;
-  if (K <= 0 || cin_c <= 0 || cout_c <= 0 || cin_c % 16 || cout_c % 16 || cout_c > 64) return MOPA_ERR_ARG;
+  if (K <= 0 || cin_c <= 0 || cout_c <= 0 || cin_c % 16 || cout_c % 16 || ntw < 1 || ntw > 4 || (cout_c / 16) % ntw) return MOPA_ERR_ARG;
   const int64_t n = (int64_t)K * cin * cout;
-  k_pack_w<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, K, cin, cout, transpose, wp);
+  if (n >= (1ll << 31)) return MOPA_ERR_ARG;
+  k_pack_w<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, K, cin, cout, transpose, ntw, wp);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -637,6 +662,177 @@ static int launch_pipe(const int* gs, const int* go, const int* gi, const int* g
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Four waves per (64-row tile, column group of 16*NTW columns): the same pipelined unit stream as k_spconv_pipe, cut
+// four ways.  What the measurements of k_spconv_pipe said (profiles/bench_spconv.py and DESIGN.md section 3): a wave
+// issues in order, so a tile's ~30-65 groups are one serial chain of ~700 cycles per unit no matter how deep the load
+// ring is; the heaviest tile (2x the mean) sets the kernel's duration once every tile is resident; and thin units
+// (one 16-channel chunk) are dominated by their fixed per-unit work.  Hence:
+//   * wave w of the block takes groups w, w+4, ... of the tile, with a private LDS accumulator; the four accumulators
+//     are summed in wave order at the end (deterministic) -- chains are 4x shorter and a level is thousands of blocks
+//     over several rounds, so the hardware dispatcher balances heavy and light tiles;
+//   * a unit is a group times NKU 16-channel chunks (the whole Cin where registers allow): one metadata lookup, one
+//     accumulator read-add-write and 4*NKU*NTW MFMAs per unit;
+//   * wide outputs are cut into column groups (grid.y) so four accumulators fit 2-4 blocks per CU.
+// The block stages the tile's metadata once (shared); everything else is as in k_spconv_pipe.
+#define T4_MU 72  // groups staged per chunk (a tile rarely has more)
+template <int NTW, int NKU, int D, bool PART>
+__global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+                                                    const int* __restrict__ grp_in, const int* __restrict__ grp_out,
+                                                    int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
+                                                    const float* __restrict__ Wp, int w_flip,
+                                                    float* __restrict__ out, int ld_out) {
+  constexpr int CP = NTW * 16;
+  constexpr int LD = CP + 4;
+  constexpr int MS = T4_MU + 4;       // + one dead group per wave for the ring's look-ahead
+  constexpr int ACCB = 65 * LD * 4;   // bytes of one accumulator (row 64 = sink)
+  static_assert(ACCB < 65536 && ACCB % 16 == 0, "metadata packing");
+  typedef typename FVec<NTW>::T BT;
+  extern __shared__ float4 smem4[];
+  char* smem = reinterpret_cast<char*>(smem4);
+  unsigned* m_in = reinterpret_cast<unsigned*>(smem + 4 * ACCB);                          // [MS][16] input row * (ld_in/4)
+  unsigned short* m_out = reinterpret_cast<unsigned short*>(smem + 4 * ACCB + MS * 64);   // [MS][16] accumulator row byte offset
+  unsigned* m_w = reinterpret_cast<unsigned*>(smem + 4 * ACCB + MS * 96);                 // [MS] byte offset of the group's W[o]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, ntiles = gridDim.x, cg = blockIdx.y;
+  const int row0 = tile * 64;
+  const int gb = grp_start[tile], ge = grp_start[tile + 1], G = grp_start[ntiles];
+  const int nkc = cin >> 4;
+  const int NU = (nkc + NKU - 1) / NKU;  // units per group
+  const unsigned ld4 = (unsigned)ld_in >> 2;
+  float* acc = reinterpret_cast<float*>(smem + wv * ACCB);
+  for (int i = lane; i < 65 * LD; i += 64) acc[i] = 0.f;
+  const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4 + lane * NTW * 16;
+  const float4* __restrict__ a_lane = reinterpret_cast<const float4*>(in) + q;
+  char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
+
+  float4 A[D][NKU];
+  float4 B[D][NKU][NTW];
+
+  for (int cb = gb; cb < ge; cb += T4_MU) {
+    __syncthreads();  // every wave is done with the previous chunk's metadata (and the accumulators are zeroed)
+    for (int e = tid * 4; e < MS * 16; e += 1024) {
+      const int src = min(cb * 16 + e, G * 16 - 4);
+      const int4 vi = *reinterpret_cast<const int4*>(grp_in + src);
+      const int4 vo = *reinterpret_cast<const int4*>(grp_out + src);
+      const bool dead = cb + (e >> 4) >= ge || (e >> 4) >= T4_MU;
+      uint4 wi;
+      wi.x = dead ? 0u : (unsigned)max(vi.x, 0) * ld4; wi.y = dead ? 0u : (unsigned)max(vi.y, 0) * ld4;
+      wi.z = dead ? 0u : (unsigned)max(vi.z, 0) * ld4; wi.w = dead ? 0u : (unsigned)max(vi.w, 0) * ld4;
+      const unsigned o0 = (unsigned)((dead || vo.x < 0) ? 64 : vo.x) * (LD * 4), o1 = (unsigned)((dead || vo.y < 0) ? 64 : vo.y) * (LD * 4);
+      const unsigned o2 = (unsigned)((dead || vo.z < 0) ? 64 : vo.z) * (LD * 4), o3 = (unsigned)((dead || vo.w < 0) ? 64 : vo.w) * (LD * 4);
+      *reinterpret_cast<uint4*>(m_in + e) = wi;
+      *reinterpret_cast<uint2*>(m_out + e) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+    }
+    if (tid < MS) {
+      const int o = grp_o[min(cb + tid, G - 1)];
+      const bool dead = cb + tid >= ge || tid >= T4_MU;
+      m_w[tid] = dead ? 0u : (unsigned)((w_flip ? K - 1 - o : o) * cin * CP * 4);
+    }
+    __syncthreads();
+    const int ng = min(T4_MU, ge - cb);
+    const int nmine = ng > wv ? (ng - wv + 3) >> 2 : 0;  // this wave: groups wv, wv+4, ...
+    const int U = nmine * NU;
+    const int gdead = T4_MU + wv;
+
+    int ig = wv < ng ? wv : gdead, iku = 0, cgp = ig, cku = 0;
+    unsigned io_n = m_in[ig * 16 + r], wo_n = m_w[ig];
+    uint2 mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);
+#define T4_ISSUE(S)                                                                                        \
+  {                                                                                                        \
+    const char* wp_ = wcg + __builtin_amdgcn_readfirstlane(wo_n);                                          \
+    _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                                      \
+      const int kc_ = PART ? min(iku * NKU + j, nkc - 1) : iku * NKU + j;                                  \
+      A[S][j] = a_lane[(uint64_t)io_n + (unsigned)(kc_ * 4)];                                              \
+      _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                   \
+        B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + v_ * 16);       \
+    }                                                                                                      \
+    if (++iku == NU) { iku = 0; ig = ig + 4 < ng ? ig + 4 : gdead; }                                       \
+    io_n = m_in[ig * 16 + r];                                                                              \
+    wo_n = m_w[ig];                                                                                        \
+  }
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      T4_ISSUE(s);
+      __builtin_amdgcn_sched_barrier(0);  // keep the ring in issue order: the loop's counted vmcnt relies on it
+    }
+    for (int u = 0; u < U; u += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const unsigned ol[4] = {mo_n.x & 0xffffu, mo_n.x >> 16, mo_n.y & 0xffffu, mo_n.y >> 16};
+        BT v[4];  // the 4 rows of a lane are distinct output rows (or the sink): read all, then write all
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const BT*>(acc_lane + ol[j]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the accumulator reads in flight under the MFMAs
+        f32x4 d[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NKU; ++j) {
+          const bool live = !PART || cku * NKU + j < nkc;
+          const float av[4] = {live ? A[s][j].x : 0.f, live ? A[s][j].y : 0.f, live ? A[s][j].z : 0.f, live ? A[s][j].w : 0.f};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const float* bw = reinterpret_cast<const float*>(&B[s][j][0]) + s2 * NTW;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
+          }
+        }
+        if (++cku == NU) { cku = 0; cgp = cgp + 4 < ng ? cgp + 4 : gdead; }
+        mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);
+        T4_ISSUE(s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float* vf = reinterpret_cast<float*>(&v[j]);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) vf[t] += d[t][j];
+          *reinterpret_cast<BT*>(acc_lane + ol[j]) = v[j];
+        }
+      }
+    }
+#undef T4_ISSUE
+  }
+  __syncthreads();
+  // ordered sum of the four partial accumulators; each output element is written exactly once
+  constexpr int V = CP / 4;
+  const float* a0 = reinterpret_cast<const float*>(smem);
+  for (int i = tid; i < 64 * V; i += 256) {
+    const int rr = i / V, c4 = i - rr * V;
+    if (row0 + rr < A_out) {
+      float4 sum = *reinterpret_cast<const float4*>(a0 + rr * LD + c4 * 4);
+#pragma unroll
+      for (int w2 = 1; w2 < 4; ++w2) {
+        const float4 p = *reinterpret_cast<const float4*>(a0 + w2 * (65 * LD) + rr * LD + c4 * 4);
+        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+      }
+      *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + cg * CP + c4 * 4) = sum;
+    }
+  }
+}
+
+template <int NTW, int NKU, int D>
+static int launch_t4(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
+                     int cin, const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
+  constexpr int CP = NTW * 16, LD = CP + 4, MS = T4_MU + 4;
+  const size_t lds = 4 * 65 * LD * 4 + MS * 100;
+  const bool part = ((cin >> 4) % NKU) != 0;
+  dim3 grid((unsigned)cdiv64(A_out, 64), cout / CP);
+#define T4_GO(P)                                                                                                          \
+  {                                                                                                                       \
+    auto kern = k_spconv_t4<NTW, NKU, D, P>;                                                                              \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set && lds > 64 * 1024) {                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return MOPA_ERR_LAUNCH;                                                                                           \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    kern<<<grid, 256, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, Wp, w_flip, out, ld_out);                    \
+  }
+  if (part) T4_GO(true) else T4_GO(false)
+#undef T4_GO
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
 // out[row][c] = sum_z part[z][row][c] (fixed order: deterministic)
 __global__ void k_sum_partials(const float* __restrict__ part, int nsplit, int A_out, int cout, int ld, float* __restrict__ out,
                                int ld_out) {
@@ -740,21 +936,44 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
                        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
-  if (cin > 192) return MOPA_ERR_ARG;
+  if (cin > ((w_flip & 2) ? 224 : 192)) return MOPA_ERR_ARG;
   // long levels: one pipelined wave per tile (k_spconv_pipe, packed weights); short levels: 4-wave blocks with
   // LDS-staged weights.  w_flip bit 0 = mirrored filter offsets, bit 1 = weight is packed (mopa_spconv_pack_weight).
   const int packed = (w_flip >> 1) & 1;
   w_flip &= 1;
   if (packed) {
-    if (!aligned || !pipe_eligible(K, num_out, cin, cout)) return MOPA_ERR_ARG;
+    int pntw;
+    const int path = packed_plan(K, num_out, cin, cout, &pntw);
+    if (!aligned || path == SP_BLK) return MOPA_ERR_ARG;
+    const int nkc = cin / 16;
+    if (path == SP_PIPE) {
 #define PP(N, DD, MU) return launch_pipe<N, DD, MU>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, w_flip, out, ld_out, st)
-    switch (cout / 16) {
-      case 1: PP(1, 6, 40);   // LDS 9.6 KB -> 16 waves / CU
-      case 2: PP(2, 6, 32);   // 13.0 KB -> 12
-      case 3: PP(3, 6, 40);   // 17.9 KB ->  8
-      default: PP(4, 4, 28);  // 20.9 KB ->  7
-    }
+      switch (cout / 16) {
+        case 1: PP(1, 6, 40);   // LDS 9.6 KB -> 16 waves / CU
+        case 2: PP(2, 6, 32);   // 13.0 KB -> 12
+        case 3: PP(3, 6, 40);   // 17.9 KB ->  8
+        default: PP(4, 4, 28);  // 20.9 KB ->  7
+      }
 #undef PP
+    }
+#define T4(N, KU, DD) return launch_t4<N, KU, DD>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
+    // unit = group x NKU chunks: the whole Cin up to 64 channels, else 3-4 chunks per unit (registers: NKU*4*(1+NTW) per ring slot)
+    if (pntw == 1) {
+      if (nkc == 1) T4(1, 1, 8);
+      if (nkc == 2) T4(1, 2, 6);
+      if (nkc == 3 || nkc == 6 || nkc == 9) T4(1, 3, 4);
+      T4(1, 4, 3);
+    }
+    if (pntw == 2) {
+      if (nkc == 1) T4(2, 1, 6);
+      if (nkc == 2) T4(2, 2, 4);
+      if (nkc == 3 || nkc == 6 || nkc == 9) T4(2, 3, 3);
+      T4(2, 4, 2);
+    }
+    if (nkc == 1) T4(3, 1, 4);
+    if (nkc == 2 || nkc == 4) T4(3, 2, 3);
+    T4(3, 3, 2);
+#undef T4
   }
   const int ntw = aligned ? blk_plan(num_out, cin, cout) : 1;
   if (blk_lds_bytes(ntw, cin) > 64 * 1024) return MOPA_ERR_ARG;

@@ -167,10 +167,11 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
     K, A_out = nbr.shape
     cin, cout = x.C, out.C
     assert out.rows == A_out and w.shape == ((K, cout, cin) if w_transposed else (K, cin, cout)), (nbr.shape, cin, cout, w.shape)
-    packed = rb is not None and bool(query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout))
-    if packed:
+    ntw = query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout) if rb is not None else 0
+    packed = ntw > 0
+    if packed:   # column groups of ntw 16-column tiles, MFMA-operand order (mopa_spconv_pack_weight)
         wk = torch.empty(K * cin * cout, dtype=w.dtype, device=w.device)
-        call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], int(w_transposed), ptr(wk), stream())
+        call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], int(w_transposed), ntw, ptr(wk), stream())
     else:
         wk = spconv_transpose_weight(w) if w_transposed else w
     spconv_launch(nbr, x, wk, out, w_flip, rb, packed)
@@ -180,13 +181,14 @@ def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_fli
     """The convolution launch itself, on a weight already laid out for the kernel that runs (bench.py times this)."""
     K, A_out = nbr.shape
     cin, cout = x.C, out.C
-    # measured on MI355X (profiles/r1_*): long levels run one pipelined wave per tile on packed weights; short ones the
-    # 4-wave block kernel with LDS-staged weights (2-3x faster than the dense-table wave kernel there).
+    # measured on MI355X (profiles/bench_spconv.py): 27-offset tables run the pipelined kernels on packed weights (one wave
+    # per tile at 16 channels, four waves per tile and column group above); the 8-offset down/up tables the dense-table
+    # wave kernel, except on the shortest levels (< 200 tiles) where the 4-wave block kernel with LDS-staged weights wins.
     if packed:
         gs, go, gi, gout = rb
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
              int(w_flip) | 2, out.p, out.ld, 0, 0, stream())
-    elif rb is not None and (A_out + 63) // 64 < 1500:
+    elif rb is not None and (A_out + 63) // 64 < (1500 if K == 27 else 200):
         gs, go, gi, gout = rb
         ws = _ws(query("mopa_spconv_grouped_workspace_bytes", K, A_out, cout), wk.device)
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,

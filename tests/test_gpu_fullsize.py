@@ -92,10 +92,12 @@ def test_sparse_conv_linearity_and_locality_full_size():
     assert set(hit.tolist()) <= set(allowed.tolist()) and hit.numel() <= 27
 
 
-@pytest.mark.parametrize("level,cin,cout", [(0, 16, 16), (0, 32, 16), (1, 32, 32), (2, 96, 48), (1, 128, 64)])
+@pytest.mark.parametrize("level,cin,cout", [(0, 16, 16), (0, 32, 16), (1, 32, 32), (1, 64, 32), (2, 48, 48), (2, 96, 48),
+                                            (1, 128, 64), (2, 80, 80), (2, 112, 96), (2, 224, 112)])
 def test_long_level_pipelined_spconv_matches_oracle_and_dense_table_kernel(level, cin, cout):
-    """Levels with >= 1500 tiles run the pipelined kernel on packed weights (mopa_spconv_pack_weight): check it, fwd and
-    backward-data, against the fp64 oracle on the GPU-built table and against the dense-table kernel (rb=None)."""
+    """27-offset tables run the pipelined kernels on packed weights (mopa_spconv_pack_weight; one wave per tile at 16
+    output channels, else four waves per tile and column group, with whole / partial channel-chunk units): check them,
+    fwd and backward-data, against the fp64 oracle on the GPU-built table and against the dense-table kernel (rb=None)."""
     from mopa_amd import sparse3d as s3
     from mopa_amd import synth
     from mopa_amd._lib import query
@@ -104,8 +106,8 @@ def test_long_level_pipelined_spconv_matches_oracle_and_dense_table_kernel(level
     g = s3.Geometry3D(b["x"][0], 3, 4096, "cuda")
     tab = g.nbr27[level]
     K, A = tab.shape
-    assert query("mopa_spconv_grouped_wants_packed", K, A, cin, cout) == 1   # this IS the pipelined path
-    assert query("mopa_spconv_grouped_wants_packed", K, A, cout, cin) == (1 if cin <= 64 else 0)
+    assert query("mopa_spconv_grouped_wants_packed", K, A, cin, cout) >= 1   # this IS a pipelined path
+    assert query("mopa_spconv_grouped_wants_packed", K, A, cout, cin) >= 1
     gen = torch.Generator().manual_seed(level * 100 + cin)
     x = torch.randn(A, cin, generator=gen)
     w = torch.randn(K, cin, cout, generator=gen) * 0.1
@@ -115,18 +117,20 @@ def test_long_level_pipelined_spconv_matches_oracle_and_dense_table_kernel(level
     xv, wv, dyv = s3.View(x.cuda()), w.cuda(), s3.View(dy.cuda())
     out, out_d = s3.new_view(A, cout, "cuda"), s3.new_view(A, cout, "cuda")
     s3.spconv_fwd(tab, xv, wv, out, rb=g.rulebook(tab))
-    s3.spconv_fwd(tab, xv, wv, out_d)
     scale = float(ref.abs().max())
     assert float((out.t.cpu().double() - ref).abs().max()) <= 2e-5 * scale          # fp32 sums of <= 27*cin terms
-    assert float((out.t - out_d.t).abs().max()) <= 2e-5 * scale
+    if cin <= 192:                                                                   # the dense-table kernel's limit
+        s3.spconv_fwd(tab, xv, wv, out_d)
+        assert float((out.t - out_d.t).abs().max()) <= 2e-5 * scale
     # backward-data: same table, mirrored offsets, per-offset transposed weight (packed by the op itself)
     ref_dx = scn3d.sparse_conv(dy.double(), tab_h, w.double().transpose(1, 2).flip(0).contiguous())
     dx, dx_d = s3.new_view(A, cin, "cuda"), s3.new_view(A, cin, "cuda")
     s3.spconv_fwd(tab, dyv, wv, dx, w_flip=True, rb=g.rulebook(tab), w_transposed=True)
-    s3.spconv_fwd(tab, dyv, wv, dx_d, w_flip=True, w_transposed=True)
     sdx = float(ref_dx.abs().max())
     assert float((dx.t.cpu().double() - ref_dx).abs().max()) <= 2e-5 * sdx
-    assert float((dx.t - dx_d.t).abs().max()) <= 2e-5 * sdx
+    if cout <= 192:
+        s3.spconv_fwd(tab, dyv, wv, dx_d, w_flip=True, w_transposed=True)
+        assert float((dx.t - dx_d.t).abs().max()) <= 2e-5 * sdx
 
 
 def test_joint_training_step_reduces_the_loss_full_size():
