@@ -298,9 +298,11 @@ enum { SP_BLK = 0, SP_PIPE = 1, SP_T4 = 2 };
 static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
   static const int force_path = getenv("MOPA_SPCONV_PATH") ? atoi(getenv("MOPA_SPCONV_PATH")) : 0;  // tuning only
   *ntw = 0;
-  if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || K != 27 || force_path == 2) return SP_BLK;
+  if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || force_path == 2) return SP_BLK;
   const int64_t tiles = cdiv64(num_out, 64);
   const int nt = cout / 16;
+  // 8-offset down/up tables (few groups per tile): the dense-table wave kernel wins on the long levels (20-34 us vs 35-45)
+  if (K != 27 && force_path != 4 && (force_path != 0 || tiles > 800)) return SP_BLK;
   if (force_path == 1) {
     if (cout > 64) return SP_BLK;
     *ntw = nt;

@@ -133,6 +133,32 @@ def test_long_level_pipelined_spconv_matches_oracle_and_dense_table_kernel(level
         assert float((dx.t - dx_d.t).abs().max()) <= 2e-5 * sdx
 
 
+@pytest.mark.parametrize("kind,cin,cout", [("down", 64, 80), ("up", 80, 64)])
+def test_short_level_down_up_tables_on_the_four_wave_kernel(kind, cin, cout):
+    """8-offset tables with <= 800 tiles also run k_spconv_t4 (packed weights): Convolution / Deconvolution k2s2 between
+    levels 3 and 4 of the bench geometry against the fp64 oracle and the dense-table kernel."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd import synth
+    from mopa_amd._lib import query
+    from oracle import scn3d
+    b = synth.make_batch(8, H=16, W=16)
+    g = s3.Geometry3D(b["x"][0], 5, 4096, "cuda")
+    tab = g.ch[3] if kind == "down" else g.up[3]
+    K, A_out = tab.shape
+    A_in = g.num_active[3] if kind == "down" else g.num_active[4]
+    assert K == 8 and query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout) >= 1
+    gen = torch.Generator().manual_seed(cin)
+    x = torch.randn(A_in, cin, generator=gen)
+    w = torch.randn(K, cin, cout, generator=gen) * 0.1
+    ref = scn3d.sparse_conv(x.double(), tab.cpu().numpy(), w.double())
+    out, out_d = s3.new_view(A_out, cout, "cuda"), s3.new_view(A_out, cout, "cuda")
+    s3.spconv_fwd(tab, s3.View(x.cuda()), w.cuda(), out, rb=g.rulebook(tab))
+    s3.spconv_fwd(tab, s3.View(x.cuda()), w.cuda(), out_d)
+    scale = float(ref.abs().max())
+    assert float((out.t.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((out.t - out_d.t).abs().max()) <= 2e-5 * scale
+
+
 def test_joint_training_step_reduces_the_loss_full_size():
     """A few FlatAdam steps on ONE fixed nuScenes-shape batch (2 scans) must lower CE + KL + SAM loss."""
     from mopa_amd import synth
