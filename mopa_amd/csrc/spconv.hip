@@ -315,8 +315,10 @@ static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
     *ntw = 1;
     return SP_PIPE;
   }
-  // 4 waves per (tile, column group): column groups of 2 tiles when they divide Cout, else 3, else 1
-  const int w = nt % 2 == 0 ? 2 : nt % 3 == 0 ? 3 : 1;
+  // 4 waves per (tile, column group): column groups of 2 tiles when they divide Cout, else 3, else 1 -- and 1 on the
+  // shortest levels, where the wider groups would leave fewer than ~3 blocks per CU
+  int w = nt % 2 == 0 ? 2 : nt % 3 == 0 ? 3 : 1;
+  if (tiles * (nt / w) < 768) w = 1;
   if (force_path == 4 || tiles * (nt / w) >= 256) {
     *ntw = w;
     return SP_T4;
@@ -963,13 +965,16 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
     if (pntw == 1) {
       if (nkc == 1) T4(1, 1, 8);
       if (nkc == 2) T4(1, 2, 6);
-      if (nkc == 3 || nkc == 6 || nkc == 9) T4(1, 3, 4);
+      if (nkc % 5 == 0) T4(1, 5, 3);   // 80 / 160 channels: whole units, no padded chunk
+      if (nkc % 7 == 0) T4(1, 7, 2);   // 112 / 224
+      if (nkc % 3 == 0) T4(1, 3, 4);
       T4(1, 4, 3);
     }
     if (pntw == 2) {
       if (nkc == 1) T4(2, 1, 6);
       if (nkc == 2) T4(2, 2, 4);
-      if (nkc == 3 || nkc == 6 || nkc == 9) T4(2, 3, 3);
+      if (nkc % 5 == 0) T4(2, 5, 2);
+      if (nkc % 3 == 0) T4(2, 3, 3);
       T4(2, 4, 2);
     }
     if (nkc == 1) T4(3, 1, 4);
