@@ -369,13 +369,13 @@ def main():
         sp = None
         if ks:
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_pipe / k_spconv_blk / k_spconv_fwd (sparse conv fwd + bwd-data)",
+                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
         t3 = os.path.join(ROOT, "profiles", "r1_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d`
         if sp and os.path.exists(t3):
             d3 = json.load(open(t3))
-            fam = [d3[k] for k in ("k_spconv_fwd", "k_spconv_blk") if k in d3]
+            fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
                 sp["traffic_source"] = "profiles/r1_3d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 3d workload)"

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmopa_hip.so")
+LIB_PATH = os.environ.get("MOPA_HIP_LIB") or os.path.join(_HERE, "libmopa_hip.so")  # env override: A/B tuning builds only
 
 _P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _T = {"p": _P, "i": _I, "l": _L, "z": _Z, "f": _F}

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64, (NTW == 1 ? 4 : NTW == 2 ? 3 : 2)) void k_spcon
   const int gb = grp_start[tile], ge = grp_start[tile + 1], G = grp_start[ntiles];
   const int nkc = cin >> 4;
   const unsigned ld4 = (unsigned)ld_in >> 2;
-  for (int i = lane; i < 65 * LD; i += 64) acc[i] = 0.f;
+  for (int i = lane; i < 65 * LD / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const unsigned b_lane = (unsigned)(lane * NTW * 16);  // this lane's 4 x NTW floats inside a packed 16 x CP weight chunk
   const float4* __restrict__ a_lane = reinterpret_cast<const float4*>(in) + q;
   char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
   const int NU = (nkc + NKU - 1) / NKU;  // units per group
   const unsigned ld4 = (unsigned)ld_in >> 2;
   float* acc = reinterpret_cast<float*>(smem + wv * ACCB);
-  for (int i = lane; i < 65 * LD; i += 64) acc[i] = 0.f;
+  for (int i = lane; i < 65 * LD / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4 + lane * NTW * 16;
   const float4* __restrict__ a_lane = reinterpret_cast<const float4*>(in) + q;
   char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
@@ -1164,16 +1164,19 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad2(const int* __restrict__ nb
     ai = l_in[ip];                                                                       \
     bi = l_out[ip];                                                                      \
   }
+    // no separate prologue (the compiler would order its loads differently from the loop's and the counted waits would
+    // have to cover both): the ring starts zeroed and the first D k-steps of the loop multiply zeros while they fill it
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-      WG2_ISSUE(s);
-      __builtin_amdgcn_sched_barrier(0);  // keep the ring in issue order: the loop's counted vmcnt relies on it
+      A[s] = typename UVec<MU>::T(0.f);
+      B0[s] = typename UVec<NT0>::T(0.f);
+      B1[s] = typename UVec<NT1>::T(0.f);
     }
-    int cp = q;
-    for (int u = 0; u < U; u += D) {
+    int cp = q - 4 * D;
+    for (int u = -D; u < U; u += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {
-        const bool ok = cp < n;
+        const bool ok = cp >= 0 && cp < n;
         cp += 4;
         float a[MU], b[NT];
         {
@@ -1190,6 +1193,7 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad2(const int* __restrict__ nb
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
         WG2_ISSUE(s);
+        __builtin_amdgcn_sched_barrier(0);  // refill the slot right after its k-step (the scheduler would batch all refills at the end)
       }
     }
 #undef WG2_ISSUE
