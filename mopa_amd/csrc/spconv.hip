@@ -679,7 +679,8 @@ static int launch_pipe(const int* gs, const int* go, const int* gi, const int* g
 //     accumulator read-add-write and 4*NKU*NTW MFMAs per unit;
 //   * wide outputs are cut into column groups (grid.y) so four accumulators fit 2-4 blocks per CU.
 // The block stages the tile's metadata once (shared); everything else is as in k_spconv_pipe.
-#define T4_MU 72  // groups staged per chunk (a tile rarely has more)
+#define T4_MU 48  // groups staged per chunk (p99 of the bench geometry is 38-57; more = a second chunk)
+#define T4_PAD 4  // accumulator row padding (floats): 0 fits a 4th block per CU at 32 columns (level 1 -6 %) but costs 3-4 % on the MFMA-heavy levels
 template <int NTW, int NKU, int D, bool PART>
 __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
                                                     const int* __restrict__ grp_in, const int* __restrict__ grp_out,
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
                                                     const float* __restrict__ Wp, int w_flip,
                                                     float* __restrict__ out, int ld_out) {
   constexpr int CP = NTW * 16;
-  constexpr int LD = CP + 4;
+  constexpr int LD = CP + T4_PAD;
   constexpr int MS = T4_MU + 4;       // + one dead group per wave for the ring's look-ahead
   constexpr int ACCB = 65 * LD * 4;   // bytes of one accumulator (row 64 = sink)
   static_assert(ACCB < 65536 && ACCB % 16 == 0, "metadata packing");
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
 template <int NTW, int NKU, int D>
 static int launch_t4(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
                      int cin, const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
-  constexpr int CP = NTW * 16, LD = CP + 4, MS = T4_MU + 4;
+  constexpr int CP = NTW * 16, LD = CP + T4_PAD, MS = T4_MU + 4;
   const size_t lds = 4 * 65 * LD * 4 + MS * 100;
   const bool part = ((cin >> 4) % NKU) != 0;
   dim3 grid((unsigned)cdiv64(A_out, 64), cout / CP);
@@ -963,22 +964,22 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
 #define T4(N, KU, DD) return launch_t4<N, KU, DD>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
     // unit = group x NKU chunks: the whole Cin up to 64 channels, else 3-4 chunks per unit (registers: NKU*4*(1+NTW) per ring slot)
     if (pntw == 1) {
-      if (nkc == 1) T4(1, 1, 8);
-      if (nkc == 2) T4(1, 2, 6);
-      if (nkc % 5 == 0) T4(1, 5, 3);   // 80 / 160 channels: whole units, no padded chunk
+      if (nkc == 1) T4(1, 1, 4);
+      if (nkc == 2) T4(1, 2, 2);
+      if (nkc % 5 == 0) T4(1, 5, 2);   // 80 / 160 channels: whole units, no padded chunk
       if (nkc % 7 == 0) T4(1, 7, 2);   // 112 / 224
-      if (nkc % 3 == 0) T4(1, 3, 4);
-      T4(1, 4, 3);
+      if (nkc % 3 == 0) T4(1, 3, 2);
+      T4(1, 4, 2);
     }
     if (pntw == 2) {
-      if (nkc == 1) T4(2, 1, 6);
-      if (nkc == 2) T4(2, 2, 4);
+      if (nkc == 1) T4(2, 1, 2);
+      if (nkc == 2) T4(2, 2, 2);
       if (nkc % 5 == 0) T4(2, 5, 2);
-      if (nkc % 3 == 0) T4(2, 3, 3);
+      if (nkc % 3 == 0) T4(2, 3, 2);
       T4(2, 4, 2);
     }
-    if (nkc == 1) T4(3, 1, 4);
-    if (nkc == 2 || nkc == 4) T4(3, 2, 3);
+    if (nkc == 1) T4(3, 1, 2);
+    if (nkc == 2 || nkc == 4) T4(3, 2, 2);
     T4(3, 3, 2);
 #undef T4
   }
