@@ -679,25 +679,25 @@ static int launch_pipe(const int* gs, const int* go, const int* gi, const int* g
 //     accumulator read-add-write and 4*NKU*NTW MFMAs per unit;
 //   * wide outputs are cut into column groups (grid.y) so four accumulators fit 2-4 blocks per CU.
 // The block stages the tile's metadata once (shared); everything else is as in k_spconv_pipe.
-#define T4_MU 48  // groups staged per chunk (p99 of the bench geometry is 38-57; more = a second chunk)
 #define T4_PAD 4  // accumulator row padding (floats): 0 fits a 4th block per CU at 32 columns (level 1 -6 %) but costs 3-4 % on the MFMA-heavy levels
-template <int NTW, int NKU, int D, bool PART>
-__global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+template <int NTW, int NKU, int D, bool PART, int NWV>  // NWV waves per tile: 4, or 1 for the 16-column layers of the long levels
+__global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
                                                     const int* __restrict__ grp_in, const int* __restrict__ grp_out,
                                                     int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
                                                     const float* __restrict__ Wp, int w_flip,
                                                     float* __restrict__ out, int ld_out) {
   constexpr int CP = NTW * 16;
   constexpr int LD = CP + T4_PAD;
-  constexpr int MS = T4_MU + 4;       // + one dead group per wave for the ring's look-ahead
+  constexpr int MU = NWV == 1 ? 40 : 48;  // groups staged per chunk (p99 of the bench geometry: 38-57; more = another chunk)
+  constexpr int MS = MU + 4;              // + dead groups for the ring's look-ahead
   constexpr int ACCB = 65 * LD * 4;   // bytes of one accumulator (row 64 = sink)
   static_assert(ACCB < 65536 && ACCB % 16 == 0, "metadata packing");
   typedef typename FVec<NTW>::T BT;
   extern __shared__ float4 smem4[];
   char* smem = reinterpret_cast<char*>(smem4);
-  unsigned* m_in = reinterpret_cast<unsigned*>(smem + 4 * ACCB);                          // [MS][16] input row * (ld_in/4)
-  unsigned short* m_out = reinterpret_cast<unsigned short*>(smem + 4 * ACCB + MS * 64);   // [MS][16] accumulator row byte offset
-  unsigned* m_w = reinterpret_cast<unsigned*>(smem + 4 * ACCB + MS * 96);                 // [MS] byte offset of the group's W[o]
+  unsigned* m_in = reinterpret_cast<unsigned*>(smem + NWV * ACCB);                          // [MS][16] input row * (ld_in/4)
+  unsigned short* m_out = reinterpret_cast<unsigned short*>(smem + NWV * ACCB + MS * 64);   // [MS][16] accumulator row byte offset
+  unsigned* m_w = reinterpret_cast<unsigned*>(smem + NWV * ACCB + MS * 96);                 // [MS] byte offset of the group's W[o]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x, ntiles = gridDim.x, cg = blockIdx.y;
   const int row0 = tile * 64;
@@ -714,13 +714,13 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
   float4 A[D][NKU];
   float4 B[D][NKU][NTW];
 
-  for (int cb = gb; cb < ge; cb += T4_MU) {
+  for (int cb = gb; cb < ge; cb += MU) {
     __syncthreads();  // every wave is done with the previous chunk's metadata (and the accumulators are zeroed)
-    for (int e = tid * 4; e < MS * 16; e += 1024) {
+    for (int e = tid * 4; e < MS * 16; e += 256 * NWV) {
       const int src = min(cb * 16 + e, G * 16 - 4);
       const int4 vi = *reinterpret_cast<const int4*>(grp_in + src);
       const int4 vo = *reinterpret_cast<const int4*>(grp_out + src);
-      const bool dead = cb + (e >> 4) >= ge || (e >> 4) >= T4_MU;
+      const bool dead = cb + (e >> 4) >= ge || (e >> 4) >= MU;
       uint4 wi;
       wi.x = dead ? 0u : (unsigned)max(vi.x, 0) * ld4; wi.y = dead ? 0u : (unsigned)max(vi.y, 0) * ld4;
       wi.z = dead ? 0u : (unsigned)max(vi.z, 0) * ld4; wi.w = dead ? 0u : (unsigned)max(vi.w, 0) * ld4;
@@ -731,14 +731,14 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
     }
     if (tid < MS) {
       const int o = grp_o[min(cb + tid, G - 1)];
-      const bool dead = cb + tid >= ge || tid >= T4_MU;
+      const bool dead = cb + tid >= ge || tid >= MU;
       m_w[tid] = dead ? 0u : (unsigned)((w_flip ? K - 1 - o : o) * cin * CP * 4);
     }
     __syncthreads();
-    const int ng = min(T4_MU, ge - cb);
-    const int nmine = ng > wv ? (ng - wv + 3) >> 2 : 0;  // this wave: groups wv, wv+4, ...
+    const int ng = min(MU, ge - cb);
+    const int nmine = ng > wv ? (ng - wv + NWV - 1) / NWV : 0;  // this wave: groups wv, wv+NWV, ...
     const int U = nmine * NU;
-    const int gdead = T4_MU + wv;
+    const int gdead = MU + wv;
 
     int ig = wv < ng ? wv : gdead, iku = 0, cgp = ig, cku = 0;
     unsigned io_n = m_in[ig * 16 + r], wo_n = m_w[ig];
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
       _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                   \
         B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + v_ * 16);       \
     }                                                                                                      \
-    if (++iku == NU) { iku = 0; ig = ig + 4 < ng ? ig + 4 : gdead; }                                       \
+    if (++iku == NU) { iku = 0; ig = ig + NWV < ng ? ig + NWV : gdead; }                                       \
     io_n = m_in[ig * 16 + r];                                                                              \
     wo_n = m_w[ig];                                                                                        \
   }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
             for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
           }
         }
-        if (++cku == NU) { cku = 0; cgp = cgp + 4 < ng ? cgp + 4 : gdead; }
+        if (++cku == NU) { cku = 0; cgp = cgp + NWV < ng ? cgp + NWV : gdead; }
         mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);
         T4_ISSUE(s);
 #pragma unroll
@@ -801,12 +801,12 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
   // ordered sum of the four partial accumulators; each output element is written exactly once
   constexpr int V = CP / 4;
   const float* a0 = reinterpret_cast<const float*>(smem);
-  for (int i = tid; i < 64 * V; i += 256) {
+  for (int i = tid; i < 64 * V; i += 64 * NWV) {
     const int rr = i / V, c4 = i - rr * V;
     if (row0 + rr < A_out) {
       float4 sum = *reinterpret_cast<const float4*>(a0 + rr * LD + c4 * 4);
 #pragma unroll
-      for (int w2 = 1; w2 < 4; ++w2) {
+      for (int w2 = 1; w2 < NWV; ++w2) {
         const float4 p = *reinterpret_cast<const float4*>(a0 + w2 * (65 * LD) + rr * LD + c4 * 4);
         sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
       }
@@ -815,23 +815,23 @@ __global__ __launch_bounds__(256) void k_spconv_t4(const int* __restrict__ grp_s
   }
 }
 
-template <int NTW, int NKU, int D>
+template <int NTW, int NKU, int D, int NWV = 4>
 static int launch_t4(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, const float* in, int ld_in,
                      int cin, const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
-  constexpr int CP = NTW * 16, LD = CP + T4_PAD, MS = T4_MU + 4;
-  const size_t lds = 4 * 65 * LD * 4 + MS * 100;
+  constexpr int CP = NTW * 16, LD = CP + T4_PAD, MS = (NWV == 1 ? 40 : 48) + 4;
+  const size_t lds = NWV * 65 * LD * 4 + MS * 100;
   const bool part = ((cin >> 4) % NKU) != 0;
   dim3 grid((unsigned)cdiv64(A_out, 64), cout / CP);
 #define T4_GO(P)                                                                                                          \
   {                                                                                                                       \
-    auto kern = k_spconv_t4<NTW, NKU, D, P>;                                                                              \
+    auto kern = k_spconv_t4<NTW, NKU, D, P, NWV>;                                                                         \
     static bool attr_set = false;                                                                                         \
     if (!attr_set && lds > 64 * 1024) {                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return MOPA_ERR_LAUNCH;                                                                                           \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    kern<<<grid, 256, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, Wp, w_flip, out, ld_out);                    \
+    kern<<<grid, 64 * NWV, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, Wp, w_flip, out, ld_out);               \
   }
   if (part) T4_GO(true) else T4_GO(false)
 #undef T4_GO
@@ -951,10 +951,12 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
     const int path = packed_plan(K, num_out, cin, cout, &pntw);
     if (!aligned || path == SP_BLK) return MOPA_ERR_ARG;
     const int nkc = cin / 16;
+    if (path == SP_PIPE && cout == 16 && nkc == 2)   // 32 -> 16: one wave per tile with whole-Cin units (40 vs 42 us)
+      return launch_t4<1, 2, 2, 1>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st);
     if (path == SP_PIPE) {
 #define PP(N, DD, MU) return launch_pipe<N, DD, MU>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, w_flip, out, ld_out, st)
       switch (cout / 16) {
-        case 1: PP(1, 6, 40);   // LDS 9.6 KB -> 16 waves / CU
+        case 1: PP(1, 2, 40);   // LDS 9.6 KB -> 16 waves / CU
         case 2: PP(2, 6, 32);   // 13.0 KB -> 12
         case 3: PP(3, 6, 40);   // 17.9 KB ->  8
         default: PP(4, 4, 28);  // 20.9 KB ->  7
