@@ -301,8 +301,8 @@ static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
   if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || force_path == 2) return SP_BLK;
   const int64_t tiles = cdiv64(num_out, 64);
   const int nt = cout / 16;
-  // 8-offset down/up tables (few groups per tile): the dense-table wave kernel wins on the long levels (20-34 us vs 35-45)
-  if (K != 27 && force_path != 4 && (force_path != 0 || tiles > 800)) return SP_BLK;
+  // 8-offset down/up tables: few groups per tile -> one wave per tile on the long levels (dispatch below), four on the short
+  if (K != 27 && force_path != 4 && force_path != 0) return SP_BLK;
   if (force_path == 1) {
     if (cout > 64) return SP_BLK;
     *ntw = nt;
@@ -962,6 +962,13 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
         default: PP(4, 4, 28);  // 20.9 KB ->  7
       }
 #undef PP
+    }
+    if (K != 27 && cdiv64(num_out, 64) > 800) {   // long down/up tables: 17-28 us vs 20-34 on the dense-table kernel
+#define T1(N, KU) return launch_t4<N, KU, 2, 1>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
+      if (pntw == 1) { if (nkc == 1) T1(1, 1); if (nkc == 2) T1(1, 2); if (nkc == 3) T1(1, 3); T1(1, 4); }
+      if (pntw == 2) { if (nkc == 1) T1(2, 1); if (nkc == 2) T1(2, 2); if (nkc == 3) T1(2, 3); T1(2, 4); }
+      if (nkc == 1) T1(3, 1); if (nkc == 2) T1(3, 2); T1(3, 3);
+#undef T1
     }
 #define T4(N, KU, DD) return launch_t4<N, KU, DD>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
     // unit = group x NKU chunks: the whole Cin up to 64 channels, else 3-4 chunks per unit (registers: NKU*4*(1+NTW) per ring slot)
