@@ -1111,23 +1111,35 @@ template <> struct UVec<3> { typedef f3u T; };
 template <> struct UVec<4> { typedef f4u T; };
 #define WG2_CAP 1024
 #define WG2_TB 8
-template <int MU, int NT, int D>
-__global__ __launch_bounds__(64) void k_spconv_wgrad2(const int* __restrict__ nbr, int A_out, int rows_per_chunk,
-                                                       const float* __restrict__ in, int ld_in, int cin,
-                                                       const float* __restrict__ dout, int ld_do, int cout,
-                                                       float* __restrict__ slabs, int K) {
+// WG2_NWV waves per (offset, row chunk): 1, or 4 on the short levels (each takes a quarter of the rows, ordered combine in LDS)
+template <int MU, int NT, int D, int WG2_NWV>
+__global__ __launch_bounds__(64 * WG2_NWV) void k_spconv_wgrad2(const int* __restrict__ nbr, int A_out, int rows_per_chunk,
+                                                                 const float* __restrict__ in, int ld_in, int cin,
+                                                                 const float* __restrict__ dout, int ld_do, int cout,
+                                                                 float* __restrict__ slabs, int K) {
   constexpr int NT0 = NT > 4 ? 4 : NT, NT1 = NT > 4 ? NT - 4 : 1;
-  __shared__ unsigned l_in[WG2_CAP + 64];   // element offset of the rule's input row (row * ld_in)
-  __shared__ unsigned l_out[WG2_CAP + 64];  // element offset of its output-gradient row
-  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  // The 27 offsets differ 10x in rule count (the submanifold centre has a rule for every row, a corner offset ~0.1 per
+  // row), so with one wave per (offset, chunk) and the whole grid resident -- the short levels, where the slab budget
+  // caps the chunk count -- the few dense waves set the kernel's duration (3-4x the mean wave).  There, four waves per
+  // block quarter every wave and make the grid several rounds deep, so the dispatcher balances dense and sparse offsets;
+  // the slab count per offset stays even (cheap ordered reduction).  Long levels already have >10k waves: one per block.
+  extern __shared__ float4 wg_smem4[];
+  char* wg_smem = reinterpret_cast<char*>(wg_smem4);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  unsigned* l_in = reinterpret_cast<unsigned*>(wg_smem) + wv * 2 * (WG2_CAP + 64);  // element offset of the rule's input row
+  unsigned* l_out = l_in + (WG2_CAP + 64);                                           // ... and of its output-gradient row
+  float* comb = reinterpret_cast<float*>(wg_smem + WG2_NWV * 2 * (WG2_CAP + 64) * 4);  // [MU*NT*4][64] combine buffer
   const int o = blockIdx.x, chunk = blockIdx.y, mb = blockIdx.z;
   f32x4 acc[MU][NT];
 #pragma unroll
   for (int u = 0; u < MU; ++u)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int rbeg = chunk * rows_per_chunk;
-  const int rend = min(A_out, rbeg + rows_per_chunk);
+  const int cbeg = chunk * rows_per_chunk;
+  const int cend = min(A_out, cbeg + rows_per_chunk);
+  const int sub = WG2_NWV == 1 ? rows_per_chunk : ((rows_per_chunk / WG2_NWV) + 63) & ~63;
+  const int rbeg = cbeg + wv * sub;
+  const int rend = min(cend, rbeg + sub);
   const int* __restrict__ nrow = nbr + (int64_t)o * A_out;
   const float* __restrict__ a_lane = in + mb * 16 * MU + r * MU;
   const float* __restrict__ b_lane = dout + r * NT;
@@ -1208,6 +1220,28 @@ __global__ __launch_bounds__(64) void k_spconv_wgrad2(const int* __restrict__ nb
     }
 #undef WG2_ISSUE
   }
+  // ordered combine: waves 1..3 hand their accumulators to wave 0 through LDS, one after the other (deterministic)
+  for (int w = 1; w < WG2_NWV; ++w) {
+    __syncthreads();
+    if (wv == w) {
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) comb[((u * NT + t) * 4 + j) * 64 + lane] = acc[u][t][j];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[u][t][j] += comb[((u * NT + t) * 4 + j) * 64 + lane];
+    }
+  }
+  if (wv != 0) return;
   float* __restrict__ sl = slabs + ((int64_t)chunk * K + o) * cin * cout;
   const int cbase = mb * 16 * MU;
 #pragma unroll
@@ -1273,8 +1307,12 @@ static int launch_wgrad(int nt, dim3 grid, hipStream_t st, const int* nbr, int A
                         int ld_in, int cin, const float* dout, int ld_do, int cout, float* slabs, int K, bool aligned) {
   constexpr int DD = MU <= 2 ? 8 : 6;
   if (aligned) {
+    // (almost) the whole grid resident at once: split every wave four ways -- unless the combine buffer would leave
+    // only two blocks per CU (measured: 128->64 at level 3 190 -> 134 us, 96->48 154 -> 125; 64->96 80 -> 97 without the cap)
+    const bool four = (int64_t)grid.x * grid.y * grid.z <= 4200 && MU * nt <= 16;
     switch (nt) {
-#define CASE(N) case N: k_spconv_wgrad2<MU, N, (MU + N <= 6 ? 8 : DD)><<<grid, 64, 0, st>>>(nbr, A_out, rpc, in, ld_in, cin, dout, ld_do, cout, slabs, K); break
+#define CASE(N) case N: if (four) k_spconv_wgrad2<MU, N, (MU + N <= 6 ? 8 : DD), 4><<<grid, 256, 4 * 2 * (WG2_CAP + 64) * 4 + MU * N * 4 * 64 * 4, st>>>(nbr, A_out, rpc, in, ld_in, cin, dout, ld_do, cout, slabs, K); \
+                else k_spconv_wgrad2<MU, N, (MU + N <= 6 ? 8 : DD), 1><<<grid, 64, 2 * (WG2_CAP + 64) * 4 + MU * N * 4 * 64 * 4, st>>>(nbr, A_out, rpc, in, ld_in, cin, dout, ld_do, cout, slabs, K); break
       CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7);
 #undef CASE
       default: return MOPA_ERR_ARG;
