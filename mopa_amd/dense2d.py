@@ -13,7 +13,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import call, ptr, query, stream, workspace
+from ._lib import GradSink, call, ptr, query, stream, workspace
 from .sparse3d import View
 
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d defaults
@@ -84,15 +84,15 @@ class ConvOp:
         relayout(self.w, wl, self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
-    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool):
+    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False):
         dev = self.w.device
         k, s, p = self.k, self.s, self.p
-        # weight gradient in igemm layout, then scattered back to OIHW
+        # weight gradient in igemm layout, then scattered (or accumulated) back to OIHW
         dwl = torch.empty(k, k, self.I, self.O, dtype=torch.float32, device=dev)
         wgrad(x.p, dout.p, ptr(dwl), self._fwd_geom(x, dout), dev)
-        relayout(dwl, dw, self.O, self.I, k, k, 0, inverse=True)
+        relayout(dwl, dw, self.O, self.I, k, k, 0, inverse=True, accumulate=acc_params)
         if db is not None:
-            colsum(dout, db)
+            colsum(dout, db, accumulate=acc_params)
         if dx is None:
             return
         wt = torch.empty(k, k, self.O, self.I, dtype=torch.float32, device=dev)
@@ -137,7 +137,7 @@ class ConvTOp:
             for kx in range(2):
                 igemm(x.p, wl, self.b, out.p, self._geom(x, out, ky, kx))
 
-    def backward(self, x: Img, dout: Img, dx: Img, dw, db):
+    def backward(self, x: Img, dout: Img, dx: Img, dw, db, acc_params: bool = False):
         dev = self.w.device
         dwl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=dev)
         for ky in range(2):
@@ -145,8 +145,8 @@ class ConvTOp:
                 g = self._geom(x, dout, ky, kx)
                 g[17], g[18] = 0, 0  # KH0/KW0: the per-class launch writes a single-tap slab
                 wgrad(x.p, dout.p, ptr(dwl, (ky * 2 + kx) * self.I * self.O), g, dev)
-        relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True)
-        colsum(dout, db)
+        relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True, accumulate=acc_params)
+        colsum(dout, db, accumulate=acc_params)
         wt = torch.empty(2, 2, self.O, self.I, dtype=torch.float32, device=dev)
         relayout(self.w, wt, self.O, self.I, 2, 2, 3)
         g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IS=2, TH=2, TW=2, KWF=2,
@@ -169,13 +169,14 @@ def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
          ws.numel(), stream())
 
 
-def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, acc_dx=False):
+def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, acc_dx=False,
+           acc_params=False):
     wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bn_act_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), 0.0, int(act),
          ymask.p if ymask is not None else None, ymask.ld if ymask is not None else 0,
          dres.p if dres is not None else None, dres.ld if dres is not None else 0, int(acc_dres), int(training),
-         ptr(dgamma), ptr(dbeta), 0, int(acc_dx), ptr(ws), ws.numel(), stream())
+         ptr(dgamma), ptr(dbeta), int(acc_params), int(acc_dx), ptr(ws), ws.numel(), stream())
 
 
 # ------------------------------------------------------------------------------------------------ the network
@@ -307,12 +308,7 @@ class Net2DFunction(torch.autograd.Function):
         dev = feat.t.device
         C = spec.num_classes
         pre = "net_2d."
-        grads = {k: None for k in spec.order}
-
-        def gbuf(name):
-            g = torch.empty_like(P[name])
-            grads[name] = g
-            return g
+        sink = GradSink(P, spec.order)   # gradients go straight into attached .grad buffers (accumulating)
 
         def cont(t):
             return None if t is None else t.contiguous().float()
@@ -330,23 +326,22 @@ class Net2DFunction(torch.autograd.Function):
             call("mopa_points_csr", ptr(ctx.point_pix), N, rows, ptr(row_start), ptr(row_points), ptr(ws), ws.numel(),
                  stream())
             ws = _ws(query("mopa_output_layer_heads_bwd_workspace_bytes", N, 64, C), dev)
-            dw1 = gbuf("linear.weight") if dl1 is not None else None
-            db1 = gbuf("linear.bias") if dl1 is not None else None
-            dw2 = gbuf("linear2.weight") if dl2 is not None else None
-            db2 = gbuf("linear2.bias") if dl2 is not None else None
+            hnames = (["linear.weight", "linear.bias"] if dl1 is not None else []) + \
+                     (["linear2.weight", "linear2.bias"] if dl2 is not None else [])
+            hg, hacc = sink.take(*hnames)
+            hg = dict(zip(hnames, hg))
             call("mopa_output_layer_heads_bwd", ptr(dfeats), ptr(dl1), ptr(dl2), ptr(ctx.feats), ptr(P["linear.weight"]),
                  ptr(P["linear2.weight"]) if spec.dual_head else None, ptr(row_start), ptr(row_points), rows, N, 64, C,
-                 dfeat.p, dfeat.ld, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), 0, ptr(ws), ws.numel(), stream())
+                 dfeat.p, dfeat.ld, ptr(hg.get("linear.weight")), ptr(hg.get("linear.bias")), ptr(hg.get("linear2.weight")),
+                 ptr(hg.get("linear2.bias")), int(hacc), ptr(ws), ws.numel(), stream())
             head_w_acc = dl1 is not None
         else:
             dfeat.t.zero_()
         if dpred is not None:
-            if not head_w_acc:
-                gbuf("linear.weight"); gbuf("linear.bias")
+            (pw, pb), pacc = sink.take("linear.weight", "linear.bias")   # same tensors as the point head's, if it ran
             ws = _ws(query("mopa_pixel_head_bwd_workspace_bytes", B, H, W, 64, C), dev)
             call("mopa_pixel_head_bwd", ptr(dpred), feat.p, feat.ld, B, Hp, Wp, H, W, 64, C, ptr(P["linear.weight"]),
-                 dfeat.p, dfeat.ld, 1, ptr(grads["linear.weight"]), ptr(grads["linear.bias"]), int(head_w_acc), ptr(ws),
-                 ws.numel(), stream())
+                 dfeat.p, dfeat.ld, 1, ptr(pw), ptr(pb), int(head_w_acc or pacc), ptr(ws), ws.numel(), stream())
 
         gmap = {}
 
@@ -374,8 +369,9 @@ class Net2DFunction(torch.autograd.Function):
                         gmap[k] = dres
                 dx = like(x)
                 gmap[key(x)] = dx
-                bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training,
-                       gbuf(name + ".weight"), gbuf(name + ".bias"))
+                (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
+                bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training, dg, db,
+                       acc_params=pacc)
             elif kind == "conv":
                 _, name, op, x, out = rec
                 dout = gmap.pop(key(out))
@@ -383,13 +379,15 @@ class Net2DFunction(torch.autograd.Function):
                 acc = k in gmap
                 dx = gmap[k] if acc else like(x)
                 gmap[k] = dx
-                op.backward(x, dout, dx, gbuf(name + ".weight"), gbuf(name + ".bias") if op.b is not None else None, acc)
+                pg, pacc = sink.take(*([name + ".weight"] + ([name + ".bias"] if op.b is not None else [])))
+                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc)
             elif kind == "convT":
                 _, name, op, x, out = rec
                 dout = gmap.pop(key(out))
                 dx = like(x)
                 gmap[key(x)] = dx
-                op.backward(x, dout, dx, gbuf(name + ".weight"), gbuf(name + ".bias"))
+                (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
+                op.backward(x, dout, dx, dw, db, acc_params=pacc)
             elif kind == "join":
                 _, lvl, cj = rec
                 full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
@@ -418,7 +416,8 @@ class Net2DFunction(torch.autograd.Function):
                 dout = gmap.pop(key(c1))
                 dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
                 wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
-                call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(gbuf(pre + "conv1.weight")), 64, 1, 0, stream())
+                (dw,), pacc = sink.take(pre + "conv1.weight")
+                call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
             elif kind == "block_in":
                 pass
-        return (None, None, None, None, None, None) + tuple(grads[k] for k in spec.order)
+        return (None, None, None, None, None, None) + sink.returned()

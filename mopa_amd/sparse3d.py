@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import call, ptr, query, stream, workspace
+from ._lib import GradSink, call, ptr, query, stream, workspace
 
 BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
 BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
@@ -220,11 +220,11 @@ def bnrelu_fwd(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats
          BN_MOMENTUM, BN_EPS, LEAK, int(training), ptr(stats), ptr(ws), ws.numel(), stream())
 
 
-def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool):
+def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool, acc_params: bool = False):
     wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bnrelu_rows_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), LEAK, int(training),
-         ptr(dgamma), ptr(dbeta), 0, int(acc_dx), ptr(ws), ws.numel(), stream())
+         ptr(dgamma), ptr(dbeta), int(acc_params), int(acc_dx), ptr(ws), ws.numel(), stream())
 
 
 # --------------------------------------------------------------------------------------- the network
@@ -333,12 +333,7 @@ class SCNNetFunction(torch.autograd.Function):
         dev = geom.device
         N, m, C = geom.n_points, spec.m, spec.num_classes
         A0 = geom.num_active[0]
-        grads = {k: None for k in spec.order}
-
-        def gbuf(name):
-            g = torch.empty_like(P[name])
-            grads[name] = g
-            return g
+        sink = GradSink(P, spec.order)   # gradients go straight into attached .grad buffers (accumulating)
 
         def cont(t):
             return None if t is None else t.contiguous().float()
@@ -348,14 +343,14 @@ class SCNNetFunction(torch.autograd.Function):
         dy = new_view(A0, m, dev)
         wsb = query("mopa_output_layer_heads_bwd_workspace_bytes", N, m, C)
         ws = _ws(wsb, dev)
-        dw1 = gbuf("linear.weight") if dl1 is not None else None
-        db1 = gbuf("linear.bias") if dl1 is not None else None
-        dw2 = gbuf("linear2.weight") if dl2 is not None else None
-        db2 = gbuf("linear2.bias") if dl2 is not None else None
+        hnames = (["linear.weight", "linear.bias"] if dl1 is not None else []) + \
+                 (["linear2.weight", "linear2.bias"] if dl2 is not None else [])
+        hg, hacc = sink.take(*hnames)
+        hg = dict(zip(hnames, hg))
         call("mopa_output_layer_heads_bwd", ptr(dfeats), ptr(dl1), ptr(dl2), ptr(ctx.out_feats),
              ptr(P["linear.weight"]), ptr(P["linear2.weight"]) if spec.dual_head else None, ptr(geom.row_start),
-             ptr(geom.row_points), A0, N, m, C, dy.p, dy.ld, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), 0, ptr(ws),
-             ws.numel(), stream())
+             ptr(geom.row_points), A0, N, m, C, dy.p, dy.ld, ptr(hg.get("linear.weight")), ptr(hg.get("linear.bias")),
+             ptr(hg.get("linear2.weight")), ptr(hg.get("linear2.bias")), int(hacc), ptr(ws), ws.numel(), stream())
 
         # gradient w.r.t. activation buffers, keyed by (storage ptr, col, C)
         gmap = {}
@@ -375,12 +370,14 @@ class SCNNetFunction(torch.autograd.Function):
                 else:
                     dx, acc = new_view(x.rows, x.C, dev), False
                     gmap[k] = dx
-                bnrelu_bwd(dyv, x, dx, stats, ctx.training, gbuf(name + ".weight"), gbuf(name + ".bias"), acc)
+                (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
+                bnrelu_bwd(dyv, x, dx, stats, ctx.training, dg, db, acc, pacc)
             elif kind == "conv":
                 _, name, table, x, out, ckind = rec
                 dout = gmap.pop(key(out))
                 w = P[name + ".weight"]
-                spconv_bwd_weight(table, x, dout, gbuf(name + ".weight"))
+                (dw,), wacc = sink.take(name + ".weight")
+                spconv_bwd_weight(table, x, dout, dw, accumulate=wacc)
                 if name == spec.prefix + "1" and not ctx.feats_needs_grad:
                     continue
                 dx = new_view(x.rows, x.C, dev)
@@ -407,4 +404,4 @@ class SCNNetFunction(torch.autograd.Function):
             dfeat_in = torch.zeros(N, cin, dtype=torch.float32, device=dev)
             call("mopa_input_layer_bwd", dx0.p, dx0.ld, ptr(geom.point_row), ptr(geom.row_start), N, cin,
                  ptr(dfeat_in), stream())
-        return (None, None, None, dfeat_in) + tuple(grads[k] for k in spec.order)
+        return (None, None, None, dfeat_in) + sink.returned()

@@ -257,3 +257,38 @@ def test_single_head_ten_classes_and_empty_image_indices():
     for got, ref in ((o2["seg_logit"], r2["seg_logit"]), (o2["seg_logit_all"], r2["seg_logit_all"]), (o3["seg_logit"], r3["seg_logit"])):
         r = ref.detach().numpy()
         np.testing.assert_allclose(got.cpu().numpy(), r, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(r).max()))
+
+
+def test_direct_gradient_accumulation_matches_autograd_accumulation(monkeypatch):
+    """With FlatAdam the parameter gradients are accumulated by the kernels straight into the flat buffer (GradSink);
+    two backward passes (source + target half of an iteration) must give what autograd's own accumulation gives."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import seg_ce, xm_kl
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    from mopa_amd.optim import FlatAdam
+    batches = [synth.make_batch(2, H=64, W=96, first=0), synth.make_batch(2, H=64, W=96, first=7)]
+
+    def run(direct):
+        monkeypatch.setenv("MOPA_DIRECT_GRADS", "1" if direct else "0")
+        torch.manual_seed(0)
+        cfg = default_cfg()
+        m2, m3 = build_model_2d(cfg)[0].cuda().train(), build_model_3d(cfg)[0].cuda().train()
+        m2.net_2d.dropout.p = 0.0
+        opts = [FlatAdam(m.parameters()) for m in (m2, m3)]
+        for o in opts:
+            o.zero_grad()
+        for b in batches:
+            lab = b["seg_label"].cuda()
+            p2, p3 = m2(b), m3(b)
+            l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"]) + p2["seg_logit_all"].square().mean()
+            l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
+            (l2 + l3).backward()
+        torch.cuda.synchronize()
+        assert all(p.grad.data_ptr() >= o.grad.data_ptr() for o, m in zip(opts, (m2, m3)) for p in m.parameters())
+        return [o.grad.clone() for o in opts]
+
+    ga, gd = run(False), run(True)
+    for a, d in zip(ga, gd):
+        assert float(a.abs().max()) > 0
+        assert float((a - d).abs().max()) <= 2e-5 * float(a.abs().max())
