@@ -94,18 +94,20 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
   }
 }
 
-// y = act(x*scale + shift (+ res));  act: 0 = identity, 1 = leaky-ReLU(leak)
+// y = act(x*scale + shift (+ res));  act: 0 = identity, 1 = leaky-ReLU(leak).
+// Thread = (row lane rl, channel quad cq): the per-channel constants live in registers and the thread walks rows
+// rl, rl + RL*grid, ... -- no per-element constant loads, no 64-bit division (the grid-stride form was TA-bound at 2.7 TB/s).
 __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                         int ldy, int A, int C, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float leak,
                                                         const float* __restrict__ res, int ld_res, int act) {
-  const int CQ = C >> 2;
-  const int64_t total = (int64_t)A * CQ;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
+  const int CQ = C >> 2, RL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  if (rl >= RL) return;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+  for (int row = blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
     const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
     if (res) {
@@ -118,6 +120,15 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
     }
     *reinterpret_cast<float4*>(y + (int64_t)row * ldy + cq * 4) = o;
   }
+}
+
+// Blocks for the (rl, cq) row-walking elementwise kernels: RL rows per block step, ~8 blocks per CU, at least 4 rows per thread.
+static inline int bn_apply_grid(int64_t num_rows, int C) {
+  const int RL = 256 / (C >> 2);
+  int64_t g = cdiv64(num_rows, (int64_t)RL * 4);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
 }
 
 MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
@@ -143,7 +154,7 @@ MOPA_API int mopa_bn_act_fwd(const float* x, int32_t ldx, float* y, int32_t ldy,
   }
   k_bn_finalize<<<(C + 3) / 4, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
                                    eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
-  k_bn_relu_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
+  k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
                                                                                   stats + C, leak, res, ld_res, act);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
@@ -241,10 +252,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ stats, const float* __restrict__ coef,
                                                        float leak, int training, int acc_dx, const float* __restrict__ ymask,
                                                        int ld_ym, int act, float* __restrict__ dres, int ld_dres, int acc_dres) {
-  const int CQ = C >> 2;
-  const int64_t total = (int64_t)A * CQ;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / CQ), cq = (int)(i - (int64_t)row * CQ);
+  // thread = (row lane, channel quad), constants in registers (see k_bn_relu_apply)
+  const int CQ = C >> 2, RL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  if (rl >= RL) return;
+  float sc[4], sh[4], mean[4], inv[4], c0[4], c1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cq * 4 + j;
+    sc[j] = stats[c]; sh[j] = stats[C + c]; mean[j] = stats[2 * C + c]; inv[j] = stats[3 * C + c];
+    c0[j] = coef[c]; c1[j] = coef[C + c];
+  }
+  for (int row = blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
     const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
     const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
     float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,15 +272,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     float o[4], dzv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = cq * 4 + j;
-      const float sc = stats[c], sh = stats[C + c];
-      const float dz = bn_dz(gs[j], xs[j], sc, sh, leak, act, ymask ? ys : nullptr, j);
+      const float dz = bn_dz(gs[j], xs[j], sc[j], sh[j], leak, act, ymask ? ys : nullptr, j);
       dzv[j] = dz;
       if (training) {
-        const float xhat = (xs[j] - stats[2 * C + c]) * stats[3 * C + c];
-        o[j] = sc * (dz - coef[c] - xhat * coef[C + c]);
+        const float xhat = (xs[j] - mean[j]) * inv[j];
+        o[j] = sc[j] * (dz - c0[j] - xhat * c1[j]);
       } else {
-        o[j] = sc * dz;
+        o[j] = sc[j] * dz;
       }
     }
     float4* dp = reinterpret_cast<float4*>(dx + (int64_t)row * ld_dx + cq * 4);
@@ -304,7 +321,7 @@ MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int
   k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask,
                                                                           ld_ym, act, bn_rows_per_block(num_rows), partial);
   k_bn_bwd_finalize<<<(C + 3) / 4, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
-  k_bn_bwd_apply<<<stream_grid((int64_t)num_rows * (C >> 2), 256), 256, 0, st>>>(
+  k_bn_bwd_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(
       dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
       ld_dres, accumulate_dres);
   MOPA_CHECK_LAUNCH();
