@@ -237,14 +237,27 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[n][i][j] = 0.f;
   float4 ra[NTAP], rb;
+  // this thread's pixel (b, oy, ox) of the NEXT tile to load: decomposed once, then advanced by WBK pixels per tile
+  int pb, poy, pox;
+  {
+    const int m = mbeg + sk;
+    pb = m / (g.OHl * g.OWl);
+    const int r = m - pb * g.OHl * g.OWl;
+    poy = r / g.OWl;
+    pox = r - poy * g.OWl;
+  }
   auto load_tile = [&](int mb) {
     const int m = mb + sk;
     rb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int n = 0; n < NTAP; ++n) ra[n] = rb;
+    const int b = pb, oy = poy, ox = pox;
+    pox += WBK;
+    while (pox >= g.OWl) {
+      pox -= g.OWl;
+      if (++poy == g.OHl) { poy = 0; ++pb; }
+    }
     if (m < mend) {
-      const int b = m / (g.OHl * g.OWl), r = m - b * g.OHl * g.OWl;
-      const int oy = r / g.OWl, ox = r - oy * g.OWl;
       const int iy = oy * g.IS + g.IY0 + tyy * g.IDY;
 #pragma unroll
       for (int n = 0; n < NTAP; ++n) {
@@ -271,18 +284,26 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
   for (int mb = mbeg; mb < mend; mb += WBK) {
     const bool more = mb + WBK < mend;
     if (more) load_tile(mb + WBK);
-#pragma unroll 4
+    // operands of pixel k+1 are read from LDS (into a second register set) before the FMAs of pixel k: the compiler's own
+    // schedule reused one register quad for every read and waited for each of them (lgkmcnt(0) per ds_read)
+    float4 bq[2], aq[2][NTAP];
+#define WG_READ(SET, K)                                                                        \
+  {                                                                                            \
+    bq[SET] = *reinterpret_cast<const float4*>(&Bs[buf][K][tx * 4]);                           \
+    _Pragma("unroll") for (int n = 0; n < NTAP; ++n) {                                         \
+      if (MT == 4) aq[SET][n] = *reinterpret_cast<const float4*>(&As[buf][n][K][ty * 4]);      \
+      else aq[SET][n].x = As[buf][n][K][ty];                                                   \
+    }                                                                                          \
+  }
+    WG_READ(0, 0);
+#pragma unroll
     for (int k = 0; k < WBK; ++k) {
-      const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][k][tx * 4]);
+      const int cur = k & 1;
+      if (k + 1 < WBK) WG_READ(cur ^ 1, k + 1);
+      const float4 b4 = bq[cur];
 #pragma unroll
       for (int n = 0; n < NTAP; ++n) {
-        float a[MT];
-        if (MT == 4) {
-          const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][n][k][ty * 4]);
-          a[0] = a4.x; a[1 % MT] = a4.y; a[2 % MT] = a4.z; a[3 % MT] = a4.w;
-        } else {
-          a[0] = As[buf][n][k][ty];
-        }
+        const float a[4] = {aq[cur][n].x, aq[cur][n].y, aq[cur][n].z, aq[cur][n].w};
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           acc[n][i][0] = fmaf(a[i], b4.x, acc[n][i][0]); acc[n][i][1] = fmaf(a[i], b4.y, acc[n][i][1]);
@@ -290,6 +311,7 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
         }
       }
     }
+#undef WG_READ
     if (more) {
       store_tile(buf ^ 1);
       __syncthreads();
