@@ -352,6 +352,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -414,7 +415,7 @@ def main():
             "roofline": roof,
             "roofline_sparse_conv": sp,
         }
-        print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s", file=sys.stderr, flush=True)
+        print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s (host enqueue {t_enqueued:.3f}s)", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only
             t_cpu = time.perf_counter()
             line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d) if joint else cpu_baseline_3d(model3d)

@@ -113,18 +113,34 @@ def ptr(t, col: int = 0):
     return t.data_ptr() + col * t.element_size()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (fast path: no Stream object, ~0.3 us)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
 def call(name: str, *args):
-    rc = getattr(load(), name)(*args)
+    rc = getattr(_lib or load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc}")
 
 
+_query_cache = {}
+
+
 def query(name: str, *args) -> int:
-    return int(getattr(load(), name)(*args))
+    """Pure size / plan queries (workspace bytes, kernel plans): memoised, the answers depend on the arguments only."""
+    if "p" in SIGNATURES[name][1]:   # takes a pointer (e.g. a geometry block): the address says nothing about the content
+        return int(getattr(_lib or load(), name)(*args))
+    key = (name, args)
+    v = _query_cache.get(key)
+    if v is None:
+        v = _query_cache[key] = int(getattr(_lib or load(), name)(*args))
+    return v
 
 
 class _Workspace:
@@ -135,7 +151,7 @@ class _Workspace:
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        key = (device.type, device.index, stream() if device.type == "cuda" else 0)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
