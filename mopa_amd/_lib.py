@@ -42,6 +42,11 @@ SIGNATURES = {
     "mopa_spconv_pack_weight": ("i", "piiiiipp"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
+    # ---- pseudo-label update (pseudo.hip)
+    "mopa_pseudo_fuse": ("i", "ppiippp"),
+    "mopa_refine_pseudo_labels_workspace_bytes": ("z", "i"),
+    "mopa_refine_pseudo_labels": ("i", "ppiilppzp"),
+    "mopa_ema_update": ("i", "pplfp"),
     # ---- row ops (rows.hip)
     "mopa_bnrelu_rows_workspace_bytes": ("z", "ii"),
     "mopa_bnrelu_rows_fwd": ("i", "pipiiippppfffippzp"),

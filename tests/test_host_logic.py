@@ -101,3 +101,16 @@ def test_scn_checkpoint_weight_layouts_load():
     m2.load_state_dict(sd4)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_oracle_pseudo_labels_pinned_by_golden(golden_dir):
+    """oracle/pseudo.py against the reference's own outputs (fixture G5: refine_pseudo_labels, prob_2_entropy)."""
+    import os
+    from oracle import pseudo
+    g = dict(np.load(os.path.join(golden_dir, "g5_misc.npz")))
+    prob = torch.softmax(torch.from_numpy(g["logit"]), 1)
+    maxp, lab = prob.max(1)
+    assert np.array_equal(pseudo.refine_pseudo_labels(maxp, lab).numpy(), g["refined"])
+    np.testing.assert_allclose(pseudo.prob_2_entropy(prob).numpy(), g["entropy"], rtol=1e-6, atol=1e-7)
+    w = pseudo.fuse_probs(torch.from_numpy(g["logit"]), torch.from_numpy(g["logit"]))
+    np.testing.assert_allclose(w.numpy(), prob.numpy(), rtol=1e-6)       # fusing a modality with itself is the identity
