@@ -12,6 +12,10 @@ Pinning status
   voxeliser (``oracle.voxelize``): PINNED against outputs of the imported
   reference (``/root/reference``, run under sys.modules stubs in the build
   container by ``oracle/gen_golden.py``); the vectors live in ``tests/golden``.
+* Pseudo-label update (``oracle.pseudo``): ``refine_pseudo_labels``
+  and ``prob_2_entropy`` PINNED by fixture G5; the EMA rule restates the
+  published update of the un-pinned pip package ``torch_ema`` (unpinned for
+  that one function, anchored on the reference's call sites).
 * 3D branch (``oracle.scn3d``): **parity unpinned**.  The arithmetic lives in
   the third-party package ``sparseconvnet`` (facebookresearch/SparseConvNet,
   installed un-pinned from git HEAD by the reference's ``install.sh:1``), whose
