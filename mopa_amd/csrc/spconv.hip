@@ -707,8 +707,12 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
   const unsigned ld4 = (unsigned)ld_in >> 2;
   float* acc = reinterpret_cast<float*>(smem + wv * ACCB);
   for (int i = lane; i < 65 * LD / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4 + lane * NTW * 16;
-  const float4* __restrict__ a_lane = reinterpret_cast<const float4*>(in) + q;
+  // uniform bases (SGPR) + 32-bit per-lane byte offsets: the loads use the saddr + voffset form, no 64-bit VALU adds.
+  // Byte offsets of input rows stay below 2^32 (checked by the launcher: 8 * num_out * ld_in * 4 < 2^32).
+  const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4;
+  const unsigned b_off = (unsigned)(lane * NTW * 16);
+  const char* __restrict__ in_b = reinterpret_cast<const char*>(in);
+  const unsigned a_off = (unsigned)(q * 16);
   char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
 
   float4 A[D][NKU];
@@ -746,11 +750,12 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
 #define T4_ISSUE(S)                                                                                        \
   {                                                                                                        \
     const char* wp_ = wcg + __builtin_amdgcn_readfirstlane(wo_n);                                          \
+    const unsigned arow_ = io_n * 16u + a_off;                                                             \
     _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                                      \
       const int kc_ = PART ? min(iku * NKU + j, nkc - 1) : iku * NKU + j;                                  \
-      A[S][j] = a_lane[(uint64_t)io_n + (unsigned)(kc_ * 4)];                                              \
+      A[S][j] = *reinterpret_cast<const float4*>(in_b + (arow_ + (unsigned)(kc_ * 64)));                   \
       _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                   \
-        B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + v_ * 16);       \
+        B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + (b_off + v_ * 16)); \
     }                                                                                                      \
     if (++iku == NU) { iku = 0; ig = ig + NWV < ng ? ig + NWV : gdead; }                                       \
     io_n = m_in[ig * 16 + r];                                                                              \
@@ -950,6 +955,8 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
     int pntw;
     const int path = packed_plan(K, num_out, cin, cout, &pntw);
     if (!aligned || path == SP_BLK) return MOPA_ERR_ARG;
+    // the pipelined kernels address input rows with 32-bit byte offsets (an input has at most 8x the output's rows)
+    if ((int64_t)num_out * 8 * ld_in * 4 >= (1ll << 32)) return MOPA_ERR_ARG;
     const int nkc = cin / 16;
     if (path == SP_PIPE && cout == 16 && nkc == 2)   // 32 -> 16: one wave per tile with whole-Cin units (40 vs 42 us)
       return launch_t4<1, 2, 2, 1>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st);

@@ -168,6 +168,8 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
     cin, cout = x.C, out.C
     assert out.rows == A_out and w.shape == ((K, cout, cin) if w_transposed else (K, cin, cout)), (nbr.shape, cin, cout, w.shape)
     ntw = query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout) if rb is not None else 0
+    if A_out * 8 * x.ld * 4 >= 1 << 32:   # the pipelined kernels use 32-bit byte offsets into the input rows
+        ntw = 0
     packed = ntw > 0
     if packed:   # column groups of ntw 16-column tiles, MFMA-operand order (mopa_spconv_pack_weight)
         wk = torch.empty(K * cin * cout, dtype=w.dtype, device=w.device)
