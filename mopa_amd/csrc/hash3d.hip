@@ -159,8 +159,38 @@ __global__ __launch_bounds__(256) void k_scan_final(const int* __restrict__ in, 
   }
 }
 
+// Short inputs (group counts per tile, the deep levels): one block walks the array 1024 items at a time -- one launch, not three.
+__global__ __launch_bounds__(256) void k_scan_small(const int* __restrict__ in, int n_host, const int* n_dev, int* __restrict__ out,
+                                                     int* __restrict__ total) {
+  const int n = resolve_n(n_host, n_dev);
+  __shared__ int l[8];
+  int carry = 0;
+  for (int b0 = 0; b0 < n; b0 += 1024) {
+    const int base = b0 + threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = (base + k < n) ? in[base + k] : 0;
+      s += v[k];
+    }
+    int tot;
+    int ex = carry + block_exclusive_scan_256(s, l, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (base + k < n) out[base + k] = ex;
+      ex += v[k];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
 static int scan_exclusive(const int* in, int* out, int n_cap, const int* n_dev, int* sums, int* total,
                           hipStream_t st) {
+  if (n_cap <= 8192) {
+    k_scan_small<<<1, 256, 0, st>>>(in, n_cap, n_dev, out, total);
+    return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+  }
   int nb = (int)cdiv64(n_cap > 0 ? n_cap : 1, SCAN_ITEMS);
   k_scan_block_sums<<<nb, 256, 0, st>>>(in, n_cap, n_dev, sums);
   k_scan_sums<<<1, 256, 0, st>>>(sums, nb, n_cap, n_dev, total);
