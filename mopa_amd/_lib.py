@@ -35,6 +35,8 @@ SIGNATURES = {
     "mopa_spconv_fwd": ("i", "piipiipiipip"),
     "mopa_rulebook_groups_count": ("i", "piipp"),
     "mopa_rulebook_groups_fill": ("i", "piippppp"),
+    "mopa_rulebook_groups_count_batched": ("i", "piipp"),
+    "mopa_rulebook_groups_fill_batched": ("i", "piippppp"),
     "mopa_spconv_grouped_workspace_bytes": ("z", "iii"),
     "mopa_spconv_fwd_grouped": ("i", "ppppiipiipiipipzp"),
     "mopa_spconv_transpose_weight": ("i", "piiipp"),

@@ -15,6 +15,7 @@
 // JoinTable buffer); weights [K][Cin][Cout] fp32.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -290,6 +291,70 @@ __global__ void k_pack_w(const float* __restrict__ w, int K, int cin_w, int cout
     const int k = kc * 16 + (lane >> 4) * 4 + s2, c = cg * cp + (lane & 15) * ntw + t;
     wp[i] = transpose ? w[((int64_t)o * cin_w + c) * cout_w + k] : w[((int64_t)o * cin_w + k) * cout_w + c];
   }
+}
+
+// All rule tables of one geometry in ONE launch each (20 tables for a 7-level UNet: 27-offset tables of every level and
+// the down / up tables between levels): desc[t] = {table pointer, K, rows, first global tile} (int64 x 4, a HOST array that
+// travels as a kernel argument), tiles and groups are numbered globally, so every table's grp_start is a slice of one scan and its group arrays are
+// the shared ones.  Saves ~55 launches per geometry build (the 3D-only step is host-bound).
+#define RB_MAX_TABLES 32
+struct RbDescs { int64_t v[RB_MAX_TABLES * 4]; };
+__device__ __forceinline__ int rb_find_table(const RbDescs& d, int ntables, int tile) {
+  int t = 0;
+  for (int k = 1; k < ntables; ++k)
+    if (tile >= (int)d.v[k * 4 + 3]) t = k;
+  return t;
+}
+__global__ __launch_bounds__(64) void k_rb_count_batched(const RbDescs desc, int ntables, int* __restrict__ tile_groups) {
+  const int t = rb_find_table(desc, ntables, blockIdx.x);
+  const int* __restrict__ nbr = reinterpret_cast<const int*>(desc.v[t * 4]);
+  const int K = (int)desc.v[t * 4 + 1], A_out = (int)desc.v[t * 4 + 2];
+  const int row = (blockIdx.x - (int)desc.v[t * 4 + 3]) * 64 + threadIdx.x;
+  int ng = 0;
+  for (int o = 0; o < K; ++o) {
+    const int nb = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
+    ng += (__popcll(__ballot(nb >= 0)) + 15) >> 4;
+  }
+  if (threadIdx.x == 0) tile_groups[blockIdx.x] = ng;
+}
+__global__ __launch_bounds__(64) void k_rb_fill_batched(const RbDescs desc, int ntables, const int* __restrict__ grp_start,
+                                                         int* __restrict__ grp_o, int* __restrict__ grp_in, int* __restrict__ grp_out) {
+  const int t = rb_find_table(desc, ntables, blockIdx.x);
+  const int* __restrict__ nbr = reinterpret_cast<const int*>(desc.v[t * 4]);
+  const int K = (int)desc.v[t * 4 + 1], A_out = (int)desc.v[t * 4 + 2];
+  const int lane = threadIdx.x, row = (blockIdx.x - (int)desc.v[t * 4 + 3]) * 64 + lane;
+  int g = grp_start[blockIdx.x];
+  for (int o = 0; o < K; ++o) {
+    const int nb = (row < A_out) ? nbr[(int64_t)o * A_out + row] : -1;
+    const unsigned long long bal = __ballot(nb >= 0);
+    const int n = __popcll(bal);
+    if (n == 0) continue;
+    const int ng = (n + 15) >> 4;
+    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+    if (nb >= 0) { grp_in[(int64_t)g * 16 + pos] = nb; grp_out[(int64_t)g * 16 + pos] = lane; }
+    if (lane < ng * 16 - n) { grp_in[(int64_t)g * 16 + n + lane] = -1; grp_out[(int64_t)g * 16 + n + lane] = -1; }
+    if (lane < ng) grp_o[g + lane] = o;
+    g += ng;
+  }
+}
+MOPA_API int mopa_rulebook_groups_count_batched(const int64_t* desc_host, int32_t ntables, int32_t total_tiles, int32_t* tile_groups,
+                                                void* stream) {
+  if (ntables <= 0 || ntables > RB_MAX_TABLES || total_tiles <= 0) return MOPA_ERR_ARG;
+  RbDescs desc;
+  memcpy(desc.v, desc_host, (size_t)ntables * 4 * sizeof(int64_t));
+  k_rb_count_batched<<<total_tiles, 64, 0, (hipStream_t)stream>>>(desc, ntables, tile_groups);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+// grp_start: exclusive scan of tile_groups over ALL tiles (global group numbers); grp_o / grp_in / grp_out: shared arrays.
+MOPA_API int mopa_rulebook_groups_fill_batched(const int64_t* desc_host, int32_t ntables, int32_t total_tiles, const int32_t* grp_start,
+                                               int32_t* grp_o, int32_t* grp_in, int32_t* grp_out, void* stream) {
+  if (ntables <= 0 || ntables > RB_MAX_TABLES || total_tiles <= 0) return MOPA_ERR_ARG;
+  RbDescs desc;
+  memcpy(desc.v, desc_host, (size_t)ntables * 4 * sizeof(int64_t));
+  k_rb_fill_batched<<<total_tiles, 64, 0, (hipStream_t)stream>>>(desc, ntables, grp_start, grp_o, grp_in, grp_out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
 }
 
 // Which kernel mopa_spconv_fwd_grouped runs for a shape (cin / cout are those of the convolution to run, i.e. swapped

@@ -92,28 +92,30 @@ class Geometry3D:
             call("mopa_rulebook_updown", ptr(keys[l]), ptr(item_row[l + 1]), A[l], A[l + 1], ptr(ch), ptr(up), st)
             self.ch.append(ch)
             self.up.append(up)
-        # grouped rulebooks (MFMA-ready 16-rule groups per 64-row tile) for every table: count -> scan -> ONE more
-        # host sync for the group totals -> fill.  Built once per geometry, used by every layer's fwd and bwd-data.
+        # grouped rulebooks (MFMA-ready 16-rule groups per 64-row tile) for ALL tables at once: tiles and groups are numbered
+        # globally -- one count launch, one scan, ONE more host sync for the group total, one fill launch.  Built once per
+        # geometry, used by every layer's fwd and bwd-data; a table's rulebook = its slice of the scan + the shared arrays.
         self._rb = {}
         tables = list(self.nbr27) + list(self.ch) + list(self.up)
-        starts = []
+        tile0, desc = [0], []
         for t in tables:
             K, Ao = t.shape
-            ntile = (Ao + 63) // 64
-            tg = torch.empty(ntile, **i32)
-            gs = torch.empty(ntile + 1, **i32)
-            call("mopa_rulebook_groups_count", ptr(t), K, Ao, ptr(tg), st)
-            ws = _ws(query("mopa_scan_workspace_bytes", ntile), device)
-            call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
-            starts.append(gs)
-        totals = torch.stack([gs[-1] for gs in starts]).cpu().tolist()  # second (and last) host sync
-        for t, gs, ng in zip(tables, starts, totals):
-            K, Ao = t.shape
-            go = torch.empty(max(ng, 1), **i32)
-            gi = torch.empty(max(ng, 1) * 16, **i32)
-            gout = torch.empty(max(ng, 1) * 16, **i32)
-            call("mopa_rulebook_groups_fill", ptr(t), K, Ao, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
-            self._rb[t.data_ptr()] = (gs, go, gi, gout)
+            desc += [t.data_ptr(), K, Ao, tile0[-1]]
+            tile0.append(tile0[-1] + (Ao + 63) // 64)
+        ntile = tile0[-1]
+        desc_h = torch.tensor(desc, dtype=torch.int64)   # host array: travels to the kernels as an argument
+        tg = torch.empty(ntile, **i32)
+        gs = torch.empty(ntile + 1, **i32)
+        call("mopa_rulebook_groups_count_batched", desc_h.data_ptr(), len(tables), ntile, ptr(tg), st)
+        ws = _ws(query("mopa_scan_workspace_bytes", ntile), device)
+        call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
+        ng = max(int(gs[-1].item()), 1)  # second (and last) host sync
+        go = torch.empty(ng, **i32)
+        gi = torch.empty(ng * 16, **i32)
+        gout = torch.empty(ng * 16, **i32)
+        call("mopa_rulebook_groups_fill_batched", desc_h.data_ptr(), len(tables), ntile, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
+        for i, t in enumerate(tables):
+            self._rb[t.data_ptr()] = (gs[tile0[i]:tile0[i + 1] + 1], go, gi, gout)
         self.row_start = torch.empty(A[0] + 1, **i32)
         self.row_points = torch.empty(N, **i32)
         wsb = query("mopa_points_csr_workspace_bytes", A[0])

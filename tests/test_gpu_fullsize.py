@@ -42,11 +42,11 @@ def test_geometry_invariants_at_120k_points_per_scan():
             i = torch.nonzero(nbr[o] >= 0).squeeze(1)
             assert bool((nbr[26 - o][nbr[o][i]] == i).all())
         # grouped rulebook == dense table as a multiset of (offset, in, out) rules
-        gs, go, gi, gout = g.rulebook(g.nbr27[l])
-        ngrp = int(gs[-1])
-        tile = torch.bucketize(torch.arange(ngrp, device="cuda"), gs[1:].long(), right=True)
-        o_e = go[:ngrp].long().repeat_interleave(16)
-        in_e, out_e = gi[:ngrp * 16].long(), gout[:ngrp * 16].long()
+        gs, go, gi, gout = g.rulebook(g.nbr27[l])       # gs: this table's slice of the global group numbering
+        g0, g1 = int(gs[0]), int(gs[-1])
+        tile = torch.bucketize(torch.arange(g0, g1, device="cuda"), gs[1:].long(), right=True)
+        o_e = go[g0:g1].long().repeat_interleave(16)
+        in_e, out_e = gi[g0 * 16:g1 * 16].long(), gout[g0 * 16:g1 * 16].long()
         ok = in_e >= 0
         rule = (o_e[ok] * A + tile.repeat_interleave(16)[ok] * 64 + out_e[ok]) * (A + 1) + in_e[ok]
         oo, ii = torch.nonzero(nbr >= 0, as_tuple=True)
