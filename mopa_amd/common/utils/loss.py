@@ -43,7 +43,9 @@ class _SoftmaxKL(torch.autograd.Function):
 
 def xm_kl(logit_p: torch.Tensor, logit_q: torch.Tensor) -> torch.Tensor:
     """F.kl_div(log_softmax(p), softmax(q.detach()), 'none').sum(1).mean()  (train_xmuda_mopa.py:389-398)."""
-    return _SoftmaxKL.apply(logit_p, logit_q)
+    # the target is detached BEFORE it enters the graph: as an input of the autograd node it would still schedule the other
+    # network's backward (with zero gradients) -- a whole redundant backward pass per loss
+    return _SoftmaxKL.apply(logit_p, logit_q.detach())
 
 
 class _WeightedCE(torch.autograd.Function):

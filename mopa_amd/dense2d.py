@@ -185,6 +185,7 @@ class Net2DFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, img, point_pix, training, drop_p, drop_seed, *flat):
+        ctx.set_materialize_grads(False)   # an output that no loss uses arrives as None in backward, not as a zero tensor
         dev = img.device
         P = dict(zip(spec.order, flat))
         pre = "net_2d."
@@ -302,6 +303,8 @@ class Net2DFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeats, dl1, dl2, dpred):
+        if dfeats is None and dl1 is None and dl2 is None and dpred is None:   # nothing flows back into this network
+            return (None,) * (6 + len(ctx.spec.order))
         spec, P, tape, J = ctx.spec, ctx.P, ctx.tape, ctx.J
         B, H, W, Hp, Wp, N = ctx.dims
         feat = ctx.feat

@@ -263,6 +263,7 @@ class SCNNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, geom: Geometry3D, training: bool, feats, *flat):
+        ctx.set_materialize_grads(False)   # an output that no loss uses arrives as None in backward, not as a zero tensor
         dev = geom.device
         P = dict(zip(spec.order, flat))
         A, m, L, reps = geom.num_active, spec.m, spec.num_planes, spec.block_reps
@@ -333,6 +334,8 @@ class SCNNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeats, dl1, dl2):
+        if dfeats is None and dl1 is None and dl2 is None:   # nothing flows back (e.g. only used as a detached KL target)
+            return (None,) * (4 + len(ctx.spec.order))
         spec, geom, P, tape = ctx.spec, ctx.geom, ctx.P, ctx.tape
         dev = geom.device
         N, m, C = geom.n_points, spec.m, spec.num_classes
