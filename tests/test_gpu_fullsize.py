@@ -292,3 +292,25 @@ def test_direct_gradient_accumulation_matches_autograd_accumulation(monkeypatch)
     for a, d in zip(ga, gd):
         assert float(a.abs().max()) > 0
         assert float((a - d).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_cross_modal_kl_does_not_run_the_other_networks_backward():
+    """xm_kl detaches its target (train_xmuda_mopa.py:389-398): the target's network must not be traversed at all --
+    no gradient tensors appear on it -- and a backward in which no output of a network is used returns immediately."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import xm_kl
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    b = synth.make_batch(2, H=64, W=96)
+    torch.manual_seed(0)
+    cfg = default_cfg()
+    m2, m3 = build_model_2d(cfg)[0].cuda().train(), build_model_3d(cfg)[0].cuda().train()
+    p2, p3 = m2(b), m3(b)
+    xm_kl(p2["seg_logit2"], p3["seg_logit"]).backward()
+    assert all(p.grad is None for p in m3.parameters())                      # 3D network untouched
+    used = [n for n, p in m2.named_parameters() if p.grad is not None]
+    assert "linear2.weight" in used and "net_2d.conv1.weight" in used and "linear.weight" not in used
+    # an unused network output reaches backward as None, not as a materialised zero tensor
+    p3b = m3(b)
+    (p3b["seg_logit"].sum() * 0.0 + xm_kl(p2["seg_logit2"].detach(), p3b["seg_logit2"].detach())).backward()
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for n, p in m3.named_parameters() if n.startswith("linear2"))
