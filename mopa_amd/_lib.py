@@ -138,6 +138,10 @@ def call(name: str, *args):
 
 _query_cache = {}
 
+# Bumped by every in-place weight update that autograd's version counters cannot see (FlatAdam.step runs a HIP kernel on the
+# flat buffer): per-step caches of re-laid-out weights key on (this epoch, tensor._version).
+WEIGHTS_EPOCH = [0]
+
 
 def query(name: str, *args) -> int:
     """Pure size / plan queries (workspace bytes, kernel plans): memoised, the answers depend on the arguments only."""

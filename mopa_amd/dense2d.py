@@ -64,6 +64,30 @@ def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
     call("mopa_conv2d_relayout_weight", ptr(src), ptr(dst), O, I, KH, KW, mode, int(inverse), int(accumulate), stream())
 
 
+_relayout_cache = {}
+
+
+def relayout_cached(w, shape, O, I, KH, KW, mode):
+    """Forward / backward-data layout of a conv weight, re-used until the weight changes (an iteration runs the network on
+    the source and on the target batch with the same weights).  An entry belongs to ONE live tensor object (weak reference:
+    the allocator hands a freed weight's address to the next tensor), one weight version (autograd's counter + the epoch
+    that FlatAdam / FlatEMA bump for their raw in-place updates) and one stream (the copy is only ordered with work of the
+    stream that made it)."""
+    import weakref
+    from ._lib import WEIGHTS_EPOCH
+    key = (id(w), mode, stream())
+    tag = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
+    hit = _relayout_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    t = torch.empty(*shape, dtype=torch.float32, device=w.device)
+    relayout(w, t, O, I, KH, KW, mode)
+    if len(_relayout_cache) > 4096:   # temporaries (tests, one-off calls) must not pile up
+        _relayout_cache.clear()
+    _relayout_cache[key] = (tag, t, weakref.ref(w))
+    return t
+
+
 # ------------------------------------------------------------------------------------------------ conv wrappers
 class ConvOp:
     """Conv2d(k, stride s, padding p) in NHWC through the implicit-GEMM kernels (fwd, dgrad, wgrad)."""
@@ -80,8 +104,7 @@ class ConvOp:
                      IX0=-self.p, TH=self.k, TW=self.k, KWF=self.k, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
 
     def forward(self, x: Img, out: Img):
-        wl = torch.empty(self.k, self.k, self.I, self.O, dtype=torch.float32, device=self.w.device)
-        relayout(self.w, wl, self.O, self.I, self.k, self.k, 0)
+        wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
     def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False):
@@ -95,8 +118,7 @@ class ConvOp:
             colsum(dout, db, accumulate=acc_params)
         if dx is None:
             return
-        wt = torch.empty(k, k, self.O, self.I, dtype=torch.float32, device=dev)
-        relayout(self.w, wt, self.O, self.I, k, k, 1)
+        wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:
             g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IY0=p, IX0=p, IDY=-1, IDX=-1,
                       TH=k, TW=k, KWF=k, Cin=self.O, Cout=self.I, ld_in=dout.ld, ld_out=dx.ld)
@@ -131,8 +153,7 @@ class ConvTOp:
                      KH0=ky, KW0=kx, KWF=2, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
 
     def forward(self, x: Img, out: Img):
-        wl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=self.w.device)
-        relayout(self.w, wl, self.O, self.I, 2, 2, 2)
+        wl = relayout_cached(self.w, (2, 2, self.I, self.O), self.O, self.I, 2, 2, 2)
         for ky in range(2):
             for kx in range(2):
                 igemm(x.p, wl, self.b, out.p, self._geom(x, out, ky, kx))
@@ -147,8 +168,7 @@ class ConvTOp:
                 wgrad(x.p, dout.p, ptr(dwl, (ky * 2 + kx) * self.I * self.O), g, dev)
         relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True, accumulate=acc_params)
         colsum(dout, db, accumulate=acc_params)
-        wt = torch.empty(2, 2, self.O, self.I, dtype=torch.float32, device=dev)
-        relayout(self.w, wt, self.O, self.I, 2, 2, 3)
+        wt = relayout_cached(self.w, (2, 2, self.O, self.I), self.O, self.I, 2, 2, 3)
         g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IS=2, TH=2, TW=2, KWF=2,
                   Cin=self.O, Cout=self.I, ld_in=dout.ld, ld_out=dx.ld)
         igemm(dout.p, wt, None, dx.p, g, False)

@@ -12,7 +12,7 @@ import math
 import torch
 import torch.distributed as dist
 
-from ._lib import call, ptr, stream
+from ._lib import WEIGHTS_EPOCH, call, ptr, stream
 
 
 class FlatAdam:
@@ -55,3 +55,4 @@ class FlatAdam:
         call("mopa_adam_flat", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              self.lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t),
              grad_scale, stream())
+        WEIGHTS_EPOCH[0] += 1   # cached weight re-layouts (dense2d) are stale now

@@ -12,7 +12,7 @@ import contextlib
 
 import torch
 
-from ._lib import call, ptr, query, stream, workspace
+from ._lib import WEIGHTS_EPOCH, call, ptr, query, stream, workspace
 
 
 def _f32(t):
@@ -78,7 +78,9 @@ class FlatEMA:
         """Run the body with the averaged weights in place (the parameters are views of the flat buffer)."""
         saved = self.opt.flat.clone()
         self.opt.flat.copy_(self.shadow)
+        WEIGHTS_EPOCH[0] += 1   # the parameters are views of the flat buffer: their own version counters did not move
         try:
             yield
         finally:
             self.opt.flat.copy_(saved)
+            WEIGHTS_EPOCH[0] += 1

@@ -223,3 +223,36 @@ def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
     assert torch.equal(e1, e2)
     with pytest.raises(IndexError):
         model({"img": img, "img_indices": [idx[0], np.array([[H, 0]])]})
+
+
+def test_cached_weight_layouts_follow_every_kind_of_weight_update():
+    """Forward / backward-data weight layouts are cached per weight version: an optimizer step through the flat buffer
+    (HIP kernel, invisible to autograd's version counters), a tracked in-place update and an EMA swap must all be seen."""
+    from mopa_amd import synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    from mopa_amd.optim import FlatAdam
+    from mopa_amd.pseudo import FlatEMA
+    b = synth.make_batch(1, H=32, W=48)
+    torch.manual_seed(0)
+    m = build_model_2d(default_cfg())[0].cuda().eval()
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    ema = FlatEMA(opt, decay=0.5)
+
+    def logits():
+        with torch.no_grad():
+            return m(b)["seg_logit"].clone()
+
+    y0 = logits()
+    assert torch.equal(logits(), y0)                       # cached layouts reproduce the same bits
+    opt.grad.copy_(torch.randn_like(opt.grad))
+    opt.step()                                             # flat-buffer Adam step
+    y1 = logits()
+    assert not torch.equal(y1, y0)
+    with torch.no_grad():
+        m.net_2d.layer1[0].conv1.weight.mul_(1.5)          # tracked in-place update of a cached layer
+    y2 = logits()
+    assert not torch.equal(y2, y1)
+    with ema.average_parameters():                         # shadow = the initial weights
+        assert torch.allclose(logits(), y0, rtol=1e-5, atol=1e-6)
+    assert torch.equal(logits(), y2)
