@@ -174,11 +174,35 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
         ntw = 0
     packed = ntw > 0
     if packed:   # column groups of ntw 16-column tiles, MFMA-operand order (mopa_spconv_pack_weight)
-        wk = torch.empty(K * cin * cout, dtype=w.dtype, device=w.device)
-        call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], int(w_transposed), ntw, ptr(wk), stream())
+        wk = _weight_form(w, ("pack", int(w_transposed), ntw))
     else:
-        wk = spconv_transpose_weight(w) if w_transposed else w
+        wk = _weight_form(w, ("transpose",)) if w_transposed else w
     spconv_launch(nbr, x, wk, out, w_flip, rb, packed)
+
+
+_weight_cache = {}
+
+
+def _weight_form(w: torch.Tensor, form: tuple) -> torch.Tensor:
+    """Packed / transposed form of a conv weight, re-used until the weight changes (the source and the target half of an
+    iteration share the weights).  Same validity rules as dense2d.relayout_cached: one live tensor object, one weight
+    version (autograd counter + _lib.WEIGHTS_EPOCH), one stream."""
+    import weakref
+    key = (id(w), form, stream())
+    tag = (_lib.WEIGHTS_EPOCH[0], w._version, w.data_ptr())
+    hit = _weight_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    K = w.shape[0]
+    if form[0] == "pack":
+        t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
+        call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], form[1], form[2], ptr(t), stream())
+    else:
+        t = spconv_transpose_weight(w)
+    if len(_weight_cache) > 4096:
+        _weight_cache.clear()
+    _weight_cache[key] = (tag, t, weakref.ref(w))
+    return t
 
 
 def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_flip: bool, rb, packed: bool):
