@@ -63,6 +63,10 @@ SIGNATURES = {
     "mopa_bn_act_bwd": ("i", "pipipiiipfipipiiippiipzp"),
     # ---- dense 2D branch (conv2d.hip, ops2d.hip)
     "mopa_conv2d_igemm": ("i", "pppppip"),
+    "mopa_conv2d_igemm_batched": ("i", "ppppilllip"),
+    "mopa_wino_weight": ("i", "piiipp"),
+    "mopa_wino_input": ("i", "piiiiipp"),
+    "mopa_wino_output": ("i", "piiiippiip"),
     "mopa_conv2d_wgrad_workspace_bytes": ("z", "p"),
     "mopa_conv2d_bwd_weight": ("i", "ppppipzp"),
     "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),

@@ -34,7 +34,12 @@ struct ConvGeom {
 template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          const ConvGeom g, int accumulate) {
+                                                          const ConvGeom g, int accumulate, int64_t bs_in, int64_t bs_w,
+                                                          int64_t bs_out) {
+  // blockIdx.z: independent problems of one shape (the 16 Winograd points); strides in floats, 0 for a single conv
+  in += blockIdx.z * bs_in;
+  w += blockIdx.z * bs_w;
+  out += blockIdx.z * bs_out;
   constexpr int TX = BN / TN, TY = 256 / TX;
   static_assert(TY * TM == BM && (TM == 4 || TM == 8) && (TN == 4 || TN == 8), "tile shape");
   constexpr int AROWS = BM / 64;             // A float4 loads per thread per K-chunk
@@ -180,30 +185,44 @@ static int pick_tile(int64_t M, int cout) {
   return 3;
 }
 
-// geom: 25 int32 in the ConvGeom order.  bias may be null.
-// flags: bit 0 = accumulate (out += result, used for gradient accumulation); bits 8-15 = tile override + 1 (tuning only).
-MOPA_API int mopa_conv2d_igemm(const float* in, const float* weight, const float* bias, float* out,
-                               const int32_t* geom_host, int32_t flags, void* stream) {
+static int igemm_launch(const float* in, const float* weight, const float* bias, float* out, const int32_t* geom_host,
+                        int32_t flags, int nbatch, int64_t bs_in, int64_t bs_w, int64_t bs_out, void* stream) {
   ConvGeom g;
   static_assert(sizeof(ConvGeom) == 25 * sizeof(int), "ConvGeom layout");
   memcpy(&g, geom_host, sizeof(g));
   if (g.Cin % BK != 0 || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0 || g.B <= 0 || g.TH * g.TW <= 0) return MOPA_ERR_ARG;
   if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return MOPA_ERR_ARG;
+  if (nbatch < 1 || nbatch > 65535 || ((bs_in | bs_w | bs_out) & 3)) return MOPA_ERR_ARG;
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
   if (M <= 0) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int accumulate = flags & 1;
-  int tile = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) - 1 : pick_tile(M, g.Cout);
+  int tile = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) - 1 : pick_tile(M * nbatch, g.Cout);
   if (tile < 0 || tile > 3 || g.Cout % kTiles[tile].bn) return MOPA_ERR_ARG;
-  dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn);
+  dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn, nbatch);
   switch (tile) {
-    case 0: k_conv2d_igemm<256, 64, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
-    case 1: k_conv2d_igemm<128, 128, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
-    case 2: k_conv2d_igemm<128, 64, 8, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
-    default: k_conv2d_igemm<64, 64, 4, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate); break;
+    case 0: k_conv2d_igemm<256, 64, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+    case 1: k_conv2d_igemm<128, 128, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+    case 2: k_conv2d_igemm<128, 64, 8, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+    default: k_conv2d_igemm<64, 64, 4, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
   }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
+}
+
+// geom: 25 int32 in the ConvGeom order.  bias may be null.
+// flags: bit 0 = accumulate (out += result, used for gradient accumulation); bits 8-15 = tile override + 1 (tuning only).
+MOPA_API int mopa_conv2d_igemm(const float* in, const float* weight, const float* bias, float* out,
+                               const int32_t* geom_host, int32_t flags, void* stream) {
+  return igemm_launch(in, weight, bias, out, geom_host, flags, 1, 0, 0, 0, stream);
+}
+
+// nbatch independent convolutions of one geometry: problem z reads in + z*in_stride, weight + z*w_stride and writes
+// out + z*out_stride (strides in floats).  Used for the 16 transformed points of the Winograd path (wino2d.hip).
+MOPA_API int mopa_conv2d_igemm_batched(const float* in, const float* weight, float* out, const int32_t* geom_host,
+                                       int32_t nbatch, int64_t in_stride, int64_t w_stride, int64_t out_stride, int32_t flags,
+                                       void* stream) {
+  return igemm_launch(in, weight, nullptr, out, geom_host, flags, nbatch, in_stride, w_stride, out_stride, stream);
 }
 
 // ----------------------------------------------------------------------------------------------

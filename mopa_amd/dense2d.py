@@ -9,6 +9,7 @@ Oracle: ``oracle/net2d.py``; golden fixture G1.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -67,25 +68,65 @@ def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
 _relayout_cache = {}
 
 
-def relayout_cached(w, shape, O, I, KH, KW, mode):
-    """Forward / backward-data layout of a conv weight, re-used until the weight changes (an iteration runs the network on
-    the source and on the target batch with the same weights).  An entry belongs to ONE live tensor object (weak reference:
-    the allocator hands a freed weight's address to the next tensor), one weight version (autograd's counter + the epoch
-    that FlatAdam / FlatEMA bump for their raw in-place updates) and one stream (the copy is only ordered with work of the
-    stream that made it)."""
+def _cached_weight_form(w, form, build):
+    """A derived layout of a conv weight, re-used until the weight changes (an iteration runs the network on the source and
+    on the target batch with the same weights).  An entry belongs to ONE live tensor object (weak reference: the allocator
+    hands a freed weight's address to the next tensor), one weight version (autograd's counter + the epoch that FlatAdam /
+    FlatEMA bump for their raw in-place updates) and one stream (the copy is only ordered with work of the stream that
+    made it)."""
     import weakref
     from ._lib import WEIGHTS_EPOCH
-    key = (id(w), mode, stream())
+    key = (id(w), form, stream())
     tag = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
     hit = _relayout_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
-    t = torch.empty(*shape, dtype=torch.float32, device=w.device)
-    relayout(w, t, O, I, KH, KW, mode)
+    t = build()
     if len(_relayout_cache) > 4096:   # temporaries (tests, one-off calls) must not pile up
         _relayout_cache.clear()
     _relayout_cache[key] = (tag, t, weakref.ref(w))
     return t
+
+
+def relayout_cached(w, shape, O, I, KH, KW, mode):
+    """Forward / backward-data implicit-GEMM layout of a conv weight (cached per weight version)."""
+    def build():
+        t = torch.empty(*shape, dtype=torch.float32, device=w.device)
+        relayout(w, t, O, I, KH, KW, mode)
+        return t
+    return _cached_weight_form(w, ("relayout", mode), build)
+
+
+def wino_weight_cached(w, dgrad: bool):
+    """U[16][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version."""
+    O, I = w.shape[0], w.shape[1]
+
+    def build():
+        u = torch.empty(16, (O if dgrad else I), (I if dgrad else O), dtype=torch.float32, device=w.device)
+        call("mopa_wino_weight", ptr(w), O, I, int(dgrad), ptr(u), stream())
+        return u
+    return _cached_weight_form(w, ("wino", int(dgrad)), build)
+
+
+def wino_eligible(cin, cout, k, s, p, B, H, W):
+    """Winograd F(2x2,3x3) beats the direct implicit GEMM for stride-1 3x3 convs with >= 128 channels on one side below
+    ~600k pixels (profiles/bench_wino.py: 1.2x at 128->64 152x240, 1.5x at 128^2, 2.1x at 256^2, 2.6x at 512^2; 64->64 and
+    the 304x480 layers are bound by the 4x transform traffic)."""
+    return (k == 3 and s == 1 and p == 1 and max(cin, cout) >= 128 and cin % 16 == 0 and cout % 64 == 0
+            and B * H * W < 600000 and os.environ.get("MOPA_WINOGRAD", "1") != "0")
+
+
+def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False):
+    """out = conv3x3(x) (+ bias) through k_wino_in -> 16 batched GEMMs -> k_wino_out."""
+    dev = U.device
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    T = B * th * tw
+    V = torch.empty(16 * T * cin, dtype=torch.float32, device=dev)
+    M = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
+    call("mopa_wino_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
+    g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
+    call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, 0, stream())
+    call("mopa_wino_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
 
 
 # ------------------------------------------------------------------------------------------------ conv wrappers
@@ -104,6 +145,9 @@ class ConvOp:
                      IX0=-self.p, TH=self.k, TW=self.k, KWF=self.k, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
 
     def forward(self, x: Img, out: Img):
+        if wino_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W):
+            wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False), self.b, out.p, out.ld)
+            return
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
@@ -117,6 +161,9 @@ class ConvOp:
         if db is not None:
             colsum(dout, db, accumulate=acc_params)
         if dx is None:
+            return
+        if wino_eligible(self.O, self.I, k, s, p, x.B, x.H, x.W):   # backward-data of a stride-1 3x3 conv is one, too
+            wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I, wino_weight_cached(self.w, True), None, dx.p, dx.ld, acc_dx)
             return
         wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:
