@@ -300,10 +300,15 @@ def main():
     from mopa_amd.step import DualStream
     dual = DualStream(dev)  # 3D branch (small latency-bound kernels) on a second HIP stream, overlapping the 2D GEMMs
 
+    resident = torch.cuda.Event()
+    resident.record()           # the synthetic batches are in HBM from here on
+    geom_ahead = os.environ.get("MOPA_BENCH_GEOM_AHEAD", "1") != "0"
+    bwd3_first = os.environ.get("MOPA_BENCH_BWD3_FIRST", "1") != "0"
+
     def half(b, lam_xm, supervised):
         """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
         o2, o3 = dual.forward(model2d, model3d, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
-                              {"x": [b["locs"], b["feats"]]})
+                              {"x": [b["locs"], b["feats"]]}, inputs_ready=resident if geom_ahead else None)
         l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
         l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
         if supervised:
@@ -315,8 +320,12 @@ def main():
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
             ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]]})                # third 3D pass on the VGI-style batch
             l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
-        l2.backward()
-        l3.backward()
+        if bwd3_first:   # the 3D backward (side stream) starts as soon as its loss gradient exists, beside the 2D backward
+            l3.backward()
+            l2.backward()
+        else:
+            l2.backward()
+            l3.backward()
         return l2.detach() + l3.detach()
 
     def step(i):
@@ -350,8 +359,15 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = timer2d.enabled = True
     t0 = time.perf_counter()
+    per_step, step_times = [], os.environ.get("MOPA_BENCH_STEP_TIMES")
     for i in range(args.steps):
         loss = step(i)
+        if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
+            if step_times == "sync":
+                torch.cuda.synchronize()
+            per_step.append(time.perf_counter() - t0)
+    if per_step:
+        print("[bench] cumulative step times:", " ".join(f"{t:.3f}" for t in per_step), file=sys.stderr, flush=True)
     t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
     torch.cuda.synchronize()
     if world > 1:

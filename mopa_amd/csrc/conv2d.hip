@@ -14,6 +14,7 @@
 //   (oy*IS + IY0 + ty*IDY, ox*IS + IX0 + tx*IDX), zero outside [IH][IW]; its weight slice is
 //   w[(KH0 + ty*KS) * KWF + (KW0 + tx*KS)] of shape [Cin][Cout].
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 struct ConvGeom {
@@ -174,13 +175,196 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same implicit GEMM on the matrix cores with f32 operands (v_mfma_f32_32x32x2_f32: exact fp32 products and fp32
+// accumulation -- the arithmetic of the fmaf chain above, in a different summation order -- at the fp32 VECTOR peak rate,
+// 157 TFLOP/s).  Why: the 8x8 register-tile kernel needs 64 B of LDS operands per 64 FMAs and ~1.3 instructions per 2 FMAs;
+// it tops out at 60 % of that peak (94 TFLOP/s on its best shape, 40-50 % on the others).  An MFMA takes its 64+64 operand
+// floats from ONE ds_read_b32 per lane each and keeps the SIMD busy for 64 cycles, so staging and addressing hide behind it.
+// Same staging (k-major A tile, double-buffered LDS, next chunk's global loads in flight), same tile shapes and the same
+// index map; the four waves of a block own WM x WN sub-tiles of 32x32 MFMA tiles.  MOPA_CONV2D_MFMA=0 selects the
+// vector-FMA kernel above (A/B measurements in DESIGN.md).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __restrict__ in, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               const ConvGeom g, int accumulate, int64_t bs_in, int64_t bs_w,
+                                                               int64_t bs_out) {
+  in += blockIdx.z * bs_in;
+  w += blockIdx.z * bs_w;
+  out += blockIdx.z * bs_out;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  static_assert((BM / WM) * (BN / WN) == 4 && WM % 32 == 0 && WN % 32 == 0, "four waves per block");
+  constexpr int AROWS = BM / 64;             // A float4 loads per thread per K-chunk
+  constexpr int BVEC = (BK * BN / 4) / 256;  // B float4 loads per thread per K-chunk
+  constexpr int BMP = BM + APAD;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BMP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ int64_t rowoff[BM];             // output offset of each tile row (-1: beyond M)
+  const int t = threadIdx.x;
+  const int M = g.B * g.OHl * g.OWl;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ohw = g.OHl * g.OWl;
+  // staging assignment: A row = t/4 + 64*j, k-quad = t%4.  Per row: input coordinates and element offset at tap (0,0);
+  // a tap adds a uniform delta, a K-chunk a uniform channel offset -> the loads of the loop are `uniform base + 32-bit
+  // per-lane offset` (saddr form, no 64-bit VALU), unconditional (rows outside the image read element 0 and are zeroed
+  // when staged), and the per-lane offsets change once per tap only.
+  const int akq = t & 3, arow = t >> 2;
+  int ay0[AROWS], ax0[AROWS], abase[AROWS];
+#pragma unroll
+  for (int j = 0; j < AROWS; ++j) {
+    const int m = m0 + arow + 64 * j;
+    if (m < M) {
+      const int b = m / ohw, r = m - b * ohw;
+      const int oy = r / g.OWl, ox = r - oy * g.OWl;
+      ay0[j] = oy * g.IS + g.IY0;
+      ax0[j] = ox * g.IS + g.IX0;
+      abase[j] = ((b * g.IH + ay0[j]) * g.IW + ax0[j]) * g.ld_in + akq * 4;
+    } else {
+      ay0[j] = -(1 << 28); ax0[j] = 0; abase[j] = 0;   // never inside the image
+    }
+  }
+  uint32_t boff[BVEC];
+#pragma unroll
+  for (int j = 0; j < BVEC; ++j) {
+    const int idx = t + 256 * j, k = idx / (BN / 4), c4 = idx - k * (BN / 4);
+    boff[j] = (uint32_t)(k * g.Cout + c4 * 4) * 4u;
+  }
+  for (int r = t; r < BM; r += 256) {
+    const int m = m0 + r;
+    int64_t off = -1;
+    if (m < M) {
+      const int b = m / ohw, q = m - b * ohw;
+      const int oy = q / g.OWl, ox = q - oy * g.OWl;
+      off = ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out;
+    }
+    rowoff[r] = off;
+  }
+  const int niter = g.TH * g.TW * (g.Cin / BK);
+  float4 ra0[AROWS], rb0[BVEC];
+  bool ok0[AROWS];
+  uint32_t aoff[AROWS];
+  bool aok[AROWS];
+  int tyy = 0, txx = 0, c0 = 0;
+  const float* wtap;
+  auto set_tap = [&]() {
+    const int dy = tyy * g.IDY, dx = txx * g.IDX;
+    const int delta = (dy * g.IW + dx) * g.ld_in;
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      aok[j] = (unsigned)(ay0[j] + dy) < (unsigned)g.IH && (unsigned)(ax0[j] + dx) < (unsigned)g.IW;
+      aoff[j] = aok[j] ? (uint32_t)(abase[j] + delta) * 4u : 0u;
+    }
+    wtap = w + (int64_t)((g.KH0 + tyy * g.KS) * g.KWF + g.KW0 + txx * g.KS) * g.Cin * g.Cout + n0;
+  };
+  auto load_tile = [&](float4* ra, float4* rb, bool* ok) {
+    const char* ic = reinterpret_cast<const char*>(in + c0);
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      ra[j] = *reinterpret_cast<const float4*>(ic + aoff[j]);
+      ok[j] = aok[j];
+    }
+    const char* wc = reinterpret_cast<const char*>(wtap + (int64_t)c0 * g.Cout);
+#pragma unroll
+    for (int j = 0; j < BVEC; ++j) rb[j] = *reinterpret_cast<const float4*>(wc + boff[j]);
+  };
+  auto advance = [&]() {   // uniform: next K-chunk, next tap after the last chunk of this one
+    c0 += BK;
+    if (c0 == g.Cin) {
+      c0 = 0;
+      if (++txx == g.TW) { txx = 0; ++tyy; }
+      set_tap();
+    }
+  };
+  auto store_tile = [&](int buf, const float4* ra, const float4* rb, const bool* ok) {
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      As[buf][akq * 4 + 0][arow + 64 * j] = ok[j] ? ra[j].x : 0.f;
+      As[buf][akq * 4 + 1][arow + 64 * j] = ok[j] ? ra[j].y : 0.f;
+      As[buf][akq * 4 + 2][arow + 64 * j] = ok[j] ? ra[j].z : 0.f;
+      As[buf][akq * 4 + 3][arow + 64 * j] = ok[j] ? ra[j].w : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < BVEC; ++j) {
+      const int idx = t + 256 * j, k = idx / (BN / 4), c4 = idx - k * (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[buf][k][c4 * 4]) = rb[j];
+    }
+  };
+
+  const int lane = t & 63, wv = t >> 6;
+  const int wm0 = (wv % (BM / WM)) * WM, wn0 = (wv / (BM / WM)) * WN;
+  const int l32 = lane & 31, lk = lane >> 5;   // MFMA operand: row / column l32, k index lk
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto multiply = [&](int cur) {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = As[cur][kk + lk][wm0 + i * 32 + l32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = Bs[cur][kk + lk][wn0 + j * 32 + l32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  set_tap();
+  load_tile(ra0, rb0, ok0);
+  store_tile(0, ra0, rb0, ok0);
+  __syncthreads();
+  // (a second register stage -- loads two chunks ahead -- was measured: +8 % on the direct small-M shapes, -4 % on the
+  // batched Winograd GEMMs that carry those layers, 118 -> 162 VGPRs: not kept)
+#pragma unroll 1
+  for (int it = 0; it < niter; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < niter) {   // global loads in flight while this tile is consumed
+      advance();
+      load_tile(ra0, rb0, ok0);
+    }
+    multiply(cur);
+    if (it + 1 < niter) {
+      store_tile(cur ^ 1, ra0, rb0, ok0);
+      __syncthreads();
+    }
+  }
+  // epilogue: accumulator register e of a 32x32 tile = row 8*(e/4) + 4*lk + e%4, column l32 -> every store instruction
+  // writes two 128-byte runs (32 consecutive output channels of two pixels)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn0 + j * 32 + l32;
+    const float bvj = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t off = rowoff[wm0 + i * 32 + 8 * (e >> 2) + 4 * lk + (e & 3)];
+        if (off < 0) continue;
+        float v = acc[i][j][e] + bvj;
+        if (accumulate) v += out[off + n];
+        out[off + n] = v;
+      }
+    }
+  }
+}
+
 // Tile choice, from measurements on MI355X at the network's own shapes (profiles/bench_igemm.py, B=8):
 //   M >= 200k pixels: 256x64 (8x8 register tile) 68-82 TF/s; with Cout % 128 == 0 and M >= 1M: 128x128 84 TF/s;
 //   M <  200k pixels (layer2-4, decoder stages 3-5): 64x64 (4x4 register tile) fills the 256 CUs -- 50-69 TF/s
 //   where the large tiles reach 34-60 (4,560 pixels x 512 channels is 144 blocks of 256x64 on 256 CUs).
 struct TileCfg { int bm, bn; };
 static const TileCfg kTiles[4] = {{256, 64}, {128, 128}, {128, 64}, {64, 64}};
-static int pick_tile(int64_t M, int cout) {
+static int pick_tile(int64_t M, int cout, bool mfma) {
+  // MFMA kernel (same sweep): 128x64 wins or ties everywhere above 200k pixels (115-119 TF/s at full resolution), 64x64 below
+  if (mfma) return M >= 200000 ? 2 : 3;
   if (M >= 200000) return (cout % 128 == 0 && M >= 1000000) ? 1 : 0;
   return 3;
 }
@@ -197,14 +381,26 @@ static int igemm_launch(const float* in, const float* weight, const float* bias,
   if (M <= 0) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int accumulate = flags & 1;
-  int tile = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) - 1 : pick_tile(M * nbatch, g.Cout);
+  static const bool env_mfma = [] { const char* e = getenv("MOPA_CONV2D_MFMA"); return !e || atoi(e) != 0; }();
+  // the MFMA kernel addresses its operands with 32-bit byte offsets
+  const bool use_mfma = env_mfma && (int64_t)g.B * g.IH * g.IW * g.ld_in < (1ll << 30) && (int64_t)BK * g.Cout < (1ll << 28);
+  int tile = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) - 1 : pick_tile(M * nbatch, g.Cout, use_mfma);
   if (tile < 0 || tile > 3 || g.Cout % kTiles[tile].bn) return MOPA_ERR_ARG;
   dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn, nbatch);
-  switch (tile) {
-    case 0: k_conv2d_igemm<256, 64, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-    case 1: k_conv2d_igemm<128, 128, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-    case 2: k_conv2d_igemm<128, 64, 8, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-    default: k_conv2d_igemm<64, 64, 4, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+  if (use_mfma) {
+    switch (tile) {
+      case 0: k_conv2d_igemm_mfma<256, 64, 64, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 1: k_conv2d_igemm_mfma<128, 128, 64, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 2: k_conv2d_igemm_mfma<128, 64, 64, 32><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      default: k_conv2d_igemm_mfma<64, 64, 32, 32><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+    }
+  } else {
+    switch (tile) {
+      case 0: k_conv2d_igemm<256, 64, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 1: k_conv2d_igemm<128, 128, 8, 8><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 2: k_conv2d_igemm<128, 64, 8, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      default: k_conv2d_igemm<64, 64, 4, 4><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+    }
   }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
@@ -349,6 +545,100 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
   }
 }
 
+// The same on the matrix cores (f32 operands, see k_conv2d_igemm_mfma): the LDS tiles are already pixel-major, which is the
+// MFMA K dimension; wave w owns the (ci half, co half) 32x32 quadrant of all NTAP taps -> per pixel pair NTAP + 1 ds_read_b32
+// and NTAP v_mfma_f32_32x32x2_f32.  Cin % 64 == 0 only (the stem keeps the vector kernel).
+template <int NTAP>
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
+                                                            float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
+  constexpr int WM = 64, WN = 64;
+  __shared__ __attribute__((aligned(16))) float As[2][NTAP][WBK][WM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK][WN + 4];
+  const int t = threadIdx.x;
+  const int tap0 = blockIdx.x * NTAP;
+  const int tiles_n = g.Cout / WN;
+  const int ci0 = (blockIdx.y / tiles_n) * WM, co0 = (blockIdx.y % tiles_n) * WN;
+  const int tyy = tap0 / g.TW, txx0 = tap0 - tyy * g.TW;
+  const int M = g.B * g.OHl * g.OWl;
+  const int mbeg = blockIdx.z * m_per_split, mend = min(M, mbeg + m_per_split);
+  const int sk = t >> 4, sq = t & 15;   // staging: pixel k = t / 16, 4-float group = t % 16
+  const int lane = t & 63, wv = t >> 6;
+  const int wci = (wv & 1) * 32, wco = (wv >> 1) * 32;
+  const int l32 = lane & 31, lk = lane >> 5;
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int n = 0; n < NTAP; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+  float4 ra[NTAP], rb;
+  int pb, poy, pox;
+  {
+    const int m = mbeg + sk;
+    pb = m / (g.OHl * g.OWl);
+    const int r = m - pb * g.OHl * g.OWl;
+    poy = r / g.OWl;
+    pox = r - poy * g.OWl;
+  }
+  auto load_tile = [&](int mb) {
+    const int m = mb + sk;
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NTAP; ++n) ra[n] = rb;
+    const int b = pb, oy = poy, ox = pox;
+    pox += WBK;
+    while (pox >= g.OWl) {
+      pox -= g.OWl;
+      if (++poy == g.OHl) { poy = 0; ++pb; }
+    }
+    if (m < mend) {
+      const int iy = oy * g.IS + g.IY0 + tyy * g.IDY;
+#pragma unroll
+      for (int n = 0; n < NTAP; ++n) {
+        const int ix = ox * g.IS + g.IX0 + (txx0 + n) * g.IDX;
+        if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+          ra[n] = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + ci0 + sq * 4);
+      }
+      rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + co0 + sq * 4);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int n = 0; n < NTAP; ++n) *reinterpret_cast<float4*>(&As[buf][n][sk][sq * 4]) = ra[n];
+    *reinterpret_cast<float4*>(&Bs[buf][sk][sq * 4]) = rb;
+  };
+  int buf = 0;
+  if (mbeg < mend) {
+    load_tile(mbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int mb = mbeg; mb < mend; mb += WBK) {
+    const bool more = mb + WBK < mend;
+    if (more) load_tile(mb + WBK);
+#pragma unroll
+    for (int kk = 0; kk < WBK; kk += 2) {
+      const float bv = Bs[buf][kk + lk][wco + l32];
+      float av[NTAP];
+#pragma unroll
+      for (int n = 0; n < NTAP; ++n) av[n] = As[buf][n][kk + lk][wci + l32];
+#pragma unroll
+      for (int n = 0; n < NTAP; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv, acc[n], 0, 0, 0);
+    }
+    if (more) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  const int64_t wsz = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
+#pragma unroll
+  for (int n = 0; n < NTAP; ++n) {
+    float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)(tap0 + n) * g.Cin + ci0 + wci) * g.Cout + co0 + wco + l32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[(int64_t)(8 * (e >> 2) + 4 * lk + (e & 3)) * g.Cout] = acc[n][e];
+  }
+}
+
 // dw[i] (+)= sum_c slabs[c][i]: 16 chunk-lanes per element + fixed-order LDS reduction.
 __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
                                                         int accumulate) {
@@ -407,13 +697,16 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
   wgrad_split(g, &ns, &mps);
   hipStream_t st = (hipStream_t)stream;
   float* slabs = (float*)ws;
+  static const bool use_mfma = [] { const char* e = getenv("MOPA_CONV2D_MFMA"); return !e || atoi(e) != 0; }();
   if (g.Cin >= 64) {
     if (wgrad_ntap(g) == 3) {
       dim3 grid(g.TH * g.TW / 3, (g.Cin / 64) * (g.Cout / 64), ns);
-      k_conv2d_wgrad<64, 3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      if (use_mfma) k_conv2d_wgrad_mfma<3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      else k_conv2d_wgrad<64, 3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     } else {
       dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
-      k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      if (use_mfma) k_conv2d_wgrad_mfma<1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      else k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     }
   } else if (wgrad_ntap(g) == 2) {
     dim3 grid(g.TH * g.TW / 2, g.Cout / 64, ns);

@@ -16,14 +16,26 @@ class DualStream:
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
 
-    def forward(self, model_2d, model_3d, batch_2d: dict, batch_3d: dict):
-        """-> (preds_2d, preds_3d); both are safe to use on the current stream when this returns."""
+    def forward(self, model_2d, model_3d, batch_2d: dict, batch_3d: dict, inputs_ready=None):
+        """-> (preds_2d, preds_3d); both are safe to use on the current stream when this returns.
+
+        ``inputs_ready``: an event after which the 3D coordinates are resident (e.g. recorded by the loader's copy stream).
+        With it the voxel geometry -- which depends on the coordinates only and holds the 3D branch's two host syncs -- is
+        built on the side stream BEFORE that stream is ordered behind the main stream, so the host does not stall on the
+        previous half's 2D backward and keeps enqueueing ahead of the device.  Without it the build waits like the rest."""
         main = torch.cuda.current_stream(self.device)
+        if inputs_ready is not None and batch_3d.get("geometry_3d") is None:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(inputs_ready)
+                batch_3d = dict(batch_3d, geometry_3d=model_3d.net_3d.geometry(batch_3d["x"][0]))
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             preds_3d = model_3d(batch_3d)
         preds_2d = model_2d(batch_2d)
         main.wait_stream(self.side)
+        for t in preds_3d.values():   # allocated from the side stream's pool, read by the loss kernels on the main stream:
+            if torch.is_tensor(t):    # their memory must not return to the side stream before those reads are done
+                t.record_stream(main)
         return preds_2d, preds_3d
 
     def join(self):

@@ -205,28 +205,42 @@ def test_dual_stream_is_bit_identical_to_sequential():
     b = synth.make_batch(2, H=64, W=96)
     lab = b["seg_label"].cuda()
 
-    def run(dual):
+    def run(dual, ahead=False):
         torch.manual_seed(0)
         cfg = default_cfg()
         m2, m3 = build_model_2d(cfg)[0].cuda().train(), build_model_3d(cfg)[0].cuda().train()
         m2.net_2d.dropout.p = 0.0
-        if dual is None:
-            p2, p3 = m2(b), m3(b)
-        else:
-            p2, p3 = dual.forward(m2, m3, b, b)
-        l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"])
-        l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
-        l2.backward()
-        l3.backward()
+        ready = torch.cuda.Event()
+        ready.record()
+        losses = []
+        for _ in range(3):   # back to back, gradients accumulate, no device sync in between (the bench's steady state)
+            if dual is None:
+                p2, p3 = m2(b), m3(b)
+            else:
+                p2, p3 = dual.forward(m2, m3, b, b, inputs_ready=ready if ahead else None)
+            l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"])
+            l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
+            if ahead:   # 3D backward first: it runs on the side stream beside the 2D backward
+                l3.backward()
+                l2.backward()
+            else:
+                l2.backward()
+                l3.backward()
+            losses += [l2.detach(), l3.detach()]
+            del p2, p3, l2, l3
         if dual is not None:
             dual.join()
         torch.cuda.synchronize()
-        return [p.grad.clone() for m in (m2, m3) for p in m.parameters()], float(l2), float(l3)
+        return [p.grad.clone() for m in (m2, m3) for p in m.parameters()], [float(x) for x in losses]
 
-    g_seq, a2, a3 = run(None)
-    g_dual, b2, b3 = run(DualStream("cuda"))
-    assert a2 == b2 and a3 == b3
+    g_seq, a = run(None)
+    g_dual, c = run(DualStream("cuda"))
+    assert a == c
     assert all(torch.equal(x, y) for x, y in zip(g_seq, g_dual))
+    # geometry built ahead of the main stream (inputs_ready) + 3D backward first: same kernels, same per-network order
+    g_ahead, d = run(DualStream("cuda"), ahead=True)
+    assert a == d
+    assert all(torch.equal(x, y) for x, y in zip(g_seq, g_ahead))
 
 
 def test_single_head_ten_classes_and_empty_image_indices():
