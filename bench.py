@@ -360,6 +360,7 @@ def main():
     timer.enabled = timer2d.enabled = True
     t0 = time.perf_counter()
     per_step, step_times = [], os.environ.get("MOPA_BENCH_STEP_TIMES")
+    ms0 = torch.cuda.memory_stats() if step_times else None
     for i in range(args.steps):
         loss = step(i)
         if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
@@ -367,6 +368,11 @@ def main():
                 torch.cuda.synchronize()
             per_step.append(time.perf_counter() - t0)
     if per_step:
+        ms1 = torch.cuda.memory_stats()
+        print("[bench] allocator in the timed region: segments malloc'd", ms1["segment.all.allocated"] - ms0["segment.all.allocated"],
+              "freed", ms1["segment.all.freed"] - ms0["segment.all.freed"], "retries", ms1["num_alloc_retries"] - ms0["num_alloc_retries"],
+              "reserved GB", round(ms1["reserved_bytes.all.current"] / 1e9, 2), "was", round(ms0["reserved_bytes.all.current"] / 1e9, 2),
+              file=sys.stderr, flush=True)
         print("[bench] cumulative step times:", " ".join(f"{t:.3f}" for t in per_step), file=sys.stderr, flush=True)
     t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
     torch.cuda.synchronize()
@@ -404,12 +410,12 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if joint and os.path.exists(tpath):                                  # of this same command (profiles/traffic.py)
-            traffic = json.load(open(tpath)).get("k_conv2d_igemm", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("k_conv2d_igemm_mfma", {}).get("hbm_bytes_per_launch")
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r1_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm (fp32 vector FMA; fwd + bwd-data + convT)",
+                    "kernel": "k_conv2d_igemm_mfma (f32-operand MFMA, exact fp32; direct fwd + bwd-data + convT launches)",
                     "launches_per_step": k2["launches"] // args.steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "

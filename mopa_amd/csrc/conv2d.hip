@@ -1,5 +1,7 @@
-// Dense 2D convolution of the image branch as an LDS-tiled implicit GEMM on the fp32 vector pipe (no MFMA here by
-// design: north_star keeps the matrix cores for the sparse conv).  NHWC activations, one kernel for
+// Dense 2D convolution of the image branch as an LDS-tiled implicit GEMM.  Two inner products over the same staging and
+// index map: f32-operand MFMA (default; exact fp32, measured 95-119 TFLOP/s) and the fp32 vector pipe (v_pk_fma_f32,
+// 60-94 TFLOP/s; north_star's literal choice, kept selectable with MOPA_CONV2D_MFMA=0 -- see DESIGN.md section 3 for the
+// measurements behind the default).  NHWC activations, one kernel for
 //   * forward conv (3x3 s1/s2, 1x1 s2, the 7x7 stem through a 16-wide tap trick),
 //   * backward-data (stride 1 directly; stride 2 as 4 output-parity classes so no FLOP is wasted on zeros),
 //   * ConvTranspose2d k2 s2 (4 output-parity classes of a 1x1 conv) and its backward-data (a 2x2 s2 conv),
@@ -546,12 +548,14 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad(const float* __restrict__ 
 }
 
 // The same on the matrix cores (f32 operands, see k_conv2d_igemm_mfma): the LDS tiles are already pixel-major, which is the
-// MFMA K dimension; wave w owns the (ci half, co half) 32x32 quadrant of all NTAP taps -> per pixel pair NTAP + 1 ds_read_b32
-// and NTAP v_mfma_f32_32x32x2_f32.  Cin % 64 == 0 only (the stem keeps the vector kernel).
-template <int NTAP>
+// MFMA K dimension.  Block = 64 input channels x 64*NCO output channels x NTAP taps; wave w owns the (ci half, co half)
+// quadrant: NTAP x NCO 32x32 tiles -> per pixel pair NTAP + NCO ds_read_b32 and NTAP * NCO v_mfma_f32_32x32x2_f32.
+// Loads are `uniform base + 32-bit per-lane offset`, unconditional (pixels outside the image / the slice read element 0 and
+// are zeroed when staged).  Cin % 64 == 0 only (the stem keeps the vector kernel).
+template <int NTAP, int NCO>
 __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
                                                             float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
-  constexpr int WM = 64, WN = 64;
+  constexpr int WM = 64, WN = 64 * NCO;
   __shared__ __attribute__((aligned(16))) float As[2][NTAP][WBK][WM + 4];
   __shared__ __attribute__((aligned(16))) float Bs[2][WBK][WN + 4];
   const int t = threadIdx.x;
@@ -563,14 +567,17 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
   const int mbeg = blockIdx.z * m_per_split, mend = min(M, mbeg + m_per_split);
   const int sk = t >> 4, sq = t & 15;   // staging: pixel k = t / 16, 4-float group = t % 16
   const int lane = t & 63, wv = t >> 6;
-  const int wci = (wv & 1) * 32, wco = (wv >> 1) * 32;
+  const int wci = (wv & 1) * 32, wco = (wv >> 1) * 32 * NCO;
   const int l32 = lane & 31, lk = lane >> 5;
-  f32x16 acc[NTAP];
+  f32x16 acc[NTAP][NCO];
 #pragma unroll
   for (int n = 0; n < NTAP; ++n)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-  float4 ra[NTAP], rb;
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.f;
+  float4 ra[NTAP], rb[NCO];
+  bool oka[NTAP], okb;
   int pb, poy, pox;
   {
     const int m = mbeg + sk;
@@ -579,32 +586,40 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
     poy = r / g.OWl;
     pox = r - poy * g.OWl;
   }
+  const char* inb = reinterpret_cast<const char*>(in + ci0 + sq * 4);
+  const char* dyb = reinterpret_cast<const char*>(dy + co0 + sq * 4);
   auto load_tile = [&](int mb) {
-    const int m = mb + sk;
-    rb = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int n = 0; n < NTAP; ++n) ra[n] = rb;
     const int b = pb, oy = poy, ox = pox;
     pox += WBK;
     while (pox >= g.OWl) {
       pox -= g.OWl;
       if (++poy == g.OHl) { poy = 0; ++pb; }
     }
-    if (m < mend) {
-      const int iy = oy * g.IS + g.IY0 + tyy * g.IDY;
+    okb = mb + sk < mend;
+    const int iy = oy * g.IS + g.IY0 + tyy * g.IDY;
+    const bool rowok = okb && (unsigned)iy < (unsigned)g.IH;
+    const int rowbase = (b * g.IH + iy) * g.IW;
 #pragma unroll
-      for (int n = 0; n < NTAP; ++n) {
-        const int ix = ox * g.IS + g.IX0 + (txx0 + n) * g.IDX;
-        if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
-          ra[n] = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + ci0 + sq * 4);
-      }
-      rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + co0 + sq * 4);
+    for (int n = 0; n < NTAP; ++n) {
+      const int ix = ox * g.IS + g.IX0 + (txx0 + n) * g.IDX;
+      oka[n] = rowok && (unsigned)ix < (unsigned)g.IW;
+      const uint32_t off = oka[n] ? (uint32_t)((rowbase + ix) * g.ld_in) * 4u : 0u;
+      ra[n] = *reinterpret_cast<const float4*>(inb + off);
     }
+    const uint32_t offb = okb ? (uint32_t)(((b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out) * 4u : 0u;
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) rb[c] = *reinterpret_cast<const float4*>(dyb + offb + c * 256);
   };
   auto store_tile = [&](int buf) {
+    // (component-wise selects: `ok ? ra[n] : zero` on the float4 becomes a pointer select and sends the arrays to scratch)
 #pragma unroll
-    for (int n = 0; n < NTAP; ++n) *reinterpret_cast<float4*>(&As[buf][n][sk][sq * 4]) = ra[n];
-    *reinterpret_cast<float4*>(&Bs[buf][sk][sq * 4]) = rb;
+    for (int n = 0; n < NTAP; ++n)
+      *reinterpret_cast<float4*>(&As[buf][n][sk][sq * 4]) =
+          make_float4(oka[n] ? ra[n].x : 0.f, oka[n] ? ra[n].y : 0.f, oka[n] ? ra[n].z : 0.f, oka[n] ? ra[n].w : 0.f);
+#pragma unroll
+    for (int c = 0; c < NCO; ++c)
+      *reinterpret_cast<float4*>(&Bs[buf][sk][c * 64 + sq * 4]) =
+          make_float4(okb ? rb[c].x : 0.f, okb ? rb[c].y : 0.f, okb ? rb[c].z : 0.f, okb ? rb[c].w : 0.f);
   };
   int buf = 0;
   if (mbeg < mend) {
@@ -617,12 +632,15 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
     if (more) load_tile(mb + WBK);
 #pragma unroll
     for (int kk = 0; kk < WBK; kk += 2) {
-      const float bv = Bs[buf][kk + lk][wco + l32];
-      float av[NTAP];
+      float av[NTAP], bv[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) bv[c] = Bs[buf][kk + lk][wco + c * 32 + l32];
 #pragma unroll
       for (int n = 0; n < NTAP; ++n) av[n] = As[buf][n][kk + lk][wci + l32];
 #pragma unroll
-      for (int n = 0; n < NTAP; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv, acc[n], 0, 0, 0);
+      for (int n = 0; n < NTAP; ++n)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv[c], acc[n][c], 0, 0, 0);
     }
     if (more) {
       store_tile(buf ^ 1);
@@ -633,9 +651,12 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
   const int64_t wsz = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
 #pragma unroll
   for (int n = 0; n < NTAP; ++n) {
-    float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)(tap0 + n) * g.Cin + ci0 + wci) * g.Cout + co0 + wco + l32;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dst[(int64_t)(8 * (e >> 2) + 4 * lk + (e & 3)) * g.Cout] = acc[n][e];
+    for (int c = 0; c < NCO; ++c) {
+      float* dst = slabs + (int64_t)blockIdx.z * wsz + ((int64_t)(tap0 + n) * g.Cin + ci0 + wci) * g.Cout + co0 + wco + c * 32 + l32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[(int64_t)(8 * (e >> 2) + 4 * lk + (e & 3)) * g.Cout] = acc[n][c][e];
+    }
   }
 }
 
@@ -664,11 +685,22 @@ static int wgrad_ntap(const ConvGeom& g) {
   return 1;
 }
 
+static bool wgrad_use_mfma(const ConvGeom& g) {
+  static const bool env_mfma = [] { const char* e = getenv("MOPA_CONV2D_MFMA"); return !e || atoi(e) != 0; }();
+  // 32-bit byte offsets into the input and the output-gradient images
+  return env_mfma && g.Cin >= 64 && (int64_t)g.B * g.IH * g.IW * g.ld_in < (1ll << 30) &&
+         (int64_t)g.B * g.OHa * g.OWa * g.ld_out < (1ll << 30);
+}
+// Output-channel tiles of 32 per wave in the MFMA kernel.  NCO = 2 (block = 64 x 128 channels: half the dY traffic, twice the
+// MFMAs per barrier) was measured on the >= 128-channel layers: same kernel time at 248 VGPRs, and the split-K reduction
+// grows with the larger split count -> 1.
+static int wgrad_nco(const ConvGeom& g) { return 1; }
+
 static void wgrad_split(const ConvGeom& g, int* nsplit, int* m_per_split) {
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
   const int wm = g.Cin >= 64 ? 64 : 16;
-  const int64_t tiles = (int64_t)(g.TH * g.TW / wgrad_ntap(g)) * (g.Cin / wm) * (g.Cout / 64);
-  int64_t ns = cdiv64(2048, tiles);
+  const int64_t tiles = (int64_t)(g.TH * g.TW / wgrad_ntap(g)) * (g.Cin / wm) * (g.Cout / (64 * wgrad_nco(g)));
+  int64_t ns = cdiv64(2048, tiles);   // (768 ... 3072 target blocks measured: +-1 % on the joint step)
   const int64_t maxs = cdiv64(M, 256);
   if (ns > maxs) ns = maxs;
   if (ns > 512) ns = 512;
@@ -697,16 +729,18 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
   wgrad_split(g, &ns, &mps);
   hipStream_t st = (hipStream_t)stream;
   float* slabs = (float*)ws;
-  static const bool use_mfma = [] { const char* e = getenv("MOPA_CONV2D_MFMA"); return !e || atoi(e) != 0; }();
+  const bool use_mfma = wgrad_use_mfma(g);
+  const int nco = wgrad_nco(g);
   if (g.Cin >= 64) {
-    if (wgrad_ntap(g) == 3) {
-      dim3 grid(g.TH * g.TW / 3, (g.Cin / 64) * (g.Cout / 64), ns);
-      if (use_mfma) k_conv2d_wgrad_mfma<3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
-      else k_conv2d_wgrad<64, 3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    const int ntap = wgrad_ntap(g) == 3 ? 3 : 1;
+    dim3 grid(g.TH * g.TW / ntap, (g.Cin / 64) * (g.Cout / (64 * nco)), ns);
+    if (use_mfma) {
+      if (ntap == 3) k_conv2d_wgrad_mfma<3, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      else k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+    } else if (ntap == 3) {
+      k_conv2d_wgrad<64, 3><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     } else {
-      dim3 grid(g.TH * g.TW, (g.Cin / 64) * (g.Cout / 64), ns);
-      if (use_mfma) k_conv2d_wgrad_mfma<1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
-      else k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
+      k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     }
   } else if (wgrad_ntap(g) == 2) {
     dim3 grid(g.TH * g.TW / 2, g.Cout / 64, ns);

@@ -1,6 +1,6 @@
 // Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the image branch with >= 128 channels (layer2-4 of the ResNet34
-// encoder, decoder stages 3-4): 2.25x fewer multiplies than the direct implicit GEMM, still on the fp32 vector pipe
-// (north_star keeps the matrix cores for the sparse conv).  Three steps, NHWC fp32:
+// encoder, decoder stages 3-4): 2.25x fewer multiplies than the direct implicit GEMM; the 16 GEMMs run on the same kernel (f32 MFMA by default).
+// Three steps, NHWC fp32:
 //   1. k_wino_in :  V[p][t][ci] = (B^T d B)[p]   per 2x2-output tile t and channel (d = the tile's 4x4 input patch, zero padded)
 //   2. 16 GEMMs  :  M[p] = V[p] (T x Cin) @ U[p] (Cin x Cout)   -- mopa_conv2d_igemm_batched (the implicit-GEMM kernel as a 1x1 conv)
 //   3. k_wino_out:  out tile = A^T M[.][t][co] A  (+ bias, or accumulated into out)

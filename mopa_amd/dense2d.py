@@ -109,11 +109,12 @@ def wino_weight_cached(w, dgrad: bool):
 
 
 def wino_eligible(cin, cout, k, s, p, B, H, W):
-    """Winograd F(2x2,3x3) beats the direct implicit GEMM for stride-1 3x3 convs with >= 128 channels on one side below
-    ~600k pixels (profiles/bench_wino.py: 1.2x at 128->64 152x240, 1.5x at 128^2, 2.1x at 256^2, 2.6x at 512^2; 64->64 and
-    the 304x480 layers are bound by the 4x transform traffic)."""
+    """Winograd F(2x2,3x3) beats the direct implicit GEMM (both on f32 MFMA) for stride-1 3x3 convs with >= 128 channels
+    on one side up to 76x120 at batch 8 (profiles/bench_wino.py: 1.2x at 128^2 76x120, 1.4x at 256->128, 1.9x at 256^2 and
+    512->256 38x60, 2.4x at 512^2 19x30; 0.96x at 128->64 152x240 and 0.73x at 64^2: there the V / M traffic -- 4x the
+    activations, written and read -- costs more than the saved multiplies)."""
     return (k == 3 and s == 1 and p == 1 and max(cin, cout) >= 128 and cin % 16 == 0 and cout % 64 == 0
-            and B * H * W < 600000 and os.environ.get("MOPA_WINOGRAD", "1") != "0")
+            and B * H * W < 200000 and os.environ.get("MOPA_WINOGRAD", "1") != "0")
 
 
 def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False):
@@ -364,7 +365,9 @@ class Net2DFunction(torch.autograd.Function):
         ctx.spec, ctx.P, ctx.tape, ctx.J, ctx.training = spec, P, tape, J, training
         if DEBUG is not None:
             DEBUG.update({f"J{k}": v.clone() for k, v in J.items()})
-        ctx.feat, ctx.feats, ctx.point_pix, ctx.dims = feat, feats, point_pix, (B, H, W, Hp, Wp, N)
+        # feats.detach(): an alias without grad_fn -- the output object itself on ctx would be a reference cycle through this
+        # node, freed only by the cyclic GC (the activations of every step stayed allocated until then)
+        ctx.feat, ctx.feats, ctx.point_pix, ctx.dims = feat, feats.detach(), point_pix, (B, H, W, Hp, Wp, N)
         ctx.drop_seed = drop_seed
         return feats, l1, l2, pred_all
 

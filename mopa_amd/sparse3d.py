@@ -350,8 +350,11 @@ class SCNNetFunction(torch.autograd.Function):
         call("mopa_output_layer_heads_fwd", y.p, y.ld, ptr(geom.point_row), N, m, C, ptr(P["linear.weight"]),
              ptr(P["linear.bias"]), ptr(w2), ptr(b2), ptr(out_feats), ptr(l1), ptr(l2) if spec.dual_head else None,
              stream())
+        U = None   # the recursive closure refers to itself through its own cell: a cycle that pins `tape` until the cyclic GC runs
         ctx.spec, ctx.geom, ctx.training, ctx.tape = spec, geom, training, tape
-        ctx.P, ctx.y_final, ctx.out_feats = P, y, out_feats
+        # a detached alias: the returned tensor itself gets this node as grad_fn, and keeping it on ctx would be a reference
+        # cycle (node -> ctx -> output -> node) that only the cyclic GC frees -- ~2 GB of activations per step
+        ctx.P, ctx.y_final, ctx.out_feats = P, y, out_feats.detach()
         ctx.feats_needs_grad = feats.requires_grad
         ctx.x0 = x0
         return out_feats, l1, l2
