@@ -141,6 +141,51 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, i
     }
   }
 }
+
+// Weight gradient in the Winograd domain: dU[p] = V[p]^T dM[p] with dM = A dY A^T per 2x2 output tile (A = (A^T)^T, 4x2).
+// thread = (tile, channel quad); output-gradient pixels beyond H, W are zero.
+__global__ __launch_bounds__(256) void k_wino_dout(const float* __restrict__ dy, int ld, int B, int H, int W, int C, int th, int tw,
+                                                    float* __restrict__ dM) {
+  const int CQ = C >> 2;
+  const int64_t T = (int64_t)B * th * tw;
+  const int64_t total = T * CQ;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / CQ;
+    const int cq = (int)(i - t * CQ);
+    const int b = (int)(t / (th * tw));
+    const int rt = (int)(t - (int64_t)b * th * tw);
+    const int ty = rt / tw, tx = rt - ty * tw;
+    float4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int y = 2 * ty + a, x = 2 * tx + c;
+        d[a][c] = (y < H && x < W) ? *reinterpret_cast<const float4*>(dy + ((int64_t)(b * H + y) * W + x) * ld + cq * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float4 r[4][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {  // A dY
+      r[0][c] = d[0][c];
+      F4OP(r[1][c], d[0][c], +, d[1][c]);
+      F4OP(r[2][c], d[0][c], -, d[1][c]);
+      r[3][c] = make_float4(-d[1][c].x, -d[1][c].y, -d[1][c].z, -d[1][c].w);
+    }
+    float* mp = dM + t * C + cq * 4;
+    const int64_t ps = T * C;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {  // (.) A^T
+      float4 m1, m2;
+      F4OP(m1, r[a][0], +, r[a][1]);
+      F4OP(m2, r[a][0], -, r[a][1]);
+      *reinterpret_cast<float4*>(mp + (a * 4 + 0) * ps) = r[a][0];
+      *reinterpret_cast<float4*>(mp + (a * 4 + 1) * ps) = m1;
+      *reinterpret_cast<float4*>(mp + (a * 4 + 2) * ps) = m2;
+      *reinterpret_cast<float4*>(mp + (a * 4 + 3) * ps) = make_float4(-r[a][1].x, -r[a][1].y, -r[a][1].z, -r[a][1].w);
+    }
+  }
+}
 #undef F4OP
 
 // U (16 * Cin * Cout floats) from the OIHW weight of a 3x3 convolution (dgrad = 1: filter of its backward-data).
@@ -164,6 +209,15 @@ MOPA_API int mopa_wino_output(const float* M, int32_t B, int32_t H, int32_t W, i
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ld_out < C || (ld_out & 3) || (((uintptr_t)out | (uintptr_t)M) & 15)) return MOPA_ERR_ARG;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   k_wino_out<<<stream_grid((int64_t)B * th * tw * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(M, B, H, W, C, th, tw, bias, out, ld_out, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+// dM (16 * T * C floats) = A dY A^T from the NHWC output gradient (row stride ld) -- the second operand of the Winograd-domain
+// weight gradient (mopa_wino_bwd_weight in conv2d.hip; the first is V from mopa_wino_input on the layer input).
+MOPA_API int mopa_wino_dout(const float* dy, int32_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* dM, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ld < C || (ld & 3) || (((uintptr_t)dy | (uintptr_t)dM) & 15)) return MOPA_ERR_ARG;
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  k_wino_dout<<<stream_grid((int64_t)B * th * tw * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(dy, ld, B, H, W, C, th, tw, dM);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

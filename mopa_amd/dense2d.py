@@ -128,6 +128,29 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
     call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, 0, stream())
     call("mopa_wino_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
+    return V
+
+
+def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
+    """The weight gradient of the same layers in the transform domain (dU[p] = V[p]^T dM[p], 16 batched 1x1 weight gradients
+    on the MFMA kernel, then G^T dU G): needs 64-aligned channels on both sides and the MFMA build."""
+    return (wino_eligible(cin, cout, k, s, p, B, H, W) and cin % 64 == 0 and cout % 64 == 0 and min(cin, cout) >= 128
+            and os.environ.get("MOPA_CONV2D_MFMA", "1") != "0" and os.environ.get("MOPA_WINOGRAD_WGRAD", "1") != "0")
+
+
+def wino_wgrad(x: Img, dout: Img, cin, cout, dwl, V=None):
+    """dwl[3][3][cin][cout] = weight gradient of conv3x3(x) given dout, through V = B^T x B (kept from the forward pass when
+    the caller has it), dM = A dout A^T."""
+    dev = dwl.device
+    B, H, W = x.B, x.H, x.W
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    dM = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
+    if V is None:
+        V = torch.empty(16 * T * cin, dtype=torch.float32, device=dev)
+        call("mopa_wino_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
+    call("mopa_wino_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
+    ws = _ws(query("mopa_wino_wgrad_workspace_bytes", T, cin, cout), dev)
+    call("mopa_wino_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dwl), ptr(ws), ws.numel(), stream())
 
 
 # ------------------------------------------------------------------------------------------------ conv wrappers
@@ -145,19 +168,23 @@ class ConvOp:
         return _geom(B=x.B, IH=x.H, IW=x.W, OHl=out.H, OWl=out.W, OHa=out.H, OWa=out.W, IS=self.s, IY0=-self.p,
                      IX0=-self.p, TH=self.k, TW=self.k, KWF=self.k, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
 
-    def forward(self, x: Img, out: Img):
+    def forward(self, x: Img, out: Img, keep_v: bool = False):
+        """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
         if wino_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W):
-            wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False), self.b, out.p, out.ld)
-            return
+            V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False), self.b, out.p, out.ld)
+            return V if keep_v and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
-    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False):
+    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False, V=None):
         dev = self.w.device
         k, s, p = self.k, self.s, self.p
         # weight gradient in igemm layout, then scattered (or accumulated) back to OIHW
         dwl = torch.empty(k, k, self.I, self.O, dtype=torch.float32, device=dev)
-        wgrad(x.p, dout.p, ptr(dwl), self._fwd_geom(x, dout), dev)
+        if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
+            wino_wgrad(x, dout, self.I, self.O, dwl, V)
+        else:
+            wgrad(x.p, dout.p, ptr(dwl), self._fwd_geom(x, dout), dev)
         relayout(dwl, dw, self.O, self.I, k, k, 0, inverse=True, accumulate=acc_params)
         if db is not None:
             colsum(dout, db, accumulate=acc_params)
@@ -275,8 +302,8 @@ class Net2DFunction(torch.autograd.Function):
             op = ConvOp(P[name + ".weight"], P[name + ".bias"] if bias else None, k, s, p)
             oh, ow = op.out_hw(x.H, x.W)
             out = out if out is not None else new_img(x.B, oh, ow, op.O, dev)
-            op.forward(x, out)
-            tape.append(("conv", name, op, x, out))
+            V = op.forward(x, out, keep_v=training)   # Winograd layers: the transformed input serves the weight gradient again
+            tape.append(("conv", name, op, x, out, V))
             return out
 
         def convT(name, x):
@@ -446,14 +473,14 @@ class Net2DFunction(torch.autograd.Function):
                 bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training, dg, db,
                        acc_params=pacc)
             elif kind == "conv":
-                _, name, op, x, out = rec
+                _, name, op, x, out, V = rec
                 dout = gmap.pop(key(out))
                 k = key(x)
                 acc = k in gmap
                 dx = gmap[k] if acc else like(x)
                 gmap[k] = dx
                 pg, pacc = sink.take(*([name + ".weight"] + ([name + ".bias"] if op.b is not None else [])))
-                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc)
+                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc, V=V)
             elif kind == "convT":
                 _, name, op, x, out = rec
                 dout = gmap.pop(key(out))

@@ -32,7 +32,8 @@ def _close(got, ref, rtol=1e-4, atol=2e-5):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,p,H,W", [(64, 64, 3, 1, 1, 19, 30), (64, 128, 3, 2, 1, 22, 36), (64, 128, 1, 2, 0, 22, 36),
-                                                (128, 64, 3, 1, 1, 16, 48), (256, 256, 3, 1, 1, 5, 7), (128, 256, 3, 2, 1, 9, 15)])
+                                                (128, 64, 3, 1, 1, 16, 48), (256, 256, 3, 1, 1, 5, 7), (128, 256, 3, 2, 1, 9, 15),
+                                                (128, 256, 3, 1, 1, 6, 11), (256, 128, 3, 1, 1, 18, 30)])   # Winograd fwd / dgrad / wgrad
 def test_conv_fwd_dgrad_wgrad(cin, cout, k, s, p, H, W):
     from mopa_amd.dense2d import ConvOp, Img, new_img
     rng = np.random.Generator(np.random.PCG64(cin + cout + k))
