@@ -69,7 +69,7 @@ SIGNATURES = {
     "mopa_wino_output": ("i", "piiiippiip"),
     "mopa_wino_dout": ("i", "piiiiipp"),
     "mopa_wino_wgrad_workspace_bytes": ("z", "iii"),
-    "mopa_wino_bwd_weight": ("i", "ppiiippzp"),
+    "mopa_wino_bwd_weight": ("i", "ppiiipipzp"),
     "mopa_conv2d_wgrad_workspace_bytes": ("z", "p"),
     "mopa_conv2d_bwd_weight": ("i", "ppppipzp"),
     "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),

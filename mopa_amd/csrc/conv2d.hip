@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
 
 // dw[i] (+)= sum_c slabs[c][i]: 16 chunk-lanes per element + fixed-order LDS reduction.
 __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
-                                                        int accumulate) {
+                                                        int accumulate, int oihw, int taps, int Cin, int Cout) {
   __shared__ float red[16][17];
   const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + el;
@@ -678,10 +678,17 @@ __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__
   red[cl][el] = s;
   __syncthreads();
   if (cl == 0 && i < n) {
-    float t = accumulate ? dw[i] : 0.f;
+    int64_t o = i;
+    if (oihw) {   // i = (tap * Cin + ci) * Cout + co  ->  torch's parameter layout [co][ci][tap]
+      const int co = (int)(i % Cout);
+      const int64_t r = i / Cout;
+      const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+      o = ((int64_t)co * Cin + ci) * taps + tap;
+    }
+    float t = accumulate ? dw[o] : 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][el];
-    dw[i] = t;
+    dw[o] = t;
   }
 }
 
@@ -725,10 +732,14 @@ MOPA_API size_t mopa_conv2d_wgrad_workspace_bytes(const int32_t* geom_host) {
 }
 
 // dweight[TH*TW][Cin][Cout] (logical taps, already in the igemm weight layout) (+)= sum_m A^T dY.
+// flags: bit 0 = accumulate into dweight; bit 1 = dweight is torch's OIHW parameter (gradient) tensor [Cout][Cin][TH][TW]
+// (only when the logical taps are the whole filter: forward geometry of a plain convolution).
 MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dweight, const int32_t* geom_host,
-                                    int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+                                    int32_t flags, void* ws, size_t ws_bytes, void* stream) {
   ConvGeom g;
   memcpy(&g, geom_host, sizeof(g));
+  const int accumulate = flags & 1, oihw = (flags >> 1) & 1;
+  if (oihw && (g.KS != 1 || g.KH0 != 0 || g.KW0 != 0 || g.KWF != g.TW)) return MOPA_ERR_ARG;
   if ((g.Cin % 64 != 0 && g.Cin != 16) || g.Cout % 64 != 0 || g.ld_in % 4 != 0 || g.ld_out % 4 != 0) return MOPA_ERR_ARG;
   if (ws_bytes < mopa_conv2d_wgrad_workspace_bytes(geom_host)) return MOPA_ERR_WORKSPACE;
   int ns, mps;
@@ -756,7 +767,7 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
     k_conv2d_wgrad<16, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
   }
   const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
-  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate);
+  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -766,9 +777,10 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
 // form):  dU[p][ci][co] = sum_t V[p][t][ci] * dM[p][t][co]  -- 16 independent 1x1 weight gradients over the T tiles, run as
 // ONE launch of the MFMA weight-gradient kernel (blockIdx.x = p), split over the tiles into slabs -- then
 // dW[a][b] = (G^T dU G)[a][b] while the slabs are summed in order (k_wino_dw; deterministic).  V = mopa_wino_input(x),
-// dM = mopa_wino_dout(dy) (wino2d.hip).  dweight: [3][3][Cin][Cout], the igemm layout of mopa_conv2d_bwd_weight.
+// dM = mopa_wino_dout(dy) (wino2d.hip).  dweight: [3][3][Cin][Cout] (the igemm layout of mopa_conv2d_bwd_weight) or OIHW.
 // block = 16 elements x 16 transform points: thread (e, p) sums its point's slabs in split order, then 16 threads transform
-__global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
+                                                  int accumulate, int oihw, int Cin, int Cout) {
   __shared__ float red[16][17];
   const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -788,11 +800,15 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs
     t[1][j] = 0.5f * (u[1][j] - u[2][j]);
     t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
   }
+  // igemm layout [tap][ci][co] (i = ci * Cout + co), or torch's OIHW [co][ci][tap]
+  const int co = (int)(i % Cout), ci = (int)(i / Cout);
+  const int64_t base = oihw ? ((int64_t)co * Cin + ci) * 9 : i, step = oihw ? 1 : n;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {  // (.) G
-    dw[(int64_t)(a * 3 + 0) * n + i] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
-    dw[(int64_t)(a * 3 + 1) * n + i] = 0.5f * (t[a][1] - t[a][2]);
-    dw[(int64_t)(a * 3 + 2) * n + i] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    float g0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]), g1 = 0.5f * (t[a][1] - t[a][2]), g2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    float* d = dw + base + (int64_t)(a * 3) * step;
+    if (accumulate) { g0 += d[0]; g1 += d[step]; g2 += d[2 * step]; }
+    d[0] = g0; d[step] = g1; d[2 * step] = g2;
   }
 }
 
@@ -813,8 +829,9 @@ MOPA_API size_t mopa_wino_wgrad_workspace_bytes(int32_t T, int32_t Cin, int32_t 
   return align_up((size_t)ns * 16 * Cin * Cout * sizeof(float), 256);
 }
 
-MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, void* ws,
-                                  size_t ws_bytes, void* stream) {
+// flags: bit 0 = accumulate into dweight; bit 1 = dweight is the OIHW parameter (gradient) tensor [Cout][Cin][3][3].
+MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, int32_t flags,
+                                  void* ws, size_t ws_bytes, void* stream) {
   if (T <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return MOPA_ERR_ARG;
   if ((int64_t)T * Cin >= (1ll << 30) || (int64_t)T * Cout >= (1ll << 30)) return MOPA_ERR_ARG;   // 32-bit byte offsets per point
   if (ws_bytes < mopa_wino_wgrad_workspace_bytes(T, Cin, Cout)) return MOPA_ERR_WORKSPACE;
@@ -830,7 +847,7 @@ MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, in
   dim3 grid(16, (Cin / 64) * (Cout / 64), ns);
   k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(V, dM, slabs, g, mps, (int64_t)T * Cin, (int64_t)T * Cout);
   const int64_t n = (int64_t)Cin * Cout;
-  k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight);
+  k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

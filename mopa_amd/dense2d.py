@@ -54,11 +54,12 @@ def igemm(x_ptr, w, bias, out_ptr, geom, accumulate=False):
     call("mopa_conv2d_igemm", x_ptr, ptr(w), ptr(bias), out_ptr, ctypes.addressof(geom), int(accumulate), stream())
 
 
-def wgrad(x_ptr, dy_ptr, dw_ptr, geom, dev, accumulate=False):
+def wgrad(x_ptr, dy_ptr, dw_ptr, geom, dev, accumulate=False, oihw=False):
+    """oihw: dw_ptr is the parameter-layout gradient tensor itself (plain convolutions only), not the igemm layout."""
     wsb = query("mopa_conv2d_wgrad_workspace_bytes", ctypes.addressof(geom))
     ws = _ws(wsb, dev)
-    call("mopa_conv2d_bwd_weight", x_ptr, dy_ptr, dw_ptr, ctypes.addressof(geom), int(accumulate), ptr(ws), ws.numel(),
-         stream())
+    call("mopa_conv2d_bwd_weight", x_ptr, dy_ptr, dw_ptr, ctypes.addressof(geom), int(accumulate) | (2 if oihw else 0), ptr(ws),
+         ws.numel(), stream())
 
 
 def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
@@ -138,10 +139,10 @@ def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
             and os.environ.get("MOPA_CONV2D_MFMA", "1") != "0" and os.environ.get("MOPA_WINOGRAD_WGRAD", "1") != "0")
 
 
-def wino_wgrad(x: Img, dout: Img, cin, cout, dwl, V=None):
-    """dwl[3][3][cin][cout] = weight gradient of conv3x3(x) given dout, through V = B^T x B (kept from the forward pass when
-    the caller has it), dM = A dout A^T."""
-    dev = dwl.device
+def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False):
+    """dw (OIHW, [cout][cin][3][3]) (+)= weight gradient of conv3x3(x) given dout, through V = B^T x B (kept from the forward
+    pass when the caller has it), dM = A dout A^T."""
+    dev = dw.device
     B, H, W = x.B, x.H, x.W
     T = B * ((H + 1) // 2) * ((W + 1) // 2)
     dM = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
@@ -150,7 +151,7 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dwl, V=None):
         call("mopa_wino_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
     call("mopa_wino_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
     ws = _ws(query("mopa_wino_wgrad_workspace_bytes", T, cin, cout), dev)
-    call("mopa_wino_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dwl), ptr(ws), ws.numel(), stream())
+    call("mopa_wino_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
 
 
 # ------------------------------------------------------------------------------------------------ conv wrappers
@@ -179,13 +180,11 @@ class ConvOp:
     def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False, V=None):
         dev = self.w.device
         k, s, p = self.k, self.s, self.p
-        # weight gradient in igemm layout, then scattered (or accumulated) back to OIHW
-        dwl = torch.empty(k, k, self.I, self.O, dtype=torch.float32, device=dev)
+        # weight gradient: the split-K reduction writes (or accumulates into) the OIHW gradient tensor directly
         if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
-            wino_wgrad(x, dout, self.I, self.O, dwl, V)
+            wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params)
         else:
-            wgrad(x.p, dout.p, ptr(dwl), self._fwd_geom(x, dout), dev)
-        relayout(dwl, dw, self.O, self.I, k, k, 0, inverse=True, accumulate=acc_params)
+            wgrad(x.p, dout.p, ptr(dw), self._fwd_geom(x, dout), dev, accumulate=acc_params, oihw=True)
         if db is not None:
             colsum(dout, db, accumulate=acc_params)
         if dx is None:
