@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm(const float* __restrict
 // vector-FMA kernel above (A/B measurements in DESIGN.md).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KB>
 __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __restrict__ in, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                const ConvGeom g, int accumulate, int64_t bs_in, int64_t bs_w,
@@ -198,25 +198,27 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
   out += blockIdx.z * bs_out;
   constexpr int MT = WM / 32, NT = WN / 32;
   static_assert((BM / WM) * (BN / WN) == 4 && WM % 32 == 0 && WN % 32 == 0, "four waves per block");
-  constexpr int AROWS = BM / 64;             // A float4 loads per thread per K-chunk
-  constexpr int BVEC = (BK * BN / 4) / 256;  // B float4 loads per thread per K-chunk
+  constexpr int KQ = KB / 4;                  // k-quads per row: the 256 threads stage RPP = 256 / KQ rows per pass
+  constexpr int RPP = 256 / KQ;
+  constexpr int AROWS = BM / RPP;             // A float4 loads per thread per K-chunk
+  constexpr int BVEC = (KB * BN / 4) / 256;   // B float4 loads per thread per K-chunk
   constexpr int BMP = BM + APAD;
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BMP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ __attribute__((aligned(16))) float As[2][KB][BMP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KB][BN];
   __shared__ int64_t rowoff[BM];             // output offset of each tile row (-1: beyond M)
   const int t = threadIdx.x;
   const int M = g.B * g.OHl * g.OWl;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int ohw = g.OHl * g.OWl;
-  // staging assignment: A row = t/4 + 64*j, k-quad = t%4.  Per row: input coordinates and element offset at tap (0,0);
+  // staging assignment: A row = t/KQ + RPP*j, k-quad = t%KQ.  Per row: input coordinates and element offset at tap (0,0);
   // a tap adds a uniform delta, a K-chunk a uniform channel offset -> the loads of the loop are `uniform base + 32-bit
   // per-lane offset` (saddr form, no 64-bit VALU), unconditional (rows outside the image read element 0 and are zeroed
   // when staged), and the per-lane offsets change once per tap only.
-  const int akq = t & 3, arow = t >> 2;
+  const int akq = t % KQ, arow = t / KQ;
   int ay0[AROWS], ax0[AROWS], abase[AROWS];
 #pragma unroll
   for (int j = 0; j < AROWS; ++j) {
-    const int m = m0 + arow + 64 * j;
+    const int m = m0 + arow + RPP * j;
     if (m < M) {
       const int b = m / ohw, r = m - b * ohw;
       const int oy = r / g.OWl, ox = r - oy * g.OWl;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
     }
     rowoff[r] = off;
   }
-  const int niter = g.TH * g.TW * (g.Cin / BK);
+  const int niter = g.TH * g.TW * (g.Cin / KB);
   float4 ra0[AROWS], rb0[BVEC];
   bool ok0[AROWS];
   uint32_t aoff[AROWS];
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
     for (int j = 0; j < BVEC; ++j) rb[j] = *reinterpret_cast<const float4*>(wc + boff[j]);
   };
   auto advance = [&]() {   // uniform: next K-chunk, next tap after the last chunk of this one
-    c0 += BK;
+    c0 += KB;
     if (c0 == g.Cin) {
       c0 = 0;
       if (++txx == g.TW) { txx = 0; ++tyy; }
@@ -282,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
   auto store_tile = [&](int buf, const float4* ra, const float4* rb, const bool* ok) {
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
-      As[buf][akq * 4 + 0][arow + 64 * j] = ok[j] ? ra[j].x : 0.f;
-      As[buf][akq * 4 + 1][arow + 64 * j] = ok[j] ? ra[j].y : 0.f;
-      As[buf][akq * 4 + 2][arow + 64 * j] = ok[j] ? ra[j].z : 0.f;
-      As[buf][akq * 4 + 3][arow + 64 * j] = ok[j] ? ra[j].w : 0.f;
+      As[buf][akq * 4 + 0][arow + RPP * j] = ok[j] ? ra[j].x : 0.f;
+      As[buf][akq * 4 + 1][arow + RPP * j] = ok[j] ? ra[j].y : 0.f;
+      As[buf][akq * 4 + 2][arow + RPP * j] = ok[j] ? ra[j].z : 0.f;
+      As[buf][akq * 4 + 3][arow + RPP * j] = ok[j] ? ra[j].w : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < BVEC; ++j) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   auto multiply = [&](int cur) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < KB; kk += 2) {
       float av[MT], bv[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) av[i] = As[cur][kk + lk][wm0 + i * 32 + l32];
@@ -390,11 +392,13 @@ static int igemm_launch(const float* in, const float* weight, const float* bias,
   if (tile < 0 || tile > 3 || g.Cout % kTiles[tile].bn) return MOPA_ERR_ARG;
   dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn, nbatch);
   if (use_mfma) {
+    // K-chunk depth 16.  (32 -- half the barriers per FLOP, twice the LDS and staging registers -- was measured: 128x64 tiles
+    // 115 -> 100 TFLOP/s, joint step 214 -> 196 scans/s: resident blocks per CU matter more than barriers here.)
     switch (tile) {
-      case 0: k_conv2d_igemm_mfma<256, 64, 64, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-      case 1: k_conv2d_igemm_mfma<128, 128, 64, 64><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-      case 2: k_conv2d_igemm_mfma<128, 64, 64, 32><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
-      default: k_conv2d_igemm_mfma<64, 64, 32, 32><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 0: k_conv2d_igemm_mfma<256, 64, 64, 64, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 1: k_conv2d_igemm_mfma<128, 128, 64, 64, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      case 2: k_conv2d_igemm_mfma<128, 64, 64, 32, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
+      default: k_conv2d_igemm_mfma<64, 64, 32, 32, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
     }
   } else {
     switch (tile) {
