@@ -82,7 +82,8 @@ class ConvTimer:
 
 
 class Conv2dTimer:
-    """HIP-event brackets around every dense implicit-GEMM launch of the 2D branch (fwd, dgrad, convT classes)."""
+    """HIP-event brackets around every launch of the dense implicit-GEMM kernel in the 2D branch (fwd, dgrad, convT classes,
+    the batched GEMMs of the Winograd layers)."""
 
     def __init__(self):
         self.records = []
@@ -107,6 +108,20 @@ class Conv2dTimer:
             timer.records.append((s, e, 4 * (M * cin + M * cout + taps * cin * cout), 2 * M * cout * taps * cin))
 
         dense2d.igemm = wrapped
+        inner_b = dense2d.igemm_batched
+
+        def wrapped_b(x_ptr, w_ptr, out_ptr, geom, nbatch, in_stride, w_stride, out_stride):   # the 16 GEMMs of a Winograd conv
+            if not timer.enabled:
+                return inner_b(x_ptr, w_ptr, out_ptr, geom, nbatch, in_stride, w_stride, out_stride)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            inner_b(x_ptr, w_ptr, out_ptr, geom, nbatch, in_stride, w_stride, out_stride)
+            e.record()
+            g = list(geom)
+            M, cin, cout = g[0] * g[3] * g[4], g[21], g[22]
+            timer.records.append((s, e, 4 * nbatch * (M * cin + M * cout + cin * cout), 2 * nbatch * M * cout * cin))
+
+        dense2d.igemm_batched = wrapped_b
 
     summary = ConvTimer.summary
 
@@ -357,11 +372,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = timer2d.enabled = True
+    # HIP-event brackets for the roofline figures on every EVENT_STRIDE-th timed step: on every step they cost 2.8 % (joint) /
+    # 4.4 % (3d) of `value` (MOPA_BENCH_EVENT_STRIDE=1 / =0 measure that: every step / never)
+    ev_stride = int(os.environ.get("MOPA_BENCH_EVENT_STRIDE", "4"))
+    n_ev_steps = 0
     t0 = time.perf_counter()
     per_step, step_times = [], os.environ.get("MOPA_BENCH_STEP_TIMES")
     ms0 = torch.cuda.memory_stats() if step_times else None
     for i in range(args.steps):
+        timer.enabled = timer2d.enabled = ev_stride > 0 and i % ev_stride == 0
+        n_ev_steps += int(timer.enabled)
         loss = step(i)
         if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
             if step_times == "sync":
@@ -393,7 +413,7 @@ def main():
         if ks:
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
-                  "launches_per_step": ks["launches"] // args.steps, "avg_launch_us": round(ks["avg_us"], 2),
+                  "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
         t3 = os.path.join(ROOT, "profiles", "r1_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d`
         if sp and os.path.exists(t3):
@@ -415,8 +435,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r1_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm_mfma (f32-operand MFMA, exact fp32; direct fwd + bwd-data + convT launches)",
-                    "launches_per_step": k2["launches"] // args.steps, "avg_launch_us": round(k2["avg_us"], 2),
+                    "kernel": "k_conv2d_igemm_mfma (f32-operand MFMA, exact fp32; conv fwd + bwd-data + convT + the Winograd layers' batched GEMMs)",
+                    "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "

@@ -54,6 +54,12 @@ def igemm(x_ptr, w, bias, out_ptr, geom, accumulate=False):
     call("mopa_conv2d_igemm", x_ptr, ptr(w), ptr(bias), out_ptr, ctypes.addressof(geom), int(accumulate), stream())
 
 
+def igemm_batched(x_ptr, w_ptr, out_ptr, geom, nbatch, in_stride, w_stride, out_stride):
+    """nbatch independent problems of one geometry in one launch (the 16 transform points of the Winograd path)."""
+    call("mopa_conv2d_igemm_batched", x_ptr, w_ptr, out_ptr, ctypes.addressof(geom), nbatch, in_stride, w_stride, out_stride, 0,
+         stream())
+
+
 def wgrad(x_ptr, dy_ptr, dw_ptr, geom, dev, accumulate=False, oihw=False):
     """oihw: dw_ptr is the parameter-layout gradient tensor itself (plain convolutions only), not the igemm layout."""
     wsb = query("mopa_conv2d_wgrad_workspace_bytes", ctypes.addressof(geom))
@@ -127,7 +133,7 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     M = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
     call("mopa_wino_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
-    call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, 0, stream())
+    igemm_batched(ptr(V), ptr(U), ptr(M), g1, 16, T * cin, cin * cout, T * cout)
     call("mopa_wino_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
     return V
 
@@ -286,6 +292,7 @@ class Net2DFunction(torch.autograd.Function):
         B, _, H, W = img.shape
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
         tape = []
+        nbt = []   # BatchNorm2d.num_batches_tracked of every layer that ran: bumped together at the end (one launch, not 43)
         ctx.bn_names = []
 
         def bn(name, x, act=1, res=None, out=None):
@@ -293,7 +300,7 @@ class Net2DFunction(torch.autograd.Function):
             stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
             bn_fwd(x, y, P, name, act, res, training, stats)
             if training:
-                P[name + ".num_batches_tracked"].add_(1)
+                nbt.append(P[name + ".num_batches_tracked"])
             tape.append(("bn", name, x, y, stats, act, res))
             return y
 
@@ -388,6 +395,8 @@ class Net2DFunction(torch.autograd.Function):
                  ptr(P["linear.bias"]), ptr(P["linear2.weight"]) if spec.dual_head else None,
                  ptr(P["linear2.bias"]) if spec.dual_head else None, ptr(feats), ptr(l1),
                  ptr(l2) if spec.dual_head else None, stream())
+        if nbt:
+            torch._foreach_add_(nbt, 1)
         ctx.spec, ctx.P, ctx.tape, ctx.J, ctx.training = spec, P, tape, J, training
         if DEBUG is not None:
             DEBUG.update({f"J{k}": v.clone() for k, v in J.items()})
