@@ -670,6 +670,119 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
   }
 }
 
+// Weight gradient of the 7x7 stem (16-wide taps: Cin = 16, TH x TW = 7 x 2, Cout = 64) on the matrix cores.  One block owns ALL
+// 14 taps over a slice of the pixels, so the output-gradient tile is read once (the per-filter-row blocks of the generic kernel
+// read it 7 times: that kernel is bound by those 2 GB, not by its FMAs).  GEMM rows = (tap, ci) = 224 = 7 row tiles of 32 (one
+// filter row each), 2 column tiles; wave w: column tile w & 1, row tiles (w >> 1), +2, +4(, +6).
+#define STEM_ROWS 224
+__global__ __launch_bounds__(256) void k_stem_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
+                                                          float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
+  __shared__ __attribute__((aligned(16))) float As[2][WBK][STEM_ROWS + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK][64 + 4];
+  const int t = threadIdx.x;
+  const int M = g.B * g.OHl * g.OWl, ohw = g.OHl * g.OWl;
+  const int mbeg = blockIdx.x * m_per_split, mend = min(M, mbeg + m_per_split);
+  const int lane = t & 63, wv = t >> 6;
+  const int wco = (wv & 1) * 32, rt0 = wv >> 1;
+  const int l32 = lane & 31, lk = lane >> 5;
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+  // staging: A = 16 pixels x 56 float4 (14 taps x 4 quads) = 896 float4 -> thread t takes idx = t + 256 j; B = 16 x 16 float4
+  int apx[4], aq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = t + 256 * j;
+    apx[j] = idx / 56;
+    aq[j] = idx - apx[j] * 56;
+  }
+  const int bpx = t >> 4, bq = t & 15;
+  float4 ra[4], rb;
+  // pixel (b, oy, ox) of each of this thread's 5 loads in the NEXT chunk: decomposed once, then advanced by WBK pixels per chunk
+  int pb[5], py[5], px[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int m = mbeg + (j < 4 ? apx[j] : bpx);
+    pb[j] = m / ohw;
+    const int r = m - pb[j] * ohw;
+    py[j] = r / g.OWl;
+    px[j] = r - py[j] * g.OWl;
+  }
+  auto load_tile = [&](int mb) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int b = pb[j], oy = py[j], ox = px[j];
+      px[j] += WBK;
+      while (px[j] >= g.OWl) {
+        px[j] -= g.OWl;
+        if (++py[j] == g.OHl) { py[j] = 0; ++pb[j]; }
+      }
+      if (j < 4) {
+        ra[j] = z;
+        if (t + 256 * j < 896 && mb + apx[j] < mend) {
+          const int tap = aq[j] >> 2, ty = tap >> 1, tx = tap & 1;
+          const int iy = oy * g.IS + g.IY0 + ty * g.IDY, ix = ox * g.IS + g.IX0 + tx * g.IDX;
+          if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+            ra[j] = *reinterpret_cast<const float4*>(in + ((int64_t)(b * g.IH + iy) * g.IW + ix) * g.ld_in + (aq[j] & 3) * 4);
+        }
+      } else {
+        rb = z;
+        if (mb + bpx < mend)
+          rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + bq * 4);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (t + 256 * j < 896) *reinterpret_cast<float4*>(&As[buf][apx[j]][aq[j] * 4]) = ra[j];
+    *reinterpret_cast<float4*>(&Bs[buf][bpx][bq * 4]) = rb;
+  };
+  int buf = 0;
+  if (mbeg < mend) {
+    load_tile(mbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int mb = mbeg; mb < mend; mb += WBK) {
+    const bool more = mb + WBK < mend;
+    if (more) load_tile(mb + WBK);
+#pragma unroll
+    for (int kk = 0; kk < WBK; kk += 2) {
+      const float bv = Bs[buf][kk + lk][wco + l32];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int rt = rt0 + 2 * n;
+        if (rt < 7) {   // uniform per wave
+          const float av = As[buf][kk + lk][rt * 32 + l32];
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  float* dst = slabs + (int64_t)blockIdx.x * STEM_ROWS * 64 + wco + l32;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int rt = rt0 + 2 * n;
+    if (rt < 7) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[(int64_t)(rt * 32 + 8 * (e >> 2) + 4 * lk + (e & 3)) * 64] = acc[n][e];
+    }
+  }
+}
+static bool stem_wgrad_mfma(const ConvGeom& g) {
+  static const bool env_mfma = [] { const char* e = getenv("MOPA_CONV2D_MFMA"); return !e || atoi(e) != 0; }();
+  return env_mfma && g.Cin == 16 && g.TW == 2 && g.TH == 7 && g.Cout == 64;
+}
+
 // dw[i] (+)= sum_c slabs[c][i]: 16 chunk-lanes per element + fixed-order LDS reduction.
 __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
                                                         int accumulate, int oihw, int taps, int Cin, int Cout) {
@@ -715,6 +828,14 @@ static int wgrad_nco(const ConvGeom& g) { return 1; }
 
 static void wgrad_split(const ConvGeom& g, int* nsplit, int* m_per_split) {
   const int64_t M = (int64_t)g.B * g.OHl * g.OWl;
+  if (stem_wgrad_mfma(g)) {   // one block per pixel slice covers all taps and channels
+    int64_t ns = cdiv64(M, 1152);
+    if (ns > 1024) ns = 1024;
+    const int64_t mps = cdiv64(cdiv64(M, ns), WBK) * WBK;
+    *nsplit = (int)cdiv64(M, mps);
+    *m_per_split = (int)mps;
+    return;
+  }
   const int wm = g.Cin >= 64 ? 64 : 16;
   const int64_t tiles = (int64_t)(g.TH * g.TW / wgrad_ntap(g)) * (g.Cin / wm) * (g.Cout / (64 * wgrad_nco(g)));
   int64_t ns = cdiv64(2048, tiles);   // (768 ... 3072 target blocks measured: +-1 % on the joint step)
@@ -763,6 +884,8 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
     } else {
       k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     }
+  } else if (stem_wgrad_mfma(g)) {
+    k_stem_wgrad_mfma<<<ns, 256, 0, st>>>(in, dy, slabs, g, mps);
   } else if (wgrad_ntap(g) == 2) {
     dim3 grid(g.TH * g.TW / 2, g.Cout / 64, ns);
     k_conv2d_wgrad<16, 2><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
