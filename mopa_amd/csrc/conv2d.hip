@@ -791,6 +791,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__
   const int64_t i = (int64_t)blockIdx.x * 16 + el;
   float s = 0.f;
   if (i < n)
+#pragma unroll 8
     for (int c = cl; c < nsplit; c += 16) s += slabs[(int64_t)c * n + i];
   red[cl][el] = s;
   __syncthreads();
@@ -913,6 +914,7 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
   float s = 0.f;
   if (i < n)
+#pragma unroll 8
     for (int c = 0; c < nsplit; ++c) s += slabs[((int64_t)c * 16 + p) * n + i];
   red[p][e] = s;
   __syncthreads();

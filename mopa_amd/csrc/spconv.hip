@@ -1335,6 +1335,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
   const int64_t i = (int64_t)blockIdx.x * 16 + el;
   float s = 0.f;
   if (i < n)
+#pragma unroll 8
     for (int c = cl; c < nchunks; c += 16) s += slabs[(int64_t)c * n + i];
   red[cl][el] = s;
   __syncthreads();
