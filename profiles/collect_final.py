@@ -5,13 +5,13 @@ R = os.path.dirname(os.path.abspath(__file__))
 F = os.path.join(R, "..", "gpurun_out", "final")
 TITLE = {"3d": "Net3DSeg-only training step (bs 8, 1x MI355X) -- BASELINE configs[1]",
          "joint": "joint 2D+3D xMUDA step (bs 8+8, 1x MI355X) -- BASELINE configs[2]"}
-CMD = {"3d": "python bench.py --workload 3d", "joint": "python bench.py"}
+CMD = {"3d": "python bench.py --workload 3d --steps 50 --warmup 5", "joint": "python bench.py --steps 10 --warmup 3"}
 for w in ("3d", "joint"):
     line = open(os.path.join(F, f"bench_{w}.json")).read().strip().splitlines()[-1]
     json.loads(line)
     stats = open(os.path.join(F, f"stats_{w}.md")).read()
     with open(os.path.join(R, f"r1_final_{w}_kernel_stats.md"), "w") as f:
-        f.write(f"# Round 1 final: {TITLE[w]}\n\nCommands (profiles/make_final.sh): `{CMD[w]} --steps 10 --warmup 3` (bench line) and `rocprofv3 --kernel-trace "
+        f.write(f"# Round 1 final: {TITLE[w]}\n\nCommands (profiles/make_final.sh): `{CMD[w]}` (bench line) and `rocprofv3 --kernel-trace "
                 f"--stats --output-format csv -- python3 bench.py ... --steps 3 --warmup 1 --no-cpu-baseline` (4 steps traced"
                 + ("; the 3D branch runs on a second stream, so kernel times overlap and their sum exceeds wall time" if w == "joint" else "")
                 + f").\n\n```\n{line}\n```\n\n{stats}")
