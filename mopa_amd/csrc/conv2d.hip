@@ -325,8 +325,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_igemm_mfma(const float* __res
   load_tile(ra0, rb0, ok0);
   store_tile(0, ra0, rb0, ok0);
   __syncthreads();
-  // (a second register stage -- loads two chunks ahead -- was measured: +8 % on the direct small-M shapes, -4 % on the
-  // batched Winograd GEMMs that carry those layers, 118 -> 162 VGPRs: not kept)
+  // PMC (profiles/pmc_igemm.sh): the MFMA pipe is busy 73 % of the time at 5 waves per SIMD; the waves wait on the loaded
+  // L2 / Infinity-Cache latency of the next chunk (with the loads removed the loop reaches 83 %).  A second register stage
+  // (loads two chunks ahead) was measured twice: +8 % on small-M direct shapes with 64x64 tiles, -4 % on the batched Winograd
+  // GEMMs that now carry those layers, +-0 on the 128x64 long-K convs (joint step 222.1 vs 222.4 scans/s): not kept.
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
     const int cur = it & 1;
