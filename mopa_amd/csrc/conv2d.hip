@@ -395,7 +395,8 @@ static int igemm_launch(const float* in, const float* weight, const float* bias,
   dim3 grid((unsigned)cdiv64(M, kTiles[tile].bm), g.Cout / kTiles[tile].bn, nbatch);
   if (use_mfma) {
     // K-chunk depth 16.  (32 -- half the barriers per FLOP, twice the LDS and staging registers -- was measured: 128x64 tiles
-    // 115 -> 100 TFLOP/s, joint step 214 -> 196 scans/s: resident blocks per CU matter more than barriers here.)
+    // 115 -> 100 TFLOP/s, joint step 214 -> 196 scans/s: resident blocks per CU matter more than barriers here; 8 -- twice the
+    // resident blocks, half the MFMAs per barrier -- 222 -> 217.)
     switch (tile) {
       case 0: k_conv2d_igemm_mfma<256, 64, 64, 64, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
       case 1: k_conv2d_igemm_mfma<128, 128, 64, 64, 16><<<grid, 256, 0, st>>>(in, weight, bias, out, g, accumulate, bs_in, bs_w, bs_out); break;
