@@ -333,7 +333,8 @@ def main():
             l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
             l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
-            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]]})                # third 3D pass on the VGI-style batch
+            gv = dual.geometry_ahead(model3d, b["vgi_locs"], resident) if geom_ahead else None
+            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]], "geometry_3d": gv})   # third 3D pass on the VGI-style batch
             l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
         if bwd3_first:   # the 3D backward (side stream) starts as soon as its loss gradient exists, beside the 2D backward
             l3.backward()
@@ -351,7 +352,8 @@ def main():
             loss = loss + half(batches[1], 0.1, False)  # target: lambda_xm_trg * KL        (yaml :57)
         else:
             b = batches[i % 2]
-            geom = Geometry3D(b["locs"], 7, 4096, dev)
+            # the voxel geometry depends on the coordinates only: built beside the previous step's backward (loader-side work)
+            geom = dual.geometry_ahead(model3d, b["locs"], resident) if geom_ahead else Geometry3D(b["locs"], 7, 4096, dev)
             out = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
             loss = seg_ce(out["seg_logit"], b["label"], cw) + seg_ce(out["seg_logit2"], b["label"], cw)
             loss.backward()

@@ -126,6 +126,24 @@ class Geometry3D:
     def rulebook(self, table: torch.Tensor):
         return self._rb.get(table.data_ptr())
 
+    def tensors(self):
+        """Every device tensor this geometry owns."""
+        out = [self.point_row, self.row_start, self.row_points]
+        for lst in (self.row_keys, self.parent, self.nbr27, self.ch, self.up):
+            out += list(lst)
+        for rb in self._rb.values():
+            out += list(rb)
+        return out
+
+    def record_stream(self, stream):
+        """The geometry was built on another stream than the one that will use it: tell the caching allocator (its memory must
+        not return to the building stream's pool while `stream` still reads it)."""
+        seen = set()
+        for t in self.tensors():
+            if t.data_ptr() not in seen and t.numel():
+                seen.add(t.data_ptr())
+                t.record_stream(stream)
+
     @property
     def num_rules(self):
         return [int((n >= 0).sum().item()) for n in self.nbr27]

@@ -38,6 +38,20 @@ class DualStream:
                 t.record_stream(main)
         return preds_2d, preds_3d
 
+    def geometry_ahead(self, model_3d, locs, inputs_ready):
+        """Voxel geometry of `locs` for a 3D pass that will run on the CURRENT stream, built on the side stream behind
+        `inputs_ready` only: its two host syncs then wait for the (short) side-stream queue instead of everything queued on
+        the current stream.  Pass the result as ``batch["geometry_3d"]``."""
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(inputs_ready)
+            geom = model_3d.net_3d.geometry(locs)
+            built = torch.cuda.Event()
+            built.record()
+        cur.wait_event(built)
+        geom.record_stream(cur)
+        return geom
+
     def join(self):
         """Call after the backward passes, before reducing / applying the 3D network's gradients."""
         torch.cuda.current_stream(self.device).wait_stream(self.side)

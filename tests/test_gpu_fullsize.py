@@ -243,6 +243,40 @@ def test_dual_stream_is_bit_identical_to_sequential():
     assert all(torch.equal(x, y) for x, y in zip(g_seq, g_ahead))
 
 
+def test_geometry_built_ahead_on_the_side_stream_gives_the_same_results():
+    """DualStream.geometry_ahead: geometry built on the side stream, consumed by a 3D pass on the current stream."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import seg_ce
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    from mopa_amd.step import DualStream
+    b = synth.make_batch(2, H=64, W=96)
+    lab = b["seg_label"].cuda()
+    ready = torch.cuda.Event()
+    ready.record()
+
+    def run(ahead):
+        torch.manual_seed(0)
+        m3 = build_model_3d(default_cfg())[0].cuda().train()
+        dual = DualStream("cuda")
+        outs = []
+        for _ in range(3):   # back to back: the allocator must not hand a geometry's memory out while the main stream reads it
+            batch = {"x": b["x"]}
+            if ahead:
+                batch["geometry_3d"] = dual.geometry_ahead(m3, b["x"][0], ready)
+            o = m3(batch)
+            seg_ce(o["seg_logit"], lab).backward()
+            outs.append(o["seg_logit"].detach())
+            del o, batch
+        torch.cuda.synchronize()
+        return outs, [p.grad.clone() for p in m3.parameters() if p.grad is not None]   # (the second head is unused here)
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert all(torch.equal(x, y) for x, y in zip(o0, o1))
+    assert all(torch.equal(x, y) for x, y in zip(g0, g1))
+
+
 def test_no_reference_cycle_pins_activations():
     """A step must free its activations by reference counting alone.  (An output tensor kept on ctx, or a recursive closure in
     forward, is a cycle that only the cyclic GC frees: the allocator then grows by the activations of every step -- 2 GB per
