@@ -70,6 +70,12 @@ SIGNATURES = {
     "mopa_wino_dout": ("i", "piiiiipp"),
     "mopa_wino_wgrad_workspace_bytes": ("z", "iii"),
     "mopa_wino_bwd_weight": ("i", "ppiiipipzp"),
+    "mopa_wino4_weight": ("i", "piiipp"),
+    "mopa_wino4_input": ("i", "piiiiipp"),
+    "mopa_wino4_output": ("i", "piiiippiip"),
+    "mopa_wino4_dout": ("i", "piiiiipp"),
+    "mopa_wino4_wgrad_workspace_bytes": ("z", "iii"),
+    "mopa_wino4_bwd_weight": ("i", "ppiiipipzp"),
     "mopa_conv2d_wgrad_workspace_bytes": ("z", "p"),
     "mopa_conv2d_bwd_weight": ("i", "ppppipzp"),
     "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),

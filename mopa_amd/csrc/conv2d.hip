@@ -944,8 +944,48 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs
   }
 }
 
-static void wino_wgrad_split(int64_t T, int Cin, int Cout, int* nsplit, int* m_per_split) {
-  const int64_t tiles = (int64_t)16 * (Cin / 64) * (Cout / 64);
+// F(4x4,3x3): 36 points, dW = G^T dU G with the 6x3 G.  block = 16 elements x 16 threads, thread (e, q) sums points q, q+16, q+32.
+__global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
+                                                   int accumulate, int oihw, int Cin, int Cout) {
+  __shared__ float red[36][17];
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int p = q + 16 * j;
+    if (p < 36) {
+      float s = 0.f;
+      if (i < n)
+        for (int c = 0; c < nsplit; ++c) s += slabs[((int64_t)c * 36 + p) * n + i];
+      red[p][e] = s;
+    }
+  }
+  __syncthreads();
+  if (q != 0 || i >= n) return;
+  float t[3][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {   // G^T u, column by column
+    const float u0 = red[0 * 6 + j][e], u1 = red[1 * 6 + j][e], u2 = red[2 * 6 + j][e], u3 = red[3 * 6 + j][e], u4 = red[4 * 6 + j][e],
+                u5 = red[5 * 6 + j][e];
+    t[0][j] = 0.25f * u0 - (1.f / 6.f) * (u1 + u2) + (1.f / 24.f) * (u3 + u4);
+    t[1][j] = (1.f / 6.f) * (u2 - u1) + (1.f / 12.f) * (u3 - u4);
+    t[2][j] = -(1.f / 6.f) * (u1 + u2) + (1.f / 6.f) * (u3 + u4) + u5;
+  }
+  const int co = (int)(i % Cout), ci = (int)(i / Cout);
+  const int64_t base = oihw ? ((int64_t)co * Cin + ci) * 9 : i, step = oihw ? 1 : n;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {   // (.) G
+    float g0 = 0.25f * t[a][0] - (1.f / 6.f) * (t[a][1] + t[a][2]) + (1.f / 24.f) * (t[a][3] + t[a][4]);
+    float g1 = (1.f / 6.f) * (t[a][2] - t[a][1]) + (1.f / 12.f) * (t[a][3] - t[a][4]);
+    float g2 = -(1.f / 6.f) * (t[a][1] + t[a][2]) + (1.f / 6.f) * (t[a][3] + t[a][4]) + t[a][5];
+    float* d = dw + base + (int64_t)(a * 3) * step;
+    if (accumulate) { g0 += d[0]; g1 += d[step]; g2 += d[2 * step]; }
+    d[0] = g0; d[step] = g1; d[2 * step] = g2;
+  }
+}
+
+static void wino_wgrad_split(int np, int64_t T, int Cin, int Cout, int* nsplit, int* m_per_split) {
+  const int64_t tiles = (int64_t)np * (Cin / 64) * (Cout / 64);
   int64_t ns = cdiv64(2048, tiles);
   const int64_t maxs = cdiv64(T, 128);
   if (ns > maxs) ns = maxs;
@@ -955,20 +995,19 @@ static void wino_wgrad_split(int64_t T, int Cin, int Cout, int* nsplit, int* m_p
   *m_per_split = (int)mps;
 }
 
-MOPA_API size_t mopa_wino_wgrad_workspace_bytes(int32_t T, int32_t Cin, int32_t Cout) {
+static size_t wino_wgrad_ws(int np, int32_t T, int32_t Cin, int32_t Cout) {
   int ns, mps;
-  wino_wgrad_split(T, Cin, Cout, &ns, &mps);
-  return align_up((size_t)ns * 16 * Cin * Cout * sizeof(float), 256);
+  wino_wgrad_split(np, T, Cin, Cout, &ns, &mps);
+  return align_up((size_t)ns * np * Cin * Cout * sizeof(float), 256);
 }
 
-// flags: bit 0 = accumulate into dweight; bit 1 = dweight is the OIHW parameter (gradient) tensor [Cout][Cin][3][3].
-MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, int32_t flags,
-                                  void* ws, size_t ws_bytes, void* stream) {
+static int wino_bwd_weight(int np, const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, int32_t flags,
+                           void* ws, size_t ws_bytes, void* stream) {
   if (T <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return MOPA_ERR_ARG;
   if ((int64_t)T * Cin >= (1ll << 30) || (int64_t)T * Cout >= (1ll << 30)) return MOPA_ERR_ARG;   // 32-bit byte offsets per point
-  if (ws_bytes < mopa_wino_wgrad_workspace_bytes(T, Cin, Cout)) return MOPA_ERR_WORKSPACE;
+  if (ws_bytes < wino_wgrad_ws(np, T, Cin, Cout)) return MOPA_ERR_WORKSPACE;
   int ns, mps;
-  wino_wgrad_split(T, Cin, Cout, &ns, &mps);
+  wino_wgrad_split(np, T, Cin, Cout, &ns, &mps);
   ConvGeom g;
   memset(&g, 0, sizeof(g));
   g.B = 1; g.IH = 1; g.IW = T; g.OHl = 1; g.OWl = T; g.OHa = 1; g.OWa = T;
@@ -976,12 +1015,26 @@ MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, in
   g.Cin = Cin; g.Cout = Cout; g.ld_in = Cin; g.ld_out = Cout;
   hipStream_t st = (hipStream_t)stream;
   float* slabs = (float*)ws;
-  dim3 grid(16, (Cin / 64) * (Cout / 64), ns);
+  dim3 grid(np, (Cin / 64) * (Cout / 64), ns);
   k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(V, dM, slabs, g, mps, (int64_t)T * Cin, (int64_t)T * Cout);
   const int64_t n = (int64_t)Cin * Cout;
-  k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
+  if (np == 16) k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
+  else k_wino4_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
+}
+
+MOPA_API size_t mopa_wino_wgrad_workspace_bytes(int32_t T, int32_t Cin, int32_t Cout) { return wino_wgrad_ws(16, T, Cin, Cout); }
+// flags: bit 0 = accumulate into dweight; bit 1 = dweight is the OIHW parameter (gradient) tensor [Cout][Cin][3][3].
+MOPA_API int mopa_wino_bwd_weight(const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, int32_t flags,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  return wino_bwd_weight(16, V, dM, T, Cin, Cout, dweight, flags, ws, ws_bytes, stream);
+}
+// The same for F(4x4,3x3): V / dM hold 36 points (mopa_wino4_input / mopa_wino4_dout), T = B * ceil(H/4) * ceil(W/4).
+MOPA_API size_t mopa_wino4_wgrad_workspace_bytes(int32_t T, int32_t Cin, int32_t Cout) { return wino_wgrad_ws(36, T, Cin, Cout); }
+MOPA_API int mopa_wino4_bwd_weight(const float* V, const float* dM, int32_t T, int32_t Cin, int32_t Cout, float* dweight, int32_t flags,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  return wino_bwd_weight(36, V, dM, T, Cin, Cout, dweight, flags, ws, ws_bytes, stream);
 }
 
 // ----------------------------------------------------------------------------------------------

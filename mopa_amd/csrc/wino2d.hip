@@ -221,3 +221,222 @@ MOPA_API int mopa_wino_dout(const float* dy, int32_t ld, int32_t B, int32_t H, i
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
+
+// ================================================================================================================
+// Winograd F(4x4, 3x3): 6x6 input patch -> 4x4 outputs, 36 transform points, 4x fewer multiplies than the direct conv (F(2x2):
+// 2.25x) and LESS transform traffic (V and M are 36/16 = 2.25x the activations instead of 4x).  Lavin & Gray's matrices:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 error is about 10x that of the direct sum (still ~1e-6 relative per layer); used where it pays (dense2d.wino_tile).
+// Thread = (tile, channel): consecutive lanes are consecutive channels, every access is a coalesced 256-byte run.
+__device__ __forceinline__ void w4_bt(const float d[6], float t[6]) {   // t = B^T d
+  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void w4_at(const float m[6], float y[4]) {   // y = A^T m
+  const float a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
+  y[0] = m[0] + a + c;
+  y[1] = b + 2.f * e;
+  y[2] = a + 4.f * c;
+  y[3] = b + 8.f * e + m[5];
+}
+__device__ __forceinline__ void w4_a(const float d[4], float r[6]) {    // r = A d  (A = (A^T)^T, 6x4)
+  r[0] = d[0];
+  r[1] = d[0] + d[1] + d[2] + d[3];
+  r[2] = d[0] - d[1] + d[2] - d[3];
+  r[3] = d[0] + 2.f * d[1] + 4.f * d[2] + 8.f * d[3];
+  r[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
+  r[5] = d[3];
+}
+__device__ __forceinline__ void w4_g(const float g[3], float t[6]) {    // t = G g
+  t[0] = 0.25f * g[0];
+  t[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
+  t[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
+  t[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+  t[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+  t[5] = g[2];
+}
+__device__ __forceinline__ void w4_gt(const float u[6], float g[3]) {   // g = G^T u
+  g[0] = 0.25f * u[0] - (1.f / 6.f) * (u[1] + u[2]) + (1.f / 24.f) * (u[3] + u[4]);
+  g[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
+  g[2] = -(1.f / 6.f) * (u[1] + u[2]) + (1.f / 6.f) * (u[3] + u[4]) + u[5];
+}
+
+// U[p][r][c] (p = 6*i + j) = (G g G^T)[p]; dgrad as in k_wino_w
+__global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U) {
+  const int R = dgrad ? O : I, C = dgrad ? I : O;
+  const int n = R * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r = i / C, c = i - r * C;
+    const int o = dgrad ? r : c, ci = dgrad ? c : r;
+    const float* g9 = w + ((int64_t)o * I + ci) * 9;
+    float t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float col[3], tc[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) col[a] = dgrad ? g9[(2 - a) * 3 + (2 - b)] : g9[a * 3 + b];
+      w4_g(col, tc);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a][b] = tc[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float u[6];
+      w4_g(t[a], u);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * n + i] = u[b];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, int ld_in, int B, int H, int W, int C, int th, int tw,
+                                                   float* __restrict__ V) {
+  const int64_t T = (int64_t)B * th * tw;
+  const int64_t total = T * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / C;
+    const int ch = (int)(i - t * C);
+    const int b = (int)(t / (th * tw));
+    const int rt = (int)(t - (int64_t)b * th * tw);
+    const int ty = rt / tw, tx = rt - ty * tw;
+    float m[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {   // B^T d, column by column
+      const int x = 4 * tx - 1 + c;
+      float d[6], tc[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int y = 4 * ty - 1 + a;
+        d[a] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? in[((int64_t)(b * H + y) * W + x) * ld_in + ch] : 0.f;
+      }
+      w4_bt(d, tc);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m[a][c] = tc[a];
+    }
+    float* vp = V + t * C + ch;
+    const int64_t ps = T * C;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {   // (.) B
+      float v[6];
+      w4_bt(m[a], v);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) vp[(a * 6 + c) * ps] = v[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ M, int B, int H, int W, int C, int th, int tw,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out, int accumulate) {
+  const int64_t T = (int64_t)B * th * tw;
+  const int64_t total = T * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / C;
+    const int ch = (int)(i - t * C);
+    const int b = (int)(t / (th * tw));
+    const int rt = (int)(t - (int64_t)b * th * tw);
+    const int ty = rt / tw, tx = rt - ty * tw;
+    const float* mp = M + t * C + ch;
+    const int64_t ps = T * C;
+    float s[4][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {   // A^T m, column by column
+      float m[6], y[4];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m[a] = mp[(a * 6 + c) * ps];
+      w4_at(m, y);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s[a][c] = y[a];
+    }
+    const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {   // (.) A
+      const int y = 4 * ty + a;
+      if (y >= H) continue;
+      float o[4];
+      w4_at(s[a], o);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int x = 4 * tx + c;
+        if (x >= W) continue;
+        float* p = out + ((int64_t)(b * H + y) * W + x) * ld_out + ch;
+        float v = o[c] + bv;
+        if (accumulate) v += *p;
+        *p = v;
+      }
+    }
+  }
+}
+
+// dM[p][t][co] = (A dY A^T)[p] per 4x4 output-gradient tile (zero beyond H, W): second operand of the transform-domain weight gradient
+__global__ __launch_bounds__(256) void k_wino4_dout(const float* __restrict__ dy, int ld, int B, int H, int W, int C, int th, int tw,
+                                                     float* __restrict__ dM) {
+  const int64_t T = (int64_t)B * th * tw;
+  const int64_t total = T * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / C;
+    const int ch = (int)(i - t * C);
+    const int b = (int)(t / (th * tw));
+    const int rt = (int)(t - (int64_t)b * th * tw);
+    const int ty = rt / tw, tx = rt - ty * tw;
+    float r[6][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // A dY, column by column
+      const int x = 4 * tx + c;
+      float d[4], rc[6];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int y = 4 * ty + a;
+        d[a] = (y < H && x < W) ? dy[((int64_t)(b * H + y) * W + x) * ld + ch] : 0.f;
+      }
+      w4_a(d, rc);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][c] = rc[a];
+    }
+    float* mp = dM + t * C + ch;
+    const int64_t ps = T * C;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {   // (.) A^T
+      float m[6];
+      w4_a(r[a], m);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mp[(a * 6 + c) * ps] = m[c];
+    }
+  }
+}
+
+// F(4x4,3x3) entry points: same contracts as mopa_wino_weight / _input / _output / _dout with 36 transform points and
+// T = B * ceil(H/4) * ceil(W/4) tiles.
+MOPA_API int mopa_wino4_weight(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* U, void* stream) {
+  if (O <= 0 || I <= 0) return MOPA_ERR_ARG;
+  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, U);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+MOPA_API int mopa_wino4_input(const float* in, int32_t ld_in, int32_t B, int32_t H, int32_t W, int32_t C, float* V, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  k_wino4_in<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+MOPA_API int mopa_wino4_output(const float* M, int32_t B, int32_t H, int32_t W, int32_t C, const float* bias, float* out, int32_t ld_out,
+                               int32_t accumulate, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_out < C) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  k_wino4_out<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(M, B, H, W, C, th, tw, bias, out, ld_out, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* dM, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  k_wino4_dout<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(dy, ld, B, H, W, C, th, tw, dM);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

@@ -104,60 +104,86 @@ def relayout_cached(w, shape, O, I, KH, KW, mode):
     return _cached_weight_form(w, ("relayout", mode), build)
 
 
-def wino_weight_cached(w, dgrad: bool):
-    """U[16][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version."""
+def wino_weight_cached(w, dgrad: bool, F: int = 2):
+    """U[(F+2)^2][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version."""
     O, I = w.shape[0], w.shape[1]
 
     def build():
-        u = torch.empty(16, (O if dgrad else I), (I if dgrad else O), dtype=torch.float32, device=w.device)
-        call("mopa_wino_weight", ptr(w), O, I, int(dgrad), ptr(u), stream())
+        u = torch.empty((F + 2) ** 2, (O if dgrad else I), (I if dgrad else O), dtype=torch.float32, device=w.device)
+        call("mopa_wino_weight" if F == 2 else "mopa_wino4_weight", ptr(w), O, I, int(dgrad), ptr(u), stream())
         return u
-    return _cached_weight_form(w, ("wino", int(dgrad)), build)
+    return _cached_weight_form(w, ("wino", F, int(dgrad)), build)
+
+
+def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
+    """Which algorithm runs a stride-1 3x3 convolution (and its backward-data): 0 = direct implicit GEMM, 2 = Winograd
+    F(2x2,3x3), 4 = F(4x4,3x3).  Measured against the direct MFMA kernel at batch 8 (profiles/bench_wino.py):
+    F(4x4) -- 4x fewer multiplies, V / M = 2.25x the activations, ~1e-5 relative error -- 1.2x at 64^2 152x240, 1.4x at
+    128->64 152x240, 2.0x at 128^2 76x120, 2.7x at 256^2 38x60, 3.5x at 512^2 19x30; F(2x2) -- 2.25x fewer multiplies, V / M =
+    4x the activations, ~2e-6 -- 0.8x / 0.9x / 1.3x / 1.8x / 2.4x on the same shapes: it remains for maps below 8 pixels
+    (MOPA_WINOGRAD_F4=0 forces it where it is eligible)."""
+    if not (k == 3 and s == 1 and p == 1 and cin % 16 == 0 and cout % 64 == 0 and os.environ.get("MOPA_WINOGRAD", "1") != "0"):
+        return 0
+    if (role in F4_ROLES and min(H, W) >= 8 and B * H * W < F4_MAX_PIXELS
+            and (role != "fwd" or B * H * W >= F4_FWD_MIN_PIXELS)):
+        return 4
+    return 2 if max(cin, cout) >= 128 and B * H * W < 200000 else 0
+
+
+F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "1500000"))
+# Which passes may use F(4x4): by default the two backward passes, where its rounding error (~1e-5 relative per layer) is a
+# linear perturbation -- logits stay bit-identical and the gradients stay as close to the fp64 oracle as with F(2x2) (tests).
+# In the FORWARD pass the same error also moves a few ReLU pre-activations across zero; layers that normalise over few samples
+# amplify such a flip (measured on a 2 x 160 x 224 input: median gradient error against fp64 1.4 % -> 1.7 %, single tensors of
+# layer4 -- 70 samples per channel -- 1.5 % -> 17 %).  It is worth another 10 % of throughput (239 -> 263 scans/s on the joint
+# step) and its logits stay within the parity tolerance, so it is an opt-in: MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad; even then
+# the forward pass keeps F(2x2) below F4_FWD_MIN_PIXELS samples per channel.
+F4_ROLES = tuple(r for r in os.environ.get("MOPA_WINOGRAD_F4_ROLES", "dgrad,wgrad").split(",") if r) \
+    if os.environ.get("MOPA_WINOGRAD_F4", "1") != "0" else ()
+F4_FWD_MIN_PIXELS = 4096
 
 
 def wino_eligible(cin, cout, k, s, p, B, H, W):
-    """Winograd F(2x2,3x3) beats the direct implicit GEMM (both on f32 MFMA) for stride-1 3x3 convs with >= 128 channels
-    on one side up to 76x120 at batch 8 (profiles/bench_wino.py: 1.2x at 128^2 76x120, 1.4x at 256->128, 1.9x at 256^2 and
-    512->256 38x60, 2.4x at 512^2 19x30; 0.96x at 128->64 152x240 and 0.73x at 64^2: there the V / M traffic -- 4x the
-    activations, written and read -- costs more than the saved multiplies)."""
-    return (k == 3 and s == 1 and p == 1 and max(cin, cout) >= 128 and cin % 16 == 0 and cout % 64 == 0
-            and B * H * W < 200000 and os.environ.get("MOPA_WINOGRAD", "1") != "0")
+    return wino_tile(cin, cout, k, s, p, B, H, W) != 0
 
 
-def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False):
-    """out = conv3x3(x) (+ bias) through k_wino_in -> 16 batched GEMMs -> k_wino_out."""
+def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2):
+    """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform."""
     dev = U.device
-    th, tw = (H + 1) // 2, (W + 1) // 2
-    T = B * th * tw
-    V = torch.empty(16 * T * cin, dtype=torch.float32, device=dev)
-    M = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
-    call("mopa_wino_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
+    th, tw = (H + F - 1) // F, (W + F - 1) // F
+    T, NP = B * th * tw, (F + 2) ** 2
+    sfx = "" if F == 2 else "4"
+    V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
+    M = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
+    call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
-    igemm_batched(ptr(V), ptr(U), ptr(M), g1, 16, T * cin, cin * cout, T * cout)
-    call("mopa_wino_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
+    igemm_batched(ptr(V), ptr(U), ptr(M), g1, NP, T * cin, cin * cout, T * cout)
+    call(f"mopa_wino{sfx}_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
     return V
 
 
 def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
-    """The weight gradient of the same layers in the transform domain (dU[p] = V[p]^T dM[p], 16 batched 1x1 weight gradients
+    """The weight gradient of the same layers in the transform domain (dU[p] = V[p]^T dM[p], batched 1x1 weight gradients
     on the MFMA kernel, then G^T dU G): needs 64-aligned channels on both sides and the MFMA build."""
-    return (wino_eligible(cin, cout, k, s, p, B, H, W) and cin % 64 == 0 and cout % 64 == 0 and min(cin, cout) >= 128
+    F = wino_tile(cin, cout, k, s, p, B, H, W, "wgrad")
+    return (F != 0 and cin % 64 == 0 and cout % 64 == 0 and min(cin, cout) >= (64 if F == 4 else 128)
             and os.environ.get("MOPA_CONV2D_MFMA", "1") != "0" and os.environ.get("MOPA_WINOGRAD_WGRAD", "1") != "0")
 
 
-def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False):
+def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
     """dw (OIHW, [cout][cin][3][3]) (+)= weight gradient of conv3x3(x) given dout, through V = B^T x B (kept from the forward
     pass when the caller has it), dM = A dout A^T."""
     dev = dw.device
     B, H, W = x.B, x.H, x.W
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    dM = torch.empty(16 * T * cout, dtype=torch.float32, device=dev)
+    T, NP = B * ((H + F - 1) // F) * ((W + F - 1) // F), (F + 2) ** 2
+    sfx = "" if F == 2 else "4"
+    dM = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
     if V is None:
-        V = torch.empty(16 * T * cin, dtype=torch.float32, device=dev)
-        call("mopa_wino_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
-    call("mopa_wino_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
-    ws = _ws(query("mopa_wino_wgrad_workspace_bytes", T, cin, cout), dev)
-    call("mopa_wino_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
+        V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
+        call(f"mopa_wino{sfx}_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
+    call(f"mopa_wino{sfx}_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
+    ws = _ws(query(f"mopa_wino{sfx}_wgrad_workspace_bytes", T, cin, cout), dev)
+    call(f"mopa_wino{sfx}_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
 
 
 # ------------------------------------------------------------------------------------------------ conv wrappers
@@ -177,9 +203,11 @@ class ConvOp:
 
     def forward(self, x: Img, out: Img, keep_v: bool = False):
         """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
-        if wino_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W):
-            V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False), self.b, out.p, out.ld)
-            return V if keep_v and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
+        F = wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "fwd")
+        if F:
+            V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False, F), self.b, out.p, out.ld, F=F)
+            same = F == wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad")   # V serves the weight gradient
+            return V if keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
@@ -188,15 +216,16 @@ class ConvOp:
         k, s, p = self.k, self.s, self.p
         # weight gradient: the split-K reduction writes (or accumulates into) the OIHW gradient tensor directly
         if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
-            wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params)
+            wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params, F=wino_tile(self.I, self.O, k, s, p, x.B, x.H, x.W, "wgrad"))
         else:
             wgrad(x.p, dout.p, ptr(dw), self._fwd_geom(x, dout), dev, accumulate=acc_params, oihw=True)
         if db is not None:
             colsum(dout, db, accumulate=acc_params)
         if dx is None:
             return
-        if wino_eligible(self.O, self.I, k, s, p, x.B, x.H, x.W):   # backward-data of a stride-1 3x3 conv is one, too
-            wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I, wino_weight_cached(self.w, True), None, dx.p, dx.ld, acc_dx)
+        F = wino_tile(self.O, self.I, k, s, p, x.B, x.H, x.W, "dgrad")   # backward-data of a stride-1 3x3 conv is one, too
+        if F:
+            wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I, wino_weight_cached(self.w, True, F), None, dx.p, dx.ld, acc_dx, F=F)
             return
         wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:

@@ -9,7 +9,7 @@ from mopa_amd._lib import call, ptr, stream
 B = 8
 shapes = [("L1 64->64 152x240", 64, 64, 152, 240), ("L2 128->128 76x120", 128, 128, 76, 120), ("L3 256->256 38x60", 256, 256, 38, 60),
           ("L4 512->512 19x30", 512, 512, 19, 30), ("D4 512->256 38x60", 512, 256, 38, 60), ("D3 256->128 76x120", 256, 128, 76, 120),
-          ("D2 128->64 152x240", 128, 64, 152, 240)]
+          ("D2 128->64 152x240", 128, 64, 152, 240), ("D1 128->64 304x480", 128, 64, 304, 480)]
 
 
 def timed(fn, reps=5):
@@ -36,29 +36,35 @@ for name, cin, cout, H, W in shapes:
     def direct():
         call("mopa_conv2d_igemm", ptr(x), ptr(wl), None, ptr(out_d), ctypes.addressof(g), 0, stream())
 
-    th, tw = (H + 1) // 2, (W + 1) // 2
-    T = B * th * tw
-    U = torch.empty(16, cin, cout, device="cuda")
-    call("mopa_wino_weight", ptr(w_oihw), cout, cin, 0, ptr(U), stream())
-    V = torch.empty(16, T, cin, device="cuda")
-    M = torch.empty(16, T, cout, device="cuda")
-    g1 = dense2d._geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
+    td = timed(direct)
+    res = []
+    for F in (2, 4):
+        sfx = "" if F == 2 else "4"
+        NP = (F + 2) ** 2
+        th, tw = (H + F - 1) // F, (W + F - 1) // F
+        T = B * th * tw
+        U = torch.empty(NP, cin, cout, device="cuda")
+        call(f"mopa_wino{sfx}_weight", ptr(w_oihw), cout, cin, 0, ptr(U), stream())
+        V = torch.empty(NP, T, cin, device="cuda")
+        M = torch.empty(NP, T, cout, device="cuda")
+        g1 = dense2d._geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
 
-    def t_in():
-        call("mopa_wino_input", ptr(x), cin, B, H, W, cin, ptr(V), stream())
+        def t_in():
+            call(f"mopa_wino{sfx}_input", ptr(x), cin, B, H, W, cin, ptr(V), stream())
 
-    def t_gemm():
-        call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, 0, stream())
+        def t_gemm():
+            call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), NP, T * cin, cin * cout, T * cout, 0, stream())
 
-    def t_out():
-        call("mopa_wino_output", ptr(M), B, H, W, cout, None, ptr(out_w), cout, 0, stream())
+        def t_out():
+            call(f"mopa_wino{sfx}_output", ptr(M), B, H, W, cout, None, ptr(out_w), cout, 0, stream())
 
-    def wino():
-        t_in(); t_gemm(); t_out()
+        def wino():
+            t_in(); t_gemm(); t_out()
 
-    td, tw_ = timed(direct), timed(wino)
-    ti, tg, to = timed(t_in), timed(t_gemm), timed(t_out)
-    err = float((out_d - out_w).abs().max()) / float(out_d.abs().max())
+        tw_ = timed(wino)
+        ti, tg, to = timed(t_in), timed(t_gemm), timed(t_out)
+        err = float((out_d - out_w).abs().max()) / float(out_d.abs().max())
+        res.append(f"F({F}x{F}) {tw_:6.1f} us = in {ti:5.1f} + gemm {tg:5.1f} + out {to:5.1f}, {td / tw_:4.2f}x, err {err:.1e}")
+    td = timed(direct)
     flops = 2.0 * B * H * W * cout * 9 * cin
-    print(f"{name:26s} direct {td:7.1f} us ({flops / td / 1e6:5.1f} TF/s)  winograd {tw_:7.1f} us = in {ti:6.1f} + gemm {tg:6.1f} "
-          f"({flops / 2.25 / tg / 1e6:5.1f} TF/s) + out {to:6.1f}   speed-up {td / tw_:4.2f}x   rel err {err:.1e}")
+    print(f"{name:22s} direct {td:6.1f} us ({flops / td / 1e6:5.1f} TF/s) | " + " | ".join(res))

@@ -33,7 +33,9 @@ def _close(got, ref, rtol=1e-4, atol=2e-5):
 
 @pytest.mark.parametrize("cin,cout,k,s,p,H,W", [(64, 64, 3, 1, 1, 19, 30), (64, 128, 3, 2, 1, 22, 36), (64, 128, 1, 2, 0, 22, 36),
                                                 (128, 64, 3, 1, 1, 16, 48), (256, 256, 3, 1, 1, 5, 7), (128, 256, 3, 2, 1, 9, 15),
-                                                (128, 256, 3, 1, 1, 6, 11), (256, 128, 3, 1, 1, 18, 30)])   # Winograd fwd / dgrad / wgrad
+                                                (128, 256, 3, 1, 1, 6, 11), (256, 128, 3, 1, 1, 18, 30),   # Winograd fwd / dgrad / wgrad: F(2x2) below 8 pixels,
+                                                (256, 256, 3, 1, 1, 9, 14), (128, 128, 3, 1, 1, 10, 13),    # F(4x4) above (ragged tiles)
+                                                (64, 64, 3, 1, 1, 8, 12), (128, 64, 3, 1, 1, 32, 48), (256, 128, 3, 1, 1, 8, 12)])
 def test_conv_fwd_dgrad_wgrad(cin, cout, k, s, p, H, W):
     from mopa_amd.dense2d import ConvOp, Img, new_img
     rng = np.random.Generator(np.random.PCG64(cin + cout + k))
@@ -224,6 +226,58 @@ def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
     assert torch.equal(e1, e2)
     with pytest.raises(IndexError):
         model({"img": img, "img_indices": [idx[0], np.array([[H, 0]])]})
+
+
+def test_winograd_f4_network_level(monkeypatch):
+    """F(4x4,3x3) at network level.  Default = backward passes only: same logits bit for bit, gradients as close to the fp64
+    oracle as the F(2x2) run.  Opt-in forward pass: logits within the stated tolerance of the oracle."""
+    from mopa_amd import dense2d
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, H, W = 2, 160, 224
+    img = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32))
+    idx = [np.stack([rng.integers(0, H, 500), rng.integers(0, W, 500)], 1) for _ in range(B)]
+
+    def run(roles, backward=True):
+        monkeypatch.setattr(dense2d, "F4_ROLES", roles)
+        model = _build_2d().train()
+        model.net_2d.dropout.p = 0.0
+        out = model({"img": img, "img_indices": idx})
+        if backward:
+            (out["seg_logit"].square().mean() + out["seg_logit2"].square().mean() + out["seg_logit_all"].square().mean()).backward()
+        return {k: v.detach().cpu() for k, v in out.items()}, {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}
+
+    used = []
+    inner = dense2d.wino_conv
+    monkeypatch.setattr(dense2d, "wino_conv", lambda *a, **kw: (used.append(kw.get("F", 2)), inner(*a, **kw))[1])
+    assert dense2d.F4_ROLES == ("dgrad", "wgrad")   # the shipped default
+    o4, g4 = run(("dgrad", "wgrad"))
+    assert 4 in used and 2 in used
+    o2, g2 = run(())
+    for k in o2:
+        assert torch.equal(o4[k], o2[k])
+    # truth = the fp64 oracle.  This random-init network is ill-conditioned in fp32 whatever the conv algorithm: the F(2x2) run
+    # (and the direct kernels) are off by a median 1.3 % of each gradient's scale; F(4x4) in the backward passes must not add to it.
+    P = {k: (det_tensor(k, v).double() if "num_batches" not in k else det_tensor(k, v)) for k, v in net2d.param_shapes(5, True).items()}
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    ref = net2d.net2dseg_forward(P, img.double(), idx, training=True, dropout_p=0.0)
+    (ref["seg_logit"].square().mean() + ref["seg_logit2"].square().mean() + ref["seg_logit_all"].square().mean()).backward()
+    worst = []
+    for k in g2:
+        truth = P[k].grad.float()
+        scale = float(truth.abs().max())
+        if scale < 1e-6:   # biases in front of a BatchNorm: the true gradient is zero
+            continue
+        e4, e2 = float((g4[k] - truth).abs().max()) / scale, float((g2[k] - truth).abs().max()) / scale
+        if e4 > max(1.5 * e2, 2e-4):
+            worst.append((k, e4, e2))
+    assert not worst, worst[:8]
+    # forward pass on F(4x4) too (MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad): logits within the tolerance of the logit parity tests
+    of, _ = run(("fwd", "dgrad", "wgrad"), backward=False)
+    for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
+        _close(of[k], ref[k].detach().float(), rtol=1e-3, atol=2e-4)
+        _close(of[k], o2[k], rtol=1e-3, atol=1e-4)
 
 
 def test_cached_weight_layouts_follow_every_kind_of_weight_update():
