@@ -955,8 +955,10 @@ __global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slab
     const int p = q + 16 * j;
     if (p < 36) {
       float s = 0.f;
-      if (i < n)
+      if (i < n) {
+#pragma unroll 8
         for (int c = 0; c < nsplit; ++c) s += slabs[((int64_t)c * 36 + p) * n + i];
+      }
       red[p][e] = s;
     }
   }
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slab
 
 static void wino_wgrad_split(int np, int64_t T, int Cin, int Cout, int* nsplit, int* m_per_split) {
   const int64_t tiles = (int64_t)np * (Cin / 64) * (Cout / 64);
-  int64_t ns = cdiv64(2048, tiles);
+  int64_t ns = cdiv64(2048, tiles);   // (768 ... 2048 target blocks: same joint step within 0.5 %)
   const int64_t maxs = cdiv64(T, 128);
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
