@@ -135,7 +135,9 @@ F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "1500000"))
 # linear perturbation -- logits stay bit-identical and the gradients stay as close to the fp64 oracle as with F(2x2) (tests).
 # In the FORWARD pass the same error also moves a few ReLU pre-activations across zero; layers that normalise over few samples
 # amplify such a flip (measured on a 2 x 160 x 224 input: median gradient error against fp64 1.4 % -> 1.7 %, single tensors of
-# layer4 -- 70 samples per channel -- 1.5 % -> 17 %).  It is worth another 10 % of throughput (239 -> 263 scans/s on the joint
+# layer4 -- 70 samples per channel -- 1.5 % -> 17 %; at the bench size, 8 x 302 x 480, profiles/f4_gradient_noise.py: median /
+# 90th percentile / max over the parameter tensors 1.0 / 2.1 / 5.0 % with F(2x2), the same with F(4x4) in the backward passes,
+# 1.4 / 2.7 / 6.7 % with F(4x4) in the forward pass too; the direct kernels: 1.0 / 2.1 / 4.3 %).  It is worth another 10 % of throughput (239 -> 263 scans/s on the joint
 # step) and its logits stay within the parity tolerance, so it is an opt-in: MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad; even then
 # the forward pass keeps F(2x2) below F4_FWD_MIN_PIXELS samples per channel.
 F4_ROLES = tuple(r for r in os.environ.get("MOPA_WINOGRAD_F4_ROLES", "dgrad,wgrad").split(",") if r) \
