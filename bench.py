@@ -313,7 +313,8 @@ def main():
         del g
 
     from mopa_amd.step import DualStream
-    dual = DualStream(dev)  # 3D branch (small latency-bound kernels) on a second HIP stream, overlapping the 2D GEMMs
+    reorder = os.environ.get("MOPA_BENCH_REORDER", "1") != "0"
+    dual = DualStream(dev, order_2d_first=reorder)  # 3D branch on a second HIP stream, overlapping the 2D GEMMs
 
     resident = torch.cuda.Event()
     resident.record()           # the synthetic batches are in HBM from here on
@@ -324,32 +325,45 @@ def main():
         """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
         o2, o3 = dual.forward(model2d, model3d, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
                               {"x": [b["locs"], b["feats"]]}, inputs_ready=resident if geom_ahead else None)
+        def loss_3d():
+            l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
+            if supervised:
+                l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+            elif mopa:
+                l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
+                gv = dual.geometry_ahead(model3d, b["vgi_locs"], resident) if geom_ahead else None
+                ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]], "geometry_3d": gv})   # third 3D pass on the VGI-style batch
+                l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
+            return l3
+
         l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
-        l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
         if supervised:
             l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
-            l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
         elif mopa:
             l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
-            l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
-            gv = dual.geometry_ahead(model3d, b["vgi_locs"], resident) if geom_ahead else None
-            ov = model3d({"x": [b["vgi_locs"], b["vgi_feats"]], "geometry_3d": gv})   # third 3D pass on the VGI-style batch
-            l3 = l3 + seg_ce(ov["seg_logit"], b["vgi_label"])
+        if reorder:
+            # the 3D losses (and the VGI pass) on the side stream: their backward -- the whole 3D backward -- is then queued there
+            # and runs beside the 2D backward without the host having to enqueue it first while the main stream waits
+            with dual.on_side(o2["seg_logit"]):
+                l3 = loss_3d()
+            l2.backward()
+            l3.backward()
+            return l2.detach(), l3.detach()
+        l3 = loss_3d()
         if bwd3_first:   # the 3D backward (side stream) starts as soon as its loss gradient exists, beside the 2D backward
             l3.backward()
             l2.backward()
         else:
             l2.backward()
             l3.backward()
-        return l2.detach() + l3.detach()
+        return l2.detach(), l3.detach()
 
     def step(i):
         for o in opts:
             o.zero_grad()
         if joint:
-            loss = half(batches[0], 1.0, True)          # source: CE + lambda_xm_src * KL   (yaml :56)
-            loss = loss + half(batches[1], 0.1, False)  # target: lambda_xm_trg * KL        (yaml :57)
+            parts = half(batches[0], 1.0, True) + half(batches[1], 0.1, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
         else:
             b = batches[i % 2]
             # the voxel geometry depends on the coordinates only: built beside the previous step's backward (loader-side work)
@@ -359,6 +373,9 @@ def main():
             loss.backward()
         if joint:
             dual.join()  # 3D backward done before its gradients are reduced / applied
+            for t in parts:   # the 3D parts live in the side stream's pool
+                t.record_stream(torch.cuda.current_stream())
+            loss = parts[0] + parts[1] + parts[2] + parts[3]
         for o in opts:
             o.all_reduce()
         for o in opts:

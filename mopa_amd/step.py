@@ -12,9 +12,21 @@ import torch
 
 
 class DualStream:
-    def __init__(self, device):
+    def __init__(self, device, order_2d_first: bool = False):
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
+        self.order_2d_first = order_2d_first
+
+    def on_side(self, *tensors_from_main):
+        """Context: run what follows (e.g. the 3D losses, so that their backward -- and with it the whole 3D backward -- is queued
+        on the side stream and does not wait behind the 2D backward) on the side stream, ordered after everything queued on the
+        current stream so far; `tensors_from_main` are recorded as used by the side stream."""
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        for t in tensors_from_main:
+            if torch.is_tensor(t):
+                t.record_stream(self.side)
+        return torch.cuda.stream(self.side)
 
     def forward(self, model_2d, model_3d, batch_2d: dict, batch_3d: dict, inputs_ready=None):
         """-> (preds_2d, preds_3d); both are safe to use on the current stream when this returns.
@@ -24,14 +36,19 @@ class DualStream:
         built on the side stream BEFORE that stream is ordered behind the main stream, so the host does not stall on the
         previous half's 2D backward and keeps enqueueing ahead of the device.  Without it the build waits like the rest."""
         main = torch.cuda.current_stream(self.device)
+        if self.order_2d_first:   # the main stream gets its (long) queue first; the 3D launches are enqueued while it runs
+            self.side.wait_stream(main)
+            preds_2d = model_2d(batch_2d)
         if inputs_ready is not None and batch_3d.get("geometry_3d") is None:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(inputs_ready)
                 batch_3d = dict(batch_3d, geometry_3d=model_3d.net_3d.geometry(batch_3d["x"][0]))
-        self.side.wait_stream(main)
+        if not self.order_2d_first:
+            self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             preds_3d = model_3d(batch_3d)
-        preds_2d = model_2d(batch_2d)
+        if not self.order_2d_first:
+            preds_2d = model_2d(batch_2d)
         main.wait_stream(self.side)
         for t in preds_3d.values():   # allocated from the side stream's pool, read by the loss kernels on the main stream:
             if torch.is_tensor(t):    # their memory must not return to the side stream before those reads are done

@@ -219,13 +219,19 @@ def test_dual_stream_is_bit_identical_to_sequential():
             else:
                 p2, p3 = dual.forward(m2, m3, b, b, inputs_ready=ready if ahead else None)
             l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"])
-            l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
-            if ahead:   # 3D backward first: it runs on the side stream beside the 2D backward
-                l3.backward()
+            if ahead == "side_loss":   # 3D losses on the side stream: the whole 3D backward is queued there, 2D backward first
+                with dual.on_side(p2["seg_logit"]):
+                    l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
                 l2.backward()
+                l3.backward()
             else:
-                l2.backward()
-                l3.backward()
+                l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
+                if ahead:   # 3D backward first: it runs on the side stream beside the 2D backward
+                    l3.backward()
+                    l2.backward()
+                else:
+                    l2.backward()
+                    l3.backward()
             losses += [l2.detach(), l3.detach()]
             del p2, p3, l2, l3
         if dual is not None:
@@ -241,6 +247,10 @@ def test_dual_stream_is_bit_identical_to_sequential():
     g_ahead, d = run(DualStream("cuda"), ahead=True)
     assert a == d
     assert all(torch.equal(x, y) for x, y in zip(g_seq, g_ahead))
+    # 2D forward enqueued first, 3D losses computed on the side stream (bench.py's order)
+    g_side, e = run(DualStream("cuda", order_2d_first=True), ahead="side_loss")
+    assert a == e
+    assert all(torch.equal(x, y) for x, y in zip(g_seq, g_side))
 
 
 def test_geometry_built_ahead_on_the_side_stream_gives_the_same_results():
