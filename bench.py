@@ -393,7 +393,9 @@ def main():
     torch.cuda.synchronize()
     # HIP-event brackets for the roofline figures on every EVENT_STRIDE-th timed step: on every step they cost 2.8 % (joint) /
     # 4.4 % (3d) of `value` (MOPA_BENCH_EVENT_STRIDE=1 / =0 measure that: every step / never)
-    ev_stride = int(os.environ.get("MOPA_BENCH_EVENT_STRIDE", "4"))
+    ev_stride = int(os.environ.get("MOPA_BENCH_EVENT_STRIDE", "5"))
+    from mopa_amd import dense2d as dense2d_mod
+    wgrad_stream_on = dense2d_mod.WGRAD_STREAM
     n_ev_steps = 0
     t0 = time.perf_counter()
     per_step, step_times = [], os.environ.get("MOPA_BENCH_STEP_TIMES")
@@ -401,6 +403,9 @@ def main():
     for i in range(args.steps):
         timer.enabled = timer2d.enabled = ev_stride > 0 and i % ev_stride == 0
         n_ev_steps += int(timer.enabled)
+        # on the bracketed steps the 2D weight gradients run on the main stream again: a bracket around a launch would otherwise
+        # time it while a second stream of this same branch shares the chip (the 3D side stream stays, as the note below says)
+        dense2d_mod.WGRAD_STREAM = wgrad_stream_on and not timer.enabled
         loss = step(i)
         if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
             if step_times == "sync":

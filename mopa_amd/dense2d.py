@@ -188,6 +188,52 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
     call(f"mopa_wino{sfx}_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
 
 
+_wgrad_streams = {}
+WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may switch it per pass, e.g. bench.py's bracketed steps)
+
+
+def wgrad_stream(dev):
+    """The stream the weight gradients of the 2D convolutions run on (None: the current stream; MOPA_WGRAD_STREAM=0)."""
+    if not WGRAD_STREAM:
+        return None
+    key = (torch.device(dev).index, stream())   # one per (device, consumer stream)
+    st = _wgrad_streams.get(key)
+    if st is None:
+        st = _wgrad_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class _on:
+    """`with _on(side, *tensors)`: run the body on `side`, ordered behind everything queued on the current stream so far; the
+    tensors (allocated from the current stream's pool, touched by `side`) are recorded for the caching allocator.  side = None:
+    no-op."""
+
+    def __init__(self, side, *tensors):
+        self.side, self.tensors = side, tensors
+
+    def __enter__(self):
+        if self.side is None:
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad_stream(dev):
+    """Order the current stream behind the weight-gradient stream (end of a backward pass)."""
+    ws = wgrad_stream(dev)
+    if ws is not None:
+        torch.cuda.current_stream().wait_stream(ws)
+
+
 # ------------------------------------------------------------------------------------------------ conv wrappers
 class ConvOp:
     """Conv2d(k, stride s, padding p) in NHWC through the implicit-GEMM kernels (fwd, dgrad, wgrad)."""
@@ -213,16 +259,22 @@ class ConvOp:
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
-    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False, V=None):
+    def backward(self, x: Img, dout: Img, dx: Img | None, dw: torch.Tensor, db, acc_dx: bool, acc_params: bool = False, V=None,
+                 wgrad_side: bool = False):
+        """wgrad_side: the caller joins the weight-gradient stream itself (join_wgrad_stream) after the whole backward pass."""
         dev = self.w.device
         k, s, p = self.k, self.s, self.p
-        # weight gradient: the split-K reduction writes (or accumulates into) the OIHW gradient tensor directly
-        if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
-            wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params, F=wino_tile(self.I, self.O, k, s, p, x.B, x.H, x.W, "wgrad"))
-        else:
-            wgrad(x.p, dout.p, ptr(dw), self._fwd_geom(x, dout), dev, accumulate=acc_params, oihw=True)
-        if db is not None:
-            colsum(dout, db, accumulate=acc_params)
+        # weight gradient: the split-K reduction writes (or accumulates into) the OIHW gradient tensor directly.  It depends on x
+        # and dout only and nothing downstream of this layer waits for it: it runs on the weight-gradient stream, beside the
+        # backward-data chain that the rest of the backward pass is waiting for (Net2DFunction.backward joins the stream).
+        ws = wgrad_stream(dev) if wgrad_side else None
+        with _on(ws, x.t, dout.t, dw, db, V):
+            if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
+                wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params, F=wino_tile(self.I, self.O, k, s, p, x.B, x.H, x.W, "wgrad"))
+            else:
+                wgrad(x.p, dout.p, ptr(dw), self._fwd_geom(x, dout), dev, accumulate=acc_params, oihw=True)
+            if db is not None:
+                colsum(dout, db, accumulate=acc_params)
         if dx is None:
             return
         F = wino_tile(self.O, self.I, k, s, p, x.B, x.H, x.W, "dgrad")   # backward-data of a stride-1 3x3 conv is one, too
@@ -519,7 +571,7 @@ class Net2DFunction(torch.autograd.Function):
                 dx = gmap[k] if acc else like(x)
                 gmap[k] = dx
                 pg, pacc = sink.take(*([name + ".weight"] + ([name + ".bias"] if op.b is not None else [])))
-                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc, V=V)
+                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc, V=V, wgrad_side=True)
             elif kind == "convT":
                 _, name, op, x, out = rec
                 dout = gmap.pop(key(out))
@@ -559,4 +611,5 @@ class Net2DFunction(torch.autograd.Function):
                 call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
             elif kind == "block_in":
                 pass
+        join_wgrad_stream(feat.t.device)   # the weight gradients are complete for whatever the caller queues next
         return (None, None, None, None, None, None) + sink.returned()
