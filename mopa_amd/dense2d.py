@@ -321,16 +321,17 @@ class ConvTOp:
             for kx in range(2):
                 igemm(x.p, wl, self.b, out.p, self._geom(x, out, ky, kx))
 
-    def backward(self, x: Img, dout: Img, dx: Img, dw, db, acc_params: bool = False):
+    def backward(self, x: Img, dout: Img, dx: Img, dw, db, acc_params: bool = False, wgrad_side: bool = False):
         dev = self.w.device
-        dwl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=dev)
-        for ky in range(2):
-            for kx in range(2):
-                g = self._geom(x, dout, ky, kx)
-                g[17], g[18] = 0, 0  # KH0/KW0: the per-class launch writes a single-tap slab
-                wgrad(x.p, dout.p, ptr(dwl, (ky * 2 + kx) * self.I * self.O), g, dev)
-        relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True, accumulate=acc_params)
-        colsum(dout, db, accumulate=acc_params)
+        with _on(wgrad_stream(dev) if wgrad_side else None, x.t, dout.t, dw, db):   # see ConvOp.backward
+            dwl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=dev)
+            for ky in range(2):
+                for kx in range(2):
+                    g = self._geom(x, dout, ky, kx)
+                    g[17], g[18] = 0, 0  # KH0/KW0: the per-class launch writes a single-tap slab
+                    wgrad(x.p, dout.p, ptr(dwl, (ky * 2 + kx) * self.I * self.O), g, dev)
+            relayout(dwl, dw, self.O, self.I, 2, 2, 2, inverse=True, accumulate=acc_params)
+            colsum(dout, db, accumulate=acc_params)
         wt = relayout_cached(self.w, (2, 2, self.O, self.I), self.O, self.I, 2, 2, 3)
         g = _geom(B=x.B, IH=dout.H, IW=dout.W, OHl=x.H, OWl=x.W, OHa=x.H, OWa=x.W, IS=2, TH=2, TW=2, KWF=2,
                   Cin=self.O, Cout=self.I, ld_in=dout.ld, ld_out=dx.ld)
@@ -578,7 +579,7 @@ class Net2DFunction(torch.autograd.Function):
                 dx = like(x)
                 gmap[key(x)] = dx
                 (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
-                op.backward(x, dout, dx, dw, db, acc_params=pacc)
+                op.backward(x, dout, dx, dw, db, acc_params=pacc, wgrad_side=True)
             elif kind == "join":
                 _, lvl, cj = rec
                 full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
@@ -605,10 +606,11 @@ class Net2DFunction(torch.autograd.Function):
             elif kind == "stem":
                 _, x4, c1, g = rec
                 dout = gmap.pop(key(c1))
-                dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
-                wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
                 (dw,), pacc = sink.take(pre + "conv1.weight")
-                call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
+                with _on(wgrad_stream(dev), x4, dout.t, dw):
+                    dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
+                    wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
+                    call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
             elif kind == "block_in":
                 pass
         join_wgrad_stream(feat.t.device)   # the weight gradients are complete for whatever the caller queues next

@@ -4,8 +4,9 @@
 # Everything lands in gpurun_out/final/; copy the summaries into profiles/ afterwards (profiles/collect_final.py).
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final; mkdir -p $O
-timeout 600 python3 bench.py --workload 3d --steps 50 --warmup 5 > $O/bench_3d.json 2> $O/bench_3d.err
 timeout 900 python3 bench.py --steps 10 --warmup 3 > $O/bench_joint.json 2> $O/bench_joint.err
+# (after the joint run: the host-bound 3D-only step is the one that suffers from a cold box -- first process, page cache)
+timeout 600 python3 bench.py --workload 3d --steps 50 --warmup 5 > $O/bench_3d.json 2> $O/bench_3d.err
 timeout 600 python3 bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_mopa.json 2> $O/bench_mopa.err
 for W in 3d joint; do
   A=""; [ $W = 3d ] && A="--workload 3d"
