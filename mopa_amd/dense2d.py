@@ -189,12 +189,22 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
 
 
 _wgrad_streams = {}
+# MOPA_WGRAD_STREAM: "1" on, "0" off, unset = on in a single-process job and OFF under a torch.distributed process group.
+# Reason for the second half: every extra stream is another hardware queue.  Measured on a 1-GPU box with two ranks sharing
+# the device (the multi-process plumbing test): two streams per rank run at the expected speed, three per rank fall off a cliff
+# (3.4 s per step instead of 0.19).  One rank per GPU plus RCCL's own stream could not be measured here, so data-parallel
+# runs keep the two-stream configuration that was; a caller that has measured it can set MOPA_WGRAD_STREAM=1.
 WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may switch it per pass, e.g. bench.py's bracketed steps)
 
 
+def _distributed():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def wgrad_stream(dev):
-    """The stream the weight gradients of the 2D convolutions run on (None: the current stream; MOPA_WGRAD_STREAM=0)."""
-    if not WGRAD_STREAM:
+    """The stream the weight gradients of the 2D convolutions run on (None: the current stream)."""
+    if not WGRAD_STREAM or (os.environ.get("MOPA_WGRAD_STREAM") != "1" and _distributed()):
         return None
     key = (torch.device(dev).index, stream())   # one per (device, consumer stream)
     st = _wgrad_streams.get(key)
