@@ -315,6 +315,8 @@ def main():
     from mopa_amd.step import DualStream
     reorder = os.environ.get("MOPA_BENCH_REORDER", "1") != "0"
     dual = DualStream(dev, order_2d_first=reorder)  # 3D branch on a second HIP stream, overlapping the 2D GEMMs
+    if os.environ.get("MOPA_BENCH_NO_SIDE") == "1":   # A/B only: the 3D branch on the main stream
+        dual.side = torch.cuda.current_stream(dev)
 
     resident = torch.cuda.Event()
     resident.record()           # the synthetic batches are in HBM from here on
