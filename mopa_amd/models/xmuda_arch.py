@@ -62,7 +62,8 @@ class Net2DSeg(nn.Module):
         t = torch.from_numpy(flat.astype(np.int32))
         if torch.device(device).type != "cuda" or t.numel() == 0:
             return t.to(device)
-        return t.pin_memory().to(device, non_blocking=True)
+        from .._lib import upload
+        return upload(t, device)
 
     def forward(self, data_batch):
         dev = _require_cuda(self)

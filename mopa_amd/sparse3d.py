@@ -52,7 +52,7 @@ class Geometry3D:
             raise RuntimeError("empty point cloud")
         coords = coords.to(torch.int64)
         if coords.device.type == "cpu":
-            coords = coords.contiguous().pin_memory().to(device, non_blocking=True)
+            coords = _lib.upload(coords, device)
         else:
             coords = coords.to(device).contiguous()
         self.device, self.n_points, self.num_levels = device, N, num_levels
