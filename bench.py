@@ -6,6 +6,15 @@
 One "step" = one training pass of the hot path over one batch of B synthetic nuScenes-shape scans per GPU
 (geometry build -> forward -> losses -> backward -> gradient all-reduce -> Adam).  Inputs are resident in HBM
 before the timed region.  value = scans/s over all ranks (weak scaling: per-GPU batch fixed).
+
+A/B switches (environment; the defaults are what the numbers in DESIGN.md were measured with):
+  MOPA_BENCH_EVENT_STRIDE=5   HIP-event brackets (roofline figures) on every n-th timed step; 0 = none, 1 = every step
+  MOPA_BENCH_STEP_TIMES=1     per-step host clock + caching-allocator counters of the timed region on stderr
+  MOPA_BENCH_GEOM_AHEAD=0     voxel geometry built behind the main stream again;  MOPA_BENCH_REORDER=0  3D forward enqueued
+                              first, 3D losses on the main stream;  MOPA_BENCH_BWD3_FIRST=0  (with REORDER=0) 2D backward first
+  MOPA_BENCH_NO_SIDE=1        3D branch on the main stream;  MOPA_WGRAD_STREAM=0  2D weight gradients on the main stream
+  MOPA_CONV2D_MFMA=0          fp32 vector-pipe conv kernels;  MOPA_WINOGRAD=0 / MOPA_WINOGRAD_F4=0 / MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad
+  MOPA_BENCH_BACKEND=gloo     (with torch.distributed.run) lets several ranks share one GPU: plumbing test only
 """
 from __future__ import annotations
 
