@@ -42,7 +42,10 @@ def _worker(rank, world, port, q):
         cpu_step_refused = False
     except RuntimeError:
         cpu_step_refused = True                                              # no CPU fallback for the update kernel
-    q.put((rank, ok, distinct, cpu_step_refused))
+    # under a multi-rank process group the 2D weight gradients stay on the caller's stream (no third stream per rank)
+    from mopa_amd import dense2d
+    no_third_stream = dense2d.wgrad_stream("cuda:0") is None if os.environ.get("MOPA_WGRAD_STREAM") != "1" else True
+    q.put((rank, ok and no_third_stream, distinct, cpu_step_refused))
     dist.destroy_process_group()
 
 

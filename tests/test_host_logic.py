@@ -114,3 +114,28 @@ def test_oracle_pseudo_labels_pinned_by_golden(golden_dir):
     np.testing.assert_allclose(pseudo.prob_2_entropy(prob).numpy(), g["entropy"], rtol=1e-6, atol=1e-7)
     w = pseudo.fuse_probs(torch.from_numpy(g["logit"]), torch.from_numpy(g["logit"]))
     np.testing.assert_allclose(w.numpy(), prob.numpy(), rtol=1e-6)       # fusing a modality with itself is the identity
+
+
+def test_conv_algorithm_choice(monkeypatch):
+    """dense2d.wino_tile: which algorithm runs a convolution in which pass (the policy behind the measurements in DESIGN.md)."""
+    from mopa_amd import dense2d
+    monkeypatch.setattr(dense2d, "F4_ROLES", ("dgrad", "wgrad"))
+    monkeypatch.delenv("MOPA_WINOGRAD", raising=False)
+    B = 8
+    t = dense2d.wino_tile
+    # forward: F(2x2) for >= 128 channels up to 76x120, direct otherwise; backward passes: F(4x4) up to full resolution
+    assert t(256, 256, 3, 1, 1, B, 38, 60, "fwd") == 2 and t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 4
+    assert t(64, 64, 3, 1, 1, B, 152, 240, "fwd") == 0 and t(64, 64, 3, 1, 1, B, 152, 240, "wgrad") == 4
+    assert t(128, 64, 3, 1, 1, B, 304, 480, "fwd") == 0 and t(64, 128, 3, 1, 1, B, 304, 480, "dgrad") == 4
+    # not a stride-1 3x3 / ragged channel counts / maps below 8 pixels
+    assert t(64, 128, 3, 2, 1, B, 152, 240, "dgrad") == 0 and t(64, 128, 1, 1, 0, B, 76, 120, "fwd") == 0
+    assert t(256, 96, 3, 1, 1, B, 38, 60, "dgrad") == 0
+    assert t(512, 512, 3, 1, 1, 2, 2, 3, "dgrad") == 2 and t(512, 512, 3, 1, 1, 2, 2, 3, "fwd") == 2
+    # opt-in forward pass on F(4x4): only with enough samples per channel
+    monkeypatch.setattr(dense2d, "F4_ROLES", ("fwd", "dgrad", "wgrad"))
+    assert t(256, 256, 3, 1, 1, B, 38, 60, "fwd") == 4 and t(256, 256, 3, 1, 1, 2, 8, 12, "fwd") == 2
+    # the weight gradient in the transform domain needs 64-aligned channels on both sides
+    monkeypatch.setattr(dense2d, "F4_ROLES", ("dgrad", "wgrad"))
+    assert dense2d.wino_wgrad_eligible(64, 64, 3, 1, 1, B, 152, 240) and not dense2d.wino_wgrad_eligible(16, 64, 3, 1, 1, B, 152, 240)
+    monkeypatch.setenv("MOPA_WINOGRAD", "0")
+    assert t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 0
