@@ -25,20 +25,26 @@ def timed(fn, reps=10):
     return s.elapsed_time(e) / reps * 1e3
 
 
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2      # 2: F(2x2,3x3), 16 points; 4: F(4x4,3x3), 36 points
+NP = (F + 2) ** 2
+if F == 4:
+    shapes = shapes + [("L1 64->64 152x240", 64, 64, 152, 240), ("D2 128->64 152x240", 128, 64, 152, 240),
+                       ("D2' 64->128 152x240", 64, 128, 152, 240), ("D1 128->64 304x480", 128, 64, 304, 480),
+                       ("D1' 64->128 304x480", 64, 128, 304, 480)]
 for name, cin, cout, H, W in shapes:
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    U = torch.randn(16, cin, cout, device="cuda")
-    V = torch.randn(16, T, cin, device="cuda")
-    M = torch.empty(16, T, cout, device="cuda")
+    T = B * ((H + F - 1) // F) * ((W + F - 1) // F)
+    U = torch.randn(NP, cin, cout, device="cuda")
+    V = torch.randn(NP, T, cin, device="cuda")
+    M = torch.empty(NP, T, cout, device="cuda")
     g1 = dense2d._geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
-    gf = 16 * T * cin * cout * 2 / 1e9
+    gf = NP * T * cin * cout * 2 / 1e9
     row = []
     for tile in range(4):
         if tile == 1 and cout % 128:
             row.append("   -   ")
             continue
         fl = (tile + 1) << 8
-        us = timed(lambda: call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, fl, stream()))
-        row.append(f"{us:6.1f}us {gf / us * 1e3 / 1e3:5.1f}TF")
-    us = timed(lambda: call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), 16, T * cin, cin * cout, T * cout, 0, stream()))
+        us = timed(lambda: call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), NP, T * cin, cin * cout, T * cout, fl, stream()))
+        row.append(f"{us:6.1f}us {gf / us * 1e3:5.1f}TF")
+    us = timed(lambda: call("mopa_conv2d_igemm_batched", ptr(V), ptr(U), ptr(M), ctypes.addressof(g1), NP, T * cin, cin * cout, T * cout, 0, stream()))
     print(f"{name:22s} T={T:6d} " + " | ".join(f"{n}: {r}" for n, r in zip(names, row)) + f" | auto {us:6.1f}us")
