@@ -194,6 +194,8 @@ _wgrad_streams = {}
 # the device (the multi-process plumbing test): two streams per rank run at the expected speed, three per rank fall off a cliff
 # (3.4 s per step instead of 0.19).  One rank per GPU plus RCCL's own stream could not be measured here, so data-parallel
 # runs keep the two-stream configuration that was; a caller that has measured it can set MOPA_WGRAD_STREAM=1.
+# (The same stream for the sparse-conv weight gradients of 3D-only training was measured too: 1347 -> 1290 scans/s -- that step
+# is host-paced and the stream switches cost more than the overlap returns: not kept.)
 WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may switch it per pass, e.g. bench.py's bracketed steps)
 
 
