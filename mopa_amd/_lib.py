@@ -42,6 +42,9 @@ SIGNATURES = {
     "mopa_spconv_transpose_weight": ("i", "piiipp"),
     "mopa_spconv_grouped_wants_packed": ("i", "iiii"),
     "mopa_spconv_pack_weight": ("i", "piiiiipp"),
+    "mopa_spconv_ws_ntw": ("i", "iiii"),
+    "mopa_spconv_pack_weight_ws": ("i", "piiiiipp"),
+    "mopa_spconv_fwd_ws": ("i", "ppppiipiipiipip"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
     # ---- pseudo-label update (pseudo.hip)

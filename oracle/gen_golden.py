@@ -9,8 +9,10 @@ Missing third-party modules are stubbed in ``sys.modules``:
   torchvision's attribute / parameter names (public architecture: BasicBlock
   [3,4,6,3], conv1 7x7 s2, maxpool 3x3 s2).  The reference code under test is
   ``UNetResNet34`` + ``Net2DSeg`` which wrap it.
-* ``sparseconvnet``: empty module (the 3D path cannot be imported; its oracle
-  stays "parity unpinned").
+* ``sparseconvnet``: the *recording* stand-in of oracle/scn_recorder.py -- generic
+  containers + leaf layers that log constructor arguments and a symbolic forward
+  trace (G6: structure pin).  No arithmetic flows through it; the 3D oracle's
+  numbers stay "parity unpinned".
 Weights come from oracle.params.det_tensor(name) so only I/O is stored.
 """
 from __future__ import annotations
@@ -70,9 +72,14 @@ def _install_stubs():
     tvr.resnet34 = lambda pretrained=False: ResNet34()
     tv.models, tvm.resnet = tvm, tvr
     sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr,
-                        "sparseconvnet": types.ModuleType("sparseconvnet"),
+                        "sparseconvnet": _scn_recorder().as_module(),
                         "openpyxl": types.ModuleType("openpyxl")})  # metric_logger.py:11 (xlsx export, unused here)
     sys.path.insert(0, REF)
+
+
+def _scn_recorder():
+    from oracle import scn_recorder
+    return scn_recorder
 
 
 def _np(d):
@@ -227,6 +234,69 @@ def gen_g5():
     print("G5 ok")
 
 
+# ----------------------------------------------------------------------------- G6
+def gen_g6():
+    """Structure pin of the 3D branch: the reference's own constructors (scn_unet.py:9-34, :38-219, xmuda_arch.py:82-126)
+    run under the recording ``sparseconvnet`` stand-in; what they build and the order they execute it in is committed as
+    JSON.  See oracle/scn_recorder.py for what this does and does not pin."""
+    from mopa.models.scn_unet import UNetSCN, UNetSCN_ED  # reference
+    from mopa.models.xmuda_arch import Net3DSeg  # reference
+    rec = _scn_recorder()
+
+    def shapes(mod):   # a LIST: module order is part of the pin (optimizer state is indexed by parameter order)
+        return [[k, list(v.shape)] for k, v in mod.state_dict().items()]
+
+    def run(mod, cin):
+        rec.set_root(mod)
+        out = mod([torch.zeros(4, 4, dtype=torch.int64), torch.ones(4, cin)])
+        assert isinstance(out, rec.Sym)
+        return [dict(t) for t in rec.TRACE], out.C
+
+    def arith(trace):   # the arithmetic layer sequence with BatchNormLeakyReLU(leak 0) == BatchNormReLU folded
+        seq = []
+        for t in trace:
+            op = {"BatchNormLeakyReLU": "BatchNormReLU"}.get(t["op"], t["op"])
+            if op == "JoinTable":
+                seq.append((op, tuple(t["parts"]), tuple(t["part_ops"]), t["level_out"]))
+            elif op == "AddTable":
+                seq.append((op, t["cout"], t["level_out"]))
+            else:
+                seq.append((op, t["cin"], t["cout"], t["level_in"], t["level_out"]))
+        return seq
+
+    doc = {"_about": "generated by oracle/gen_golden.py::gen_g6 from /root/reference under oracle/scn_recorder.py; "
+                     "see that file's docstring for provenance"}
+    kw = dict(in_channels=1, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7)  # config/xmuda.py:217-224
+    variants = {"UNetSCN": kw, "UNetSCN_residual": dict(kw, residual_blocks=True),
+                "UNetSCN_reps2": dict(kw, block_reps=2), "UNetSCN_residual_reps2": dict(kw, residual_blocks=True, block_reps=2),
+                "UNetSCN_m32_planes5": dict(kw, m=32, num_planes=5)}
+    for name, k in variants.items():
+        rec.LOG.clear()
+        net = UNetSCN(**k)
+        ctor = [dict(c) for c in rec.LOG]
+        trace, cout = run(net, k["in_channels"])
+        doc[name] = {"kwargs": k, "out_channels": net.out_channels, "ctor_calls": ctor, "state_dict": shapes(net),
+                     "trace": trace}
+        assert cout == net.out_channels
+    rec.LOG.clear()
+    ed = UNetSCN_ED(1, m=16)
+    ctor = [dict(c) for c in rec.LOG]
+    trace, cout = run(ed, 1)
+    doc["UNetSCN_ED"] = {"kwargs": {"in_channels": 1, "m": 16}, "ctor_calls": ctor, "state_dict": shapes(ed), "trace": trace}
+    # the reference's unrolled network and scn.UNet (restated) must be the same arithmetic, layer for layer
+    a, b = arith(doc["UNetSCN"]["trace"]), arith(trace)
+    assert a == b, [(x, y) for x, y in zip(a, b) if x != y][:3]
+    doc["UNetSCN_equals_UNetSCN_ED"] = True
+    doc["layer_sequence"] = [list(map(lambda v: list(v) if isinstance(v, tuple) else v, t)) for t in a]
+    for name, k in {"Net3DSeg_dual": dict(dual_head=True), "Net3DSeg_single": dict(dual_head=False),
+                    "Net3DSeg_MCD": dict(dual_head=True, da_method="MCD")}.items():
+        net = Net3DSeg(num_classes=5, backbone_3d="SCN", backbone_3d_kwargs=kw, **k)
+        doc[name] = {"kwargs": k, "state_dict": shapes(net)}
+    with open(os.path.join(OUT, "g6_scn_structure.json"), "w") as f:
+        json.dump(doc, f, indent=0, sort_keys=True)
+    print("G6", len(doc["UNetSCN"]["state_dict"]), "tensors;", len(doc["layer_sequence"]), "ops; ED == UNet:", a == b)
+
+
 # ----------------------------------------------------------------------------- G7
 def gen_g7():
     """Integer pins of the synthetic scan (our own generator; not reference-derived)."""
@@ -254,4 +324,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
     else:
-        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g7()
+        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7()

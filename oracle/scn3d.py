@@ -226,40 +226,60 @@ def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="s
 
 
 def unet_forward(params: dict, geom: Geometry, feats: torch.Tensor, *, m=16, num_planes=7,
-                 block_reps=1, training=True, prefix="sparseModel.", taps: dict | None = None):
-    """UNetSCN.forward (scn_unet.py:32-34): returns per-point features (N, m)."""
+                 block_reps=1, training=True, prefix="sparseModel.", taps: dict | None = None,
+                 trace: list | None = None):
+    """UNetSCN.forward (scn_unet.py:32-34): returns per-point features (N, m).
+
+    `trace` (optional list) receives the executed layer sequence as tuples in the vocabulary of
+    tests/golden/g6_scn_structure.json["layer_sequence"] (structure pin, tests/test_scn_structure.py)."""
     planes = [(i + 1) * m for i in range(num_planes)]
     P = lambda n: params[prefix + n]  # noqa: E731
 
-    def bn(name, x):
+    def rec(*t):
+        if trace is not None:
+            trace.append(list(t))
+
+    def bn(name, x, l=0):
+        rec("BatchNormReLU", x.shape[1], x.shape[1], l, l)
         return bn_relu(x, P(name + ".weight"), P(name + ".bias"), P(name + ".running_mean"),
                        P(name + ".running_var"), training)
 
     def U(pre, l, x):
         idx = 0
         for _ in range(block_reps):
-            x = sparse_conv(bn(f"{pre}{idx}.0", x), geom.nbr27[l], P(f"{pre}{idx}.1.weight"))
+            w = P(f"{pre}{idx}.1.weight")
+            x = sparse_conv(bn(f"{pre}{idx}.0", x, l), geom.nbr27[l], w)
+            rec("SubmanifoldConvolution", w.shape[1], w.shape[2], l, l)
             idx += 1
         if l < num_planes - 1:
             p = f"{pre}{idx}.1."
-            y = sparse_conv(bn(p + "0", x), geom.ch[l], P(p + "1.weight"))
+            y = sparse_conv(bn(p + "0", x, l), geom.ch[l], P(p + "1.weight"))
+            rec("Convolution", x.shape[1], y.shape[1], l, l + 1)
             y = U(p + "2.", l + 1, y)
-            y = sparse_conv(bn(p + "3", y), geom.up[l], P(p + "4.weight"))
+            y = bn(p + "3", y, l + 1)
+            rec("Deconvolution", y.shape[1], P(p + "4.weight").shape[2], l + 1, l)
+            y = sparse_conv(y, geom.up[l], P(p + "4.weight"))
+            rec("JoinTable", [x.shape[1], y.shape[1]], ["SubmanifoldConvolution", "Deconvolution"], l)
             x = torch.cat([x, y], 1)  # JoinTable([skip, up])
             idx += 2
             for _ in range(block_reps):
-                x = sparse_conv(bn(f"{pre}{idx}.0", x), geom.nbr27[l], P(f"{pre}{idx}.1.weight"))
+                w = P(f"{pre}{idx}.1.weight")
+                x = sparse_conv(bn(f"{pre}{idx}.0", x, l), geom.nbr27[l], w)
+                rec("SubmanifoldConvolution", w.shape[1], w.shape[2], l, l)
                 idx += 1
         if taps is not None:
             taps[f"level{l}"] = x
         return x
 
     x = input_layer(geom.point_row, feats, geom.num_active[0])
+    rec("InputLayer", x.shape[1], x.shape[1], None, 0)
+    rec("SubmanifoldConvolution", x.shape[1], m, 0, 0)
     x = sparse_conv(x, geom.nbr27[0], P("1.weight"))
     if taps is not None:
         taps["stem"] = x
     x = U("2.", 0, x)
     x = bn("3", x)
+    rec("OutputLayer", m, m, 0, 0)
     return output_layer(geom.point_row, x)
 
 

@@ -37,7 +37,7 @@ def main():
     torch.manual_seed(0)
     m = 16
     print(f"{'level':>5} {'table':>6} {'rows':>8} {'rules':>9} {'cin':>4} {'cout':>4} {'wave us':>9} {'grouped us':>10} "
-          f"{'alg GB/s':>9} {'TF/s':>6} same")
+          f"{'ws us':>8} {'t40 us':>7} {'ws frac':>7} {'TF/s':>6} same ws_err")
     for l in range(L):
         C = m * (l + 1)
         cases = [("subm", g.nbr27[l], C, C), ("subm", g.nbr27[l], 2 * C, C)]
@@ -68,13 +68,26 @@ def main():
                 call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin,
                      ptr(wp if packed else w), cout, 2 if packed else 0, o2.p, o2.ld, ptr(ws), ws.numel(), stream())
 
+            ntw_ws = s3.query("mopa_spconv_ws_ntw", K, Ao, cin, cout)
+            o3 = s3.new_view(Ao, cout, "cuda")
+            wws = torch.empty_like(w)
+            if ntw_ws:
+                call("mopa_spconv_pack_weight_ws", ptr(w), K, cin, cout, 0, ntw_ws, ptr(wws), stream())
+
+            def ws_kernel():
+                call("mopa_spconv_fwd_ws", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin, ptr(wws), cout, 0,
+                     o3.p, o3.ld, stream())
+
             tw = timed(wave, reps) if cin <= 192 else float('nan')   # the dense-table kernel stops at 192 input channels
             tg = timed(grouped, reps)
+            tws = timed(ws_kernel, reps) if ntw_ws else float('nan')
             same = torch.equal(o1.t, o2.t)
-            err = float((o1.t - o2.t).abs().max())
-            alg = (Ain * cin + Ao * cout + K * Ao) * 4
-            print(f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {alg / tg / 1e3:>9.0f} "
-                  f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e}")
+            ref = o1.t if cin <= 192 else o2.t
+            err = float((ref - o3.t).abs().max() / ref.abs().max()) if ntw_ws else float('nan')
+            alg = rules * cin * 4 + Ao * cout * 4 + rules * 8 + K * cin * cout * 4
+            t40 = alg / 3.2e6
+            print(f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {tws:>8.1f} {t40:>7.1f} "
+                  f"{alg / tws / 8e6:>7.3f} {2 * rules * cin * cout / tws / 1e6:>6.1f} {same} {err:.1e}", flush=True)
 
 
 if __name__ == "__main__":

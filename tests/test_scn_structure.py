@@ -1,0 +1,107 @@
+"""Structure pin of the 3D branch (fixture G6, CPU only).
+
+tests/golden/g6_scn_structure.json was produced by importing the reference's ``UNetSCN``, ``UNetSCN_ED`` and ``Net3DSeg``
+(mopa/models/scn_unet.py:9-34,38-219, mopa/models/xmuda_arch.py:82-126) under the recording ``sparseconvnet`` stand-in
+(oracle/scn_recorder.py, generator oracle/gen_golden.py::gen_g6).  What is pinned here: layer list, constructor
+arguments, channel counts, execution order and JoinTable operand order of the reference's own wiring, and the
+state_dict names that follow from it.  NOT pinned (source absent): SparseConvNet's arithmetic -- tests/test_oracle_scn3d.py.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scn3d
+
+
+@pytest.fixture(scope="module")
+def g6(golden_dir):
+    with open(os.path.join(golden_dir, "g6_scn_structure.json")) as f:
+        return json.load(f)
+
+
+def _fold(shape):
+    """SCN stores conv weights as (volume, nIn, nOut) or (volume, 1, nIn, nOut): compare on the folded 3-D form."""
+    s = list(shape)
+    return s[:1] + s[2:] if len(s) == 4 and s[1] == 1 else s
+
+
+def test_reference_constructor_arguments(g6):
+    """What scn_unet.py:25-30 passes to sparseconvnet, as logged by the recording stand-in."""
+    calls = g6["UNetSCN"]["ctor_calls"]
+    assert calls[0] == {"type": "InputLayer", "dimension": 3, "spatial_size": 4096, "mode": 4}
+    assert calls[1]["type"] == "SubmanifoldConvolution" and (calls[1]["nIn"], calls[1]["nOut"], calls[1]["filter_size"],
+                                                             calls[1]["bias"]) == (1, 16, 3, False)
+    unet = calls[2]
+    assert unet["type"] == "UNet" and unet["reps"] == 1 and unet["nPlanes"] == [16, 32, 48, 64, 80, 96, 112]
+    assert unet["residual_blocks"] is False and unet["downsample"] == [2, 2] and unet["leakiness"] == 0
+    assert calls[-2]["type"] == "BatchNormReLU" and calls[-2]["nPlanes"] == 16 and calls[-2]["eps"] == 1e-4
+    assert calls[-1]["type"] == "OutputLayer"
+    # every convolution of the network is bias-free, every BN has SCN's eps / momentum, leakiness 0
+    for c in calls:
+        if "Convolution" in c["type"] or c["type"] == "Deconvolution":
+            assert c["bias"] is False
+            assert c["filter_volume"] == (27 if c["type"] == "SubmanifoldConvolution" else 8)
+            if c["type"] != "SubmanifoldConvolution":
+                assert (c["filter_size"], c["filter_stride"]) == (2, 2)
+        if c["type"].startswith("BatchNorm"):
+            assert (c["eps"], c["momentum"], c["leakiness"]) == (1e-4, 0.9, 0)
+
+
+def test_unrolled_reference_network_equals_scn_unet(g6):
+    """UNetSCN_ED (the reference's own unrolled restatement, scn_unet.py:38-135) runs the same layer sequence."""
+    assert g6["UNetSCN_equals_UNetSCN_ED"] is True
+    seq = g6["layer_sequence"]
+    assert len(seq) == 60
+    joins = [t for t in seq if t[0] == "JoinTable"]
+    assert len(joins) == 6
+    for t in joins:   # [skip | up]: the encoder feature first, the deconvolution output second (scn_unet.py:108-124)
+        assert t[1][0] == t[1][1] and t[2] == ["SubmanifoldConvolution", "Deconvolution"]
+    assert [t[3] for t in joins] == [5, 4, 3, 2, 1, 0]
+
+
+@pytest.mark.parametrize("variant,kw", [("UNetSCN", {}), ("UNetSCN_reps2", {"block_reps": 2}),
+                                        ("UNetSCN_m32_planes5", {"m": 32, "num_planes": 5})])
+def test_oracle_parameter_names_and_shapes(g6, variant, kw):
+    want = [[k, _fold(v)] for k, v in g6[variant]["state_dict"]]
+    got = [[k, list(v)] for k, v in scn3d.unet_param_shapes(**kw).items()]
+    assert got == want   # names, shapes AND module order
+
+
+@pytest.mark.parametrize("variant,kw", [("UNetSCN", {}), ("UNetSCN_reps2", {"block_reps": 2})])
+def test_oracle_executes_the_reference_layer_sequence(g6, variant, kw):
+    reps = kw.get("block_reps", 1)
+    rng = np.random.Generator(np.random.PCG64(3))
+    c = np.concatenate([rng.integers(0, 150, (300, 3)), rng.integers(0, 2, (300, 1))], 1).astype(np.int64)
+    geom = scn3d.Geometry(c)
+    shapes = scn3d.unet_param_shapes(block_reps=reps)
+    P = {"sparseModel." + k[len("sparseModel."):]: (torch.ones(s) if "running_var" in k else torch.zeros(s)) for k, s in shapes.items()}
+    trace = []
+    scn3d.unet_forward(P, geom, torch.ones(300, 1), block_reps=reps, training=False, trace=trace)
+
+    def arith(tr):
+        out = []
+        for t in tr:
+            op = {"BatchNormLeakyReLU": "BatchNormReLU"}.get(t["op"], t["op"])
+            if op == "JoinTable":
+                out.append([op, t["parts"], t["part_ops"], t["level_out"]])
+            else:
+                out.append([op, t["cin"], t["cout"], t["level_in"], t["level_out"]])
+        return out
+
+    assert trace == arith(g6[variant]["trace"])
+
+
+@pytest.mark.parametrize("dual,key", [(True, "Net3DSeg_dual"), (False, "Net3DSeg_single")])
+def test_product_state_dict_matches_reference_names(g6, dual, key):
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    cfg = default_cfg(num_classes=5, dual_head=dual)
+    model, _ = build_model_3d(cfg)
+    got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    want = [[k, _fold(v)] for k, v in g6[key]["state_dict"]]
+    # names, shapes and traversal order: torch optimizers / torch_ema index their state by parameter order
+    assert got == want
+    assert [k for k, _ in model.named_parameters()] == [k for k, _ in want if "running" not in k]
