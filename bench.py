@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the MoPA hot path on MI355X (contract: see the task statement / DESIGN.md section "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W [--workload 3d|joint] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload 3d|joint|mopa] [--batch B]
+
+`--gpus N` with N > 1, started as a plain process (no RANK / WORLD_SIZE in the environment), launches N ranks itself:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`, one rank
+per GPU over RCCL; rank 0 prints the one JSON line.  Started by a launcher already (the driver's torchrun form), it is a rank.
 
 One "step" = one training pass of the hot path over one batch of B synthetic nuScenes-shape scans per GPU
 (geometry build -> forward -> losses -> backward -> gradient all-reduce -> Adam).  Inputs are resident in HBM
@@ -14,7 +18,9 @@ A/B switches (environment; the defaults are what the numbers in DESIGN.md were m
                               first, 3D losses on the main stream;  MOPA_BENCH_BWD3_FIRST=0  (with REORDER=0) 2D backward first
   MOPA_BENCH_NO_SIDE=1        3D branch on the main stream;  MOPA_WGRAD_STREAM=0  2D weight gradients on the main stream
   MOPA_CONV2D_MFMA=0          fp32 vector-pipe conv kernels;  MOPA_WINOGRAD=0 / MOPA_WINOGRAD_F4=0 / MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad
-  MOPA_BENCH_BACKEND=gloo     (with torch.distributed.run) lets several ranks share one GPU: plumbing test only
+  MOPA_BENCH_BACKEND=gloo     lets several ranks share one GPU (RCCL refuses that): plumbing test only
+  MOPA_BENCH_DRY=1            launcher / process-group plumbing only (no GPU work): every rank joins the group, exchanges its
+                              scan seeds and point counts, rank 0 prints a JSON line with n_gpus = world (CPU test of --gpus N)
 """
 from __future__ import annotations
 
@@ -148,7 +154,7 @@ def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
     s = synth.make_scan(4242)
     coords = np.concatenate([s["coords"], np.zeros((len(s["coords"]), 1), np.int64)], 1)
     P2 = {k: v.detach().cpu().clone() for k, v in model2d.state_dict().items()}
-    P3 = {k: v.detach().cpu().float().clone() for k, v in model3d.state_dict().items()}
+    P3 = {k: v.detach().cpu().float().clone() for k, v in scn3d.fold_state_dict(model3d.state_dict()).items()}
     for P in (P2, P3):
         for k, v in P.items():
             if v.dtype.is_floating_point and "running" not in k:
@@ -190,7 +196,7 @@ def cpu_baseline_3d(model, seconds_budget=25.0):
     torch.set_num_threads(max(1, min(ncpu, 32)))  # more threads than that only adds contention on these op sizes
     pts = synth.lidar_points(12345)
     coords = np.concatenate([synth.voxelize(pts), np.zeros((len(pts), 1), np.int64)], 1)
-    P = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    P = {k: v.detach().cpu().float().clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
     for k, v in P.items():
         if "running" not in k:
             v.requires_grad_(True)
@@ -215,11 +221,65 @@ def cpu_baseline_3d(model, seconds_budget=25.0):
                 sample=f"{n} x (1 synthetic 34,880-pt scan, Net3DSeg geometry+fwd+bwd, torch-CPU fp32 oracle)")
 
 
+def launch_ranks(args) -> int:
+    """--gpus N from a plain process: start N ranks (one per GPU) under torch.distributed.run and wait for them.
+    Nothing in this process has touched the GPU (no HIP call is made by importing torch), so the children own the devices."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this platform (RCCL / xGMI peer mappings)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """MOPA_BENCH_DRY=1: the multi-process plumbing of `--gpus N` without a GPU (gloo): group setup, per-rank scan seeds,
+    the point-count exchange behind the global loss mean, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    from mopa_amd.step import global_mean_weight
+    if world > 1:
+        dist.init_process_group(os.environ.get("MOPA_BENCH_BACKEND", "gloo"))
+    B = args.batch or 8
+    seeds = [1000 * rank + i for i in range(2 * B)]
+    n_local = 34880 * B
+    w = global_mean_weight(n_local)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allseeds = [None] * world
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(allseeds, seeds)
+    else:
+        allseeds = [seeds]
+    if rank == 0:
+        flat = [s for r in allseeds for s in r]
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": "weak", "dry": True, "distinct_scans": len(set(flat)) == len(flat),
+                          "loss_weight_rank0": w, "config": {"parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
+    if os.environ.get("MOPA_BENCH_DRY") == "1":
+        return dry_run(args, rank, world)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)  # (only differs from LOCAL_RANK in the single-GPU plumbing test below)
     torch.cuda.set_device(local)
@@ -370,11 +430,24 @@ def main():
             l3.backward()
         return l2.detach(), l3.detach()
 
+    # Loss means are per rank; the reference's single-process mean over the global batch weights rank r by N_r / sum N
+    # (SURVEY 8e).  The point counts are known on the host when the batch is built, so the one-float exchange happens here,
+    # outside the timed region; with equal counts (this synthetic workload) every weight is exactly 1.
+    from mopa_amd.step import global_mean_weight
+    rank_weight = global_mean_weight(sum(int(b["locs"].shape[0]) for b in batches))
+    overlap_3d = os.environ.get("MOPA_BENCH_OVERLAP_AR", "1") != "0"
+
     def step(i):
         for o in opts:
             o.zero_grad()
+        work3 = None
         if joint:
             parts = half(batches[0], 1.0, True) + half(batches[1], 0.1, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
+            if world > 1 and overlap_3d:
+                # the 3D network's gradients are complete when the side stream drains: reduce them there, under the tail of the
+                # 2D backward on the main stream (RCCL orders its own stream behind the stream current at the call)
+                with torch.cuda.stream(dual.side):
+                    work3 = opts[0].all_reduce(async_op=True)
         else:
             b = batches[i % 2]
             # the voxel geometry depends on the coordinates only: built beside the previous step's backward (loader-side work)
@@ -387,10 +460,14 @@ def main():
             for t in parts:   # the 3D parts live in the side stream's pool
                 t.record_stream(torch.cuda.current_stream())
             loss = parts[0] + parts[1] + parts[2] + parts[3]
-        for o in opts:
+        for k, o in enumerate(opts):
+            if k == 0 and work3 is not None:
+                continue
             o.all_reduce()
+        if work3 is not None:
+            work3.wait()   # the current stream waits for the collective; the host does not block
         for o in opts:
-            o.step(1.0 / world)
+            o.step(rank_weight / world)
         return loss
 
     scans_per_step = 2 * B if joint else B
@@ -491,7 +568,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "scans_per_step_per_gpu": scans_per_step, "global_batch": scans_per_step * world,
-                       "points_per_scan": 34880, "image": "302x480", "parallelism": f"dp{world}"},
+                       "points_per_scan": 34880, "image": "302x480", "parallelism": f"dp{world}",
+                       "collective": "one flat fp32 gradient all-reduce per network per step (RCCL), 3D one overlapped with the 2D backward"
+                       if world > 1 else "none (1 rank)"},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "roofline": roof,
             "roofline_sparse_conv": sp,

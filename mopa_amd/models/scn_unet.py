@@ -9,6 +9,7 @@ Weights are ``(K, Cin, Cout)`` with K = 27 (submanifold) or 8 (stride-2 conv/dec
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -16,6 +17,11 @@ import torch.nn as nn
 from .. import sparse3d
 
 DIMENSION = 3
+
+# Layout of sparse-conv weights in state_dict(): "4d" = (filter_volume, 1, nIn, nOut), what current SparseConvNet (grouped
+# convolutions; `install.sh:1` installs HEAD) stores and strict-loads; "3d" = (filter_volume, nIn, nOut), the older releases
+# that xMUDA's published checkpoints were written with.  Loading accepts both whatever this says.
+CHECKPOINT_LAYOUT = os.environ.get("MOPA_SCN_CKPT_LAYOUT", "4d")
 
 
 class _Slot(nn.Module):
@@ -32,6 +38,15 @@ class _SparseConvParams(nn.Module):
         # SCN init: normal(0, sqrt(2 / (nIn * filter_volume)))  (Appendix A.4/A.5)
         self.weight = nn.Parameter(torch.randn(K, n_in, n_out) * math.sqrt(2.0 / (n_in * K)))
 
+    def checkpoint_shape(self):
+        K, n_in, n_out = self.weight.shape
+        return (K, 1, n_in, n_out) if CHECKPOINT_LAYOUT == "4d" else (K, n_in, n_out)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        w = destination[prefix + "weight"]
+        destination[prefix + "weight"] = w.reshape(self.checkpoint_shape())   # a view: same storage, SCN's shape
+
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # SparseConvNet checkpoints store (filter_volume, nIn, nOut) or, in other releases, (filter_volume, 1, nIn, nOut)
         # (SURVEY.md A.4/A.7); both map onto this module's (K, Cin, Cout) without touching the values.
@@ -39,6 +54,9 @@ class _SparseConvParams(nn.Module):
         w = state_dict.get(key)
         if w is not None and w.dim() == 4 and w.shape[1] == 1 and tuple(w.shape[0:1] + w.shape[2:]) == tuple(self.weight.shape):
             state_dict[key] = w.reshape(self.weight.shape)
+            super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+            state_dict[key] = w   # leave the caller's dict as it was
+            return
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
@@ -57,8 +75,9 @@ class UNetSCN(nn.Module):
         super().__init__()
         if residual_blocks:
             raise NotImplementedError("residual_blocks=True is not on the shipped hot path (config/xmuda.py:220)")
-        if m % 16 != 0:
-            raise NotImplementedError("m must be a multiple of 16 (MFMA tile width); the reference ships m=16")
+        if m not in (16, 32, 64):
+            raise NotImplementedError("m must be 16, 32 or 64 (MFMA tile width; the output-head kernels split a row over "
+                                      "m/4 lanes, a power of two <= 16); the reference ships m=16")
         self.in_channels, self.out_channels = in_channels, m
         self.m, self.block_reps, self.full_scale, self.num_planes = m, block_reps, full_scale, num_planes
         planes = [(i + 1) * m for i in range(num_planes)]
@@ -93,3 +112,14 @@ class UNetSCN(nn.Module):
     def geometry(self, locs) -> sparse3d.Geometry3D:
         dev = next(self.parameters()).device
         return sparse3d.Geometry3D(locs, self.num_planes, self.full_scale, dev)
+
+
+def checkpoint_shapes(model: nn.Module):
+    """Per trainable parameter of `model` (in ``parameters()`` order): the shape it has in ``state_dict()`` if that differs
+    from the live parameter (sparse-conv weights in SparseConvNet's 4-D layout), else ``None``.  For
+    ``FlatAdam(..., checkpoint_shapes=...)``."""
+    special = {}
+    for mod in model.modules():
+        if isinstance(mod, _SparseConvParams):
+            special[id(mod.weight)] = tuple(mod.checkpoint_shape())
+    return [special.get(id(p)) if special.get(id(p)) != tuple(p.shape) else None for p in model.parameters() if p.requires_grad]

@@ -22,6 +22,29 @@ class _Spec:
         self.__dict__.update(kw)
 
 
+def _teacher_scope_enter():
+    """Forward passes under ``torch.no_grad()`` never trust cached weight layouts, and leave none behind.
+
+    The caches of re-laid-out conv weights (dense2d / sparse3d) are validated by ``(WEIGHTS_EPOCH, tensor._version,
+    data_ptr)``.  ``torch_ema``'s ``average_parameters()`` / ``copy_to`` / ``restore`` -- what the reference uses for its
+    teacher forward, ``train_xmuda_mopa.py:221-226,264-280`` -- write through ``param.data.copy_`` which changes none of
+    the three, and that forward runs under ``torch.no_grad()``.  Bumping the epoch on entry and exit of every no-grad
+    forward makes the teacher pass read the live (EMA) weights and the next student pass rebuild from the restored ones;
+    cost: one weight re-layout (~0.1 ms) per no-grad forward.  Any other raw in-place write (e.g. ``dist.broadcast(p.data)``
+    after a first forward) needs ``mopa_amd.invalidate_weight_caches()``."""
+    if not torch.is_grad_enabled():
+        from .._lib import WEIGHTS_EPOCH
+        WEIGHTS_EPOCH[0] += 1
+        return True
+    return False
+
+
+def _teacher_scope_exit(entered):
+    if entered:
+        from .._lib import WEIGHTS_EPOCH
+        WEIGHTS_EPOCH[0] += 1
+
+
 def _require_cuda(module: nn.Module):
     dev = next(module.parameters()).device
     if dev.type != "cuda":
@@ -85,8 +108,11 @@ class Net2DSeg(nn.Module):
         tensors.update(dict(self.named_buffers()))
         self._calls += 1
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFF
-        feats, l1, l2, pred_all = dense2d.Net2DFunction.apply(spec, img, pix, self.training, float(self.net_2d.dropout.p),
-                                                             seed, *[tensors[k] for k in spec.order])
+        scope = _teacher_scope_enter()
+        with torch.cuda.device(dev):   # kernels launch on the current stream of the device the tensors live on
+            feats, l1, l2, pred_all = dense2d.Net2DFunction.apply(spec, img, pix, self.training, float(self.net_2d.dropout.p),
+                                                                 seed, *[tensors[k] for k in spec.order])
+        _teacher_scope_exit(scope)
         preds = {"feats": feats}
         if self.output_all:
             preds["seg_logit_all"] = pred_all
@@ -129,13 +155,17 @@ class Net3DSeg(nn.Module):
         locs, feats = data_batch["x"][0], data_batch["x"][1]
         geom = data_batch.get("geometry_3d") if isinstance(data_batch, dict) else None
         if geom is None:
-            geom = self.net_3d.geometry(locs)
+            with torch.cuda.device(dev):
+                geom = self.net_3d.geometry(locs)
         feats = feats.to(dev, non_blocking=True)
         spec = self._spec()
         tensors = dict(self.named_parameters())
         tensors.update(dict(self.named_buffers()))
         flat = [tensors[k] for k in spec.order]
-        f, l1, l2 = sparse3d.SCNNetFunction.apply(spec, geom, self.training, feats, *flat)
+        scope = _teacher_scope_enter()
+        with torch.cuda.device(dev):
+            f, l1, l2 = sparse3d.SCNNetFunction.apply(spec, geom, self.training, feats, *flat)
+        _teacher_scope_exit(scope)
         preds = {"feats": f, "seg_logit": l1}
         if self.dual_head:
             preds["seg_logit2"] = l2

@@ -4,6 +4,13 @@ All parameters of a network become views into ONE fp32 buffer and their ``.grad`
 buffer: one HIP launch updates the model (``mopa_adam_flat``) and the same flat buffer is what RCCL all-reduces
 over xGMI -- one collective per network per iteration.  Semantics of ``torch.optim.Adam`` as the
 reference configures it (``mopa/common/solver/build.py:7-21``, yaml ``OPTIMIZER: TYPE Adam, BASE_LR 1e-3``).
+
+``FlatAdam`` IS a ``torch.optim.Optimizer``: the reference hands its optimizer to ``build_scheduler`` (a
+``MultiStepLR`` that rewrites ``param_groups[0]["lr"]``, ``mopa/common/solver/build.py:24-47``,
+``train_xmuda_mopa.py:135-136``) and to ``CheckpointerV2`` which calls ``optimizer.state_dict()`` /
+``load_state_dict()`` (``mopa/common/utils/checkpoint.py:48-49,76-77``).  ``state_dict()`` has exactly the layout of
+``torch.optim.Adam`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, one param group), so optimizer
+checkpoints move between the reference and this build in both directions.
 """
 from __future__ import annotations
 
@@ -15,44 +22,135 @@ import torch.distributed as dist
 from ._lib import WEIGHTS_EPOCH, call, ptr, stream
 
 
-class FlatAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, checkpoint_shapes=None):
+        """``checkpoint_shapes``: optional list (one entry per parameter, ``None`` = the parameter's own shape) of the shapes
+        the moment tensors take in ``state_dict()`` -- ``mopa_amd.models.scn_unet.checkpoint_shapes(model)`` gives
+        SparseConvNet's 4-D conv-weight layout so that a reference-side ``torch.optim.Adam.load_state_dict`` of our
+        checkpoint pairs every moment with a parameter of the same shape."""
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("FlatAdam got no parameters")
-        dev = self.params[0].device
-        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]  # keep every view 16-byte aligned
+        if isinstance(params[0], dict):
+            raise ValueError("FlatAdam takes one flat list of parameters (the reference builds a single param group)")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self.params = params
+        dev = params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # keep every view 16-byte aligned
         self.n = sum(sizes)
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
+        self._slices = []
         off = 0
         with torch.no_grad():
-            for p, sz in zip(self.params, sizes):
+            for p, sz in zip(params, sizes):
                 view = self.flat[off:off + p.numel()].view_as(p)
                 view.copy_(p)
                 p.data = view
-                p.grad = self.grad[off:off + p.numel()].view_as(p)
+                self._slices.append((off, p.numel()))
                 off += sz
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self._attach_grads()
         self.t = 0
+        self._ckpt_shapes = list(checkpoint_shapes) if checkpoint_shapes is not None else [None] * len(params)
+        if len(self._ckpt_shapes) != len(params):
+            raise ValueError("checkpoint_shapes must have one entry per trainable parameter")
 
-    def zero_grad(self):
-        self.grad.zero_()  # hipMemsetAsync; the .grad views stay attached so autograd accumulates in place
+    # ---- reference-facing conveniences (kept from round 1)
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        self.param_groups[0]["lr"] = v
+
+    def _grad_view(self, i):
+        off, n = self._slices[i]
+        return self.grad[off:off + n].view_as(self.params[i])
+
+    def _attach_grads(self):
+        for i, p in enumerate(self.params):
+            p.grad = self._grad_view(i)
+
+    def _check_grads(self):
+        """Every ``p.grad`` must still be the view of the flat gradient buffer the HIP kernels accumulate into.
+        ``model.zero_grad()`` (torch's default sets grads to None) or a hook that replaces ``.grad`` would otherwise make
+        ``step`` and ``all_reduce`` read a stale flat buffer without any error: a detached gradient is folded back in and
+        the view is re-attached."""
+        base = self.grad.data_ptr()
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * self._slices[i][0]:
+                continue
+            view = self._grad_view(i)
+            if g is not None:   # autograd attached a fresh tensor after the view was dropped: keep what it accumulated
+                if g.shape != p.shape:
+                    raise RuntimeError("FlatAdam: a parameter's .grad was replaced by a tensor of another shape")
+                view.add_(g.to(view.dtype))
+            p.grad = view
+
+    def zero_grad(self, set_to_none: bool = False):
+        """In-place memset; the ``.grad`` views stay attached so the backward kernels accumulate into the flat buffer
+        (``set_to_none`` is accepted for API compatibility and ignored: dropping the views would break that)."""
+        self.grad.zero_()
+        self._checked = False
 
     def all_reduce(self, async_op=False):
         """Sum the flat gradient over ranks (RCCL when the process group backend is 'nccl')."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self._check_grads()
+            self._checked = True   # once per iteration (~0.1 ms of host time for 200 parameters)
             return dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=async_op)
         return None
 
-    def step(self, grad_scale: float = 1.0):
-        self.t += 1
-        b1, b2 = self.betas
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0, closure=None):
+        loss = closure() if closure is not None else None
+        if not getattr(self, "_checked", False):
+            self._check_grads()
+        self._checked = False
         if self.flat.device.type != "cuda":
             raise RuntimeError("FlatAdam.step needs the HIP extension on an MI355X (no CPU fallback)")
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.t += 1
         call("mopa_adam_flat", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
-             self.lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t),
+             float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t),
              grad_scale, stream())
-        WEIGHTS_EPOCH[0] += 1   # cached weight re-layouts (dense2d) are stale now
+        WEIGHTS_EPOCH[0] += 1   # cached weight re-layouts (dense2d / sparse3d) are stale now
+        return loss
+
+    # ---- checkpointing in torch.optim.Adam's layout (mopa/common/utils/checkpoint.py:48-49,76-77)
+    def state_dict(self):
+        state = {}
+        if self.t > 0:
+            for i, (off, n) in enumerate(self._slices):
+                shape = self._ckpt_shapes[i] or self.params[i].shape
+                state[i] = {"step": torch.tensor(float(self.t)),
+                            "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        groups[0]["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one param group with %d parameters" % len(self.params))
+        for k, v in groups[0].items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for key, st in sd["state"].items():
+            i = int(key)
+            off, n = self._slices[i]
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters with different step counts (one fused update per model)")
+        self.t = steps.pop() if steps else 0

@@ -66,6 +66,21 @@ class FlatEMA:
         self.num_updates = 0 if use_num_updates else None
         self.shadow = optimizer.flat.clone()
 
+    def state_dict(self):
+        """Same keys as ``torch_ema.ExponentialMovingAverage.state_dict()`` (per-parameter shadow tensors), so EMA
+        checkpoints written by the reference's ``CheckpointerV2(..., ema=...)`` style code load here and vice versa."""
+        shadow = [self.shadow[off:off + n].view(p.shape).clone() for (off, n), p in zip(self.opt._slices, self.opt.params)]
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": shadow, "collected_params": None}
+
+    def load_state_dict(self, sd):
+        self.decay = float(sd["decay"])
+        self.num_updates = sd["num_updates"]
+        sp = sd["shadow_params"]
+        if len(sp) != len(self.opt.params):
+            raise ValueError("FlatEMA.load_state_dict: %d shadow tensors for %d parameters" % (len(sp), len(self.opt.params)))
+        for (off, n), t in zip(self.opt._slices, sp):
+            self.shadow[off:off + n].copy_(t.reshape(-1))
+
     def update(self):
         decay = self.decay
         if self.num_updates is not None:

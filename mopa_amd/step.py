@@ -9,6 +9,26 @@ Results are bit-identical to sequential execution (same kernels, same per-networ
 from __future__ import annotations
 
 import torch
+import torch.distributed as dist
+
+
+def global_mean_weight(n_local: int, group=None) -> float:
+    """Weight that turns this rank's per-rank loss MEAN into its share of the mean over the global batch.
+
+    The reference is single-process: its losses are means over all points of the batch
+    (``mopa/train/train_xmuda_mopa.py:354-363,389-398``).  Data-parallel ranks each average over their own N_r points and the
+    gradients are summed and divided by the world size (``FlatAdam.step(grad_scale=w / world)``), which equals the global
+    mean only when every rank holds the same number of points.  In general rank r must be weighted by
+    ``w_r = N_r * world / sum_r N_r`` -- one float per rank per iteration, exchanged here.  The count is
+    known on the host as soon as the batch is collated, so call this from the loader side, not between kernels."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0
+    t = torch.tensor([float(n_local)], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    total = float(t.item())
+    return float(n_local) * dist.get_world_size(group) / total if total > 0 else 1.0
 
 
 class DualStream:

@@ -15,6 +15,8 @@ import torch
 def det_tensor(name: str, shape, dtype=torch.float32, salt: int = 0) -> torch.Tensor:
     rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) + 7919 * salt))
     shape = tuple(shape)
+    if len(shape) == 4 and shape[1] == 1 and "sparseModel" in name:   # SparseConvNet's (volume, 1, nIn, nOut) checkpoint layout
+        return det_tensor(name, (shape[0], shape[2], shape[3]), dtype, salt).reshape(shape)
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=torch.int64)

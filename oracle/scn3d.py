@@ -188,6 +188,13 @@ def bn_relu(x, weight, bias, running_mean, running_var, training: bool, leak: fl
 # --------------------------------------------------------------------------- #
 # parameter naming (A.7) and the network
 # --------------------------------------------------------------------------- #
+def fold_state_dict(sd: dict) -> dict:
+    """SparseConvNet checkpoints store conv weights as (volume, 1, nIn, nOut) (grouped-convolution releases) or
+    (volume, nIn, nOut); this oracle computes on the 3-D form.  Returns a dict with the 4-D tensors reshaped (views)."""
+    return {k: (v.reshape(v.shape[0], v.shape[2], v.shape[3]) if (hasattr(v, "dim") and v.dim() == 4 and v.shape[1] == 1
+                                                                 and "sparseModel" in k) else v) for k, v in sd.items()}
+
+
 def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="sparseModel."):
     """Ordered {name: shape} for UNetSCN (scn_unet.py:25-30 + scn.UNet A.7)."""
     planes = [(i + 1) * m for i in range(num_planes)]

@@ -37,7 +37,7 @@ def main():
     torch.manual_seed(0)
     m = 16
     print(f"{'level':>5} {'table':>6} {'rows':>8} {'rules':>9} {'cin':>4} {'cout':>4} {'wave us':>9} {'grouped us':>10} "
-          f"{'ws us':>8} {'t40 us':>7} {'ws frac':>7} {'TF/s':>6} same ws_err")
+          f"{'gt us':>8} {'t40 us':>7} {'gt frac':>7} {'TF/s':>6} same ws_err")
     for l in range(L):
         C = m * (l + 1)
         cases = [("subm", g.nbr27[l], C, C), ("subm", g.nbr27[l], 2 * C, C)]
@@ -68,15 +68,16 @@ def main():
                 call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin,
                      ptr(wp if packed else w), cout, 2 if packed else 0, o2.p, o2.ld, ptr(ws), ws.numel(), stream())
 
-            ntw_ws = s3.query("mopa_spconv_ws_ntw", K, Ao, cin, cout)
+            ntw_ws = s3.query("mopa_spconv_gt_handles", K, Ao, cin, cout)
             o3 = s3.new_view(Ao, cout, "cuda")
             wws = torch.empty_like(w)
+            ws3 = torch.empty(max(256, s3.query("mopa_spconv_gt_workspace_bytes", K, Ao, cin, cout)), dtype=torch.uint8, device="cuda")
             if ntw_ws:
-                call("mopa_spconv_pack_weight_ws", ptr(w), K, cin, cout, 0, ntw_ws, ptr(wws), stream())
+                call("mopa_spconv_pack_weight_gt", ptr(w), K, cin, cout, 0, ptr(wws), stream())
 
             def ws_kernel():
-                call("mopa_spconv_fwd_ws", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin, ptr(wws), cout, 0,
-                     o3.p, o3.ld, stream())
+                call("mopa_spconv_fwd_gt", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, Ao, xv.p, xv.ld, cin, ptr(wws), cout, 0,
+                     o3.p, o3.ld, ptr(ws3), ws3.numel(), stream())
 
             tw = timed(wave, reps) if cin <= 192 else float('nan')   # the dense-table kernel stops at 192 input channels
             tg = timed(grouped, reps)

@@ -190,7 +190,7 @@ def det_tensor_like(k, v):
 
 
 def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64):
-    P = {k: v.detach().cpu().to(dtype).clone() for k, v in model.state_dict().items()}
+    P = {k: v.detach().cpu().to(dtype).clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
     for k in P:
         if "running" not in k:
             P[k].requires_grad_(True)
@@ -215,7 +215,7 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
         # well-conditioned eval case: running statistics := the batch statistics of this input (oracle pass with
         # momentum 1), otherwise arbitrary running stats blow activations up over 7 levels and ReLU-mask flips
         # dominate every fp32-vs-fp64 comparison.
-        P0 = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+        P0 = {k: v.detach().cpu().double().clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
         old, scn3d.BN_MOMENTUM = scn3d.BN_MOMENTUM, 1.0
         try:
             scn3d.net3dseg_forward(P0, scn3d.Geometry(c, num_planes), feats.double(), training=True,
@@ -224,7 +224,7 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
             scn3d.BN_MOMENTUM = old
         model.load_state_dict({k: v.float() for k, v in P0.items()})
     f_dev = feats.cuda().requires_grad_(True)
-    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    sd_before = {k: v.clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
     out = model({"x": [torch.from_numpy(c), f_dev]})
     gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
     sum((out[k] * gouts[k].cuda()).sum() for k in out).backward()

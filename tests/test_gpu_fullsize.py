@@ -346,7 +346,7 @@ def test_single_head_ten_classes_and_empty_image_indices():
     assert o2["seg_logit"].shape == (150, 10) and o2["seg_logit_all"].shape == (2, 33, 50, 10) and o3["seg_logit"].shape == (500, 10)
     P2 = {k: det_tensor(k, v) for k, v in net2d.param_shapes(10, False).items()}
     r2 = net2d.net2dseg_forward(P2, img, idx, dual_head=False, training=False)
-    P3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
+    P3 = {k: v.detach().cpu() for k, v in scn3d.fold_state_dict(m3.state_dict()).items()}
     r3 = scn3d.net3dseg_forward(P3, scn3d.Geometry(coords, 3), torch.ones(500, 1), dual_head=False, training=False, num_planes=3)
     for got, ref in ((o2["seg_logit"], r2["seg_logit"]), (o2["seg_logit_all"], r2["seg_logit_all"]), (o3["seg_logit"], r3["seg_logit"])):
         r = ref.detach().numpy()

@@ -19,8 +19,9 @@ def test_factory_returns_model_and_metric_with_reference_names():
     sd2, sd3 = m2.state_dict(), m3.state_dict()
     for k, shape in net2d.param_shapes(5, True).items():
         assert tuple(sd2[k].shape) == tuple(shape), k
-    for k, shape in scn3d.unet_param_shapes().items():
-        assert tuple(sd3["net_3d." + k].shape) == tuple(shape), k
+    for k, shape in scn3d.unet_param_shapes().items():   # checkpoints carry SparseConvNet's (K, 1, Cin, Cout)
+        got = tuple(sd3["net_3d." + k].shape)
+        assert (got[:1] + got[2:] if len(got) == 4 else got) == tuple(shape), k
     assert set(sd2) == set(net2d.param_shapes(5, True))
     # plain dict / attribute configs both work, unsupported backbones raise like the reference (xmuda_arch.py:37,98)
     cfg.MODEL_3D.TYPE = "SPVCNN"

@@ -100,7 +100,7 @@ def test_product_state_dict_matches_reference_names(g6, dual, key):
     from mopa_amd.models.build import build_model_3d
     cfg = default_cfg(num_classes=5, dual_head=dual)
     model, _ = build_model_3d(cfg)
-    got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    got = [[k, _fold(v.shape)] for k, v in model.state_dict().items()]   # (K,1,Cin,Cout) in checkpoints == (K,Cin,Cout)
     want = [[k, _fold(v)] for k, v in g6[key]["state_dict"]]
     # names, shapes and traversal order: torch optimizers / torch_ema index their state by parameter order
     assert got == want
