@@ -42,10 +42,6 @@ SIGNATURES = {
     "mopa_spconv_transpose_weight": ("i", "piiipp"),
     "mopa_spconv_grouped_wants_packed": ("i", "iiii"),
     "mopa_spconv_pack_weight": ("i", "piiiiipp"),
-    "mopa_spconv_gt_handles": ("i", "iiii"),
-    "mopa_spconv_gt_workspace_bytes": ("z", "iiii"),
-    "mopa_spconv_pack_weight_gt": ("i", "piiiipp"),
-    "mopa_spconv_fwd_gt": ("i", "ppppiipiipiipipzp"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
     # ---- pseudo-label update (pseudo.hip)

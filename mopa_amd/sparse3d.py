@@ -21,8 +21,6 @@ import torch
 from . import _lib
 from ._lib import GradSink, call, ptr, query, stream, workspace
 
-GT_KERNEL = os.environ.get("MOPA_SPCONV_GT", "1") != "0"   # gather-tile kernel for 64..128 output channels (A/B switch)
-
 BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
 BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
 LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
@@ -191,12 +189,6 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
     K, A_out = nbr.shape
     cin, cout = x.C, out.C
     assert out.rows == A_out and w.shape == ((K, cout, cin) if w_transposed else (K, cin, cout)), (nbr.shape, cin, cout, w.shape)
-    if (rb is not None and GT_KERNEL and A_out * 8 * x.ld * 4 < 1 << 32 and x.ld % 4 == 0 and out.ld % 4 == 0
-            and query("mopa_spconv_gt_handles", K, A_out, cin, cout)):
-        # wide outputs: one block per 64-row tile and all columns, gathered rows shared through LDS (spconv_gt.hip)
-        wk = _weight_form(w, ("pack_gt", int(w_transposed)))
-        spconv_launch(nbr, x, wk, out, w_flip, rb, "gt")
-        return
     ntw = query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout) if rb is not None else 0
     if A_out * 8 * x.ld * 4 >= 1 << 32:   # the pipelined kernels use 32-bit byte offsets into the input rows
         ntw = 0
@@ -225,9 +217,6 @@ def _weight_form(w: torch.Tensor, form: tuple) -> torch.Tensor:
     if form[0] == "pack":
         t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
         call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], form[1], form[2], ptr(t), stream())
-    elif form[0] == "pack_gt":
-        t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
-        call("mopa_spconv_pack_weight_gt", ptr(w), K, w.shape[1], w.shape[2], form[1], ptr(t), stream())
     else:
         t = spconv_transpose_weight(w)
     if len(_weight_cache) > 4096:
@@ -243,12 +232,7 @@ def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_fli
     # measured on MI355X (profiles/bench_spconv.py): 27-offset tables run the pipelined kernels on packed weights (one wave
     # per tile at 16 channels, four waves per tile and column group above); the 8-offset down/up tables the dense-table
     # wave kernel, except on the shortest levels (< 200 tiles) where the 4-wave block kernel with LDS-staged weights wins.
-    if packed == "gt":
-        gs, go, gi, gout = rb
-        ws = _ws(query("mopa_spconv_gt_workspace_bytes", K, A_out, cin, cout), wk.device)
-        call("mopa_spconv_fwd_gt", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
-             int(w_flip), out.p, out.ld, ptr(ws), ws.numel(), stream())
-    elif packed:
+    if packed:
         gs, go, gi, gout = rb
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
              int(w_flip) | 2, out.p, out.ld, 0, 0, stream())

@@ -1,0 +1,327 @@
+"""BASELINE.json configs [2], [3], [4] exercised at FULL size on the GPU (round-2 additions; VERDICT r1 "configs_untested").
+
+* configs[4]  A2D2->SemanticKITTI shape: one 120,000-point scan, 10 classes -- Net3DSeg forward + backward against the
+  fp64 oracle (the only config with > 100 k points per scan and C = 10).
+* configs[2]  full xMUDA joint step, 8 source + 8 target scans (302x480 image + 34,880 points each) through the bench's own
+  stream schedule -- size-independent properties: the two halves' gradients add up, every scan of the batch is computed
+  like the same scan alone (eval mode), losses finite, nothing left on the side stream.
+* configs[3]  MoPA iteration per GPU (4 + 4 scans): pseudo-label CE + SAM-mask consistency + the third 3D pass on the
+  object-augmented batch -- the full loss of ONE target scan against the oracle, then the 4 + 4 step through properties.
+Tolerances are stated where they are used; the integer parts (active sets, pseudo labels) are compared exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CLASS_WEIGHTS = [2.68678412, 4.36182969, 5.47896839, 3.89026883, 1.0]
+
+
+def _models(num_classes=5, seed=0, train=True, dropout=0.0):
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    torch.manual_seed(seed)
+    cfg = default_cfg(num_classes=num_classes, dual_head=True)
+    m2, m3 = build_model_2d(cfg)[0].cuda(), build_model_3d(cfg)[0].cuda()
+    m2.net_2d.dropout.p = dropout
+    return m2.train(train), m3.train(train)
+
+
+def test_config4_kitti_shape_120k_points_10_classes_vs_oracle():
+    """Net3DSeg forward + backward on one 120,000-point KITTI-shape scan, C = 10, against the fp64 oracle; the fp32 oracle's own
+    distance from it is the yardstick (same rule as tests/test_gpu_3d.py: <= 4x that, floor 2e-4 of the tensor's scale)."""
+    from mopa_amd import synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    from oracle import scn3d
+    from oracle.params import det_tensor
+    pts = synth.lidar_points(77, synth.KITTI)
+    c = np.concatenate([synth.voxelize(pts), np.zeros((len(pts), 1), np.int64)], 1)
+    assert c.shape == (120_000, 4) and c[:, :3].max() < 4096
+    cfg = default_cfg(num_classes=10, dual_head=True)
+    model, _ = build_model_3d(cfg)
+    model.load_state_dict({k: det_tensor(k, v.shape) for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
+    rng = np.random.Generator(np.random.PCG64(4))
+    feats = torch.ones(len(pts), 1)
+    out = model({"x": [torch.from_numpy(c), feats]})
+    assert out["seg_logit"].shape == (120_000, 10) and out["feats"].shape == (120_000, 16)
+    gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
+    sum((out[k] * gouts[k].cuda()).sum() for k in out).backward()
+    geom = scn3d.Geometry(c, 7)
+
+    def oracle(dtype):
+        P = {k: v.to(dtype).clone() for k, v in sd0.items()}
+        for k in P:
+            if "running" not in k:
+                P[k].requires_grad_(True)
+        ref = scn3d.net3dseg_forward(P, geom, feats.to(dtype), training=True)
+        sum((ref[k] * gouts[k].to(dtype)).sum() for k in ref).backward()
+        return P, ref
+
+    P64, r64 = oracle(torch.float64)
+    P32, r32 = oracle(torch.float32)
+
+    def close(got, truth, yard, what):
+        scale = max(1e-6, float(np.abs(truth).max()))
+        err, yerr = float(np.abs(got - truth).max()), float(np.abs(yard - truth).max())
+        assert err <= max(4.0 * yerr, 2e-4 * scale), (what, err, yerr, scale)
+
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        close(out[k].detach().cpu().double().numpy(), r64[k].detach().numpy(), r32[k].detach().double().numpy(), k)
+    named = dict(model.named_parameters())
+    for k, p in P64.items():
+        if p.requires_grad:
+            close(named[k].grad.cpu().double().numpy(), p.grad.numpy(), P32[k].grad.double().numpy(), k)
+    # integer side of this config: the device geometry equals the oracle's at 120 k points (bit-exact)
+    g = model.net_3d.geometry(torch.from_numpy(c))
+    assert g.num_active == geom.num_active
+    assert np.array_equal(g.point_row.cpu().numpy(), geom.point_row)
+    for l in (0, 3, 6):
+        assert np.array_equal(g.nbr27[l].cpu().numpy(), geom.nbr27[l])
+
+
+def _bench_batches(B, seed0=0, with_mopa=False):
+    """The bench's synthetic batches (bench.py main()): resident tensors, reference collate layout."""
+    from mopa_amd import synth
+    from mopa_amd.models.xmuda_arch import Net2DSeg
+    H, W = 302, 480
+    out = []
+    for j in range(2):
+        scans = [synth.make_scan(seed0 + j * B + i) for i in range(B)]
+        b = synth.collate(scans)
+        bt = dict(locs=b["x"][0].cuda(), feats=b["x"][1].cuda(), label=b["seg_label"].cuda(), img=b["img"].cuda(),
+                  pix=Net2DSeg.pack_indices(b["img_indices"], H, W, "cuda"), idx=b["img_indices"], raw=b, scans=scans)
+        if with_mopa and j == 1:
+            bt["pl2d"], bt["pl3d"] = b["pseudo_label_2d"].cuda(), b["pseudo_label_3d"].cuda()
+            bt["sam"] = [m.cuda() for m in b["sam_mask_ls"]]
+        out.append(bt)
+    return out
+
+
+def _grads(models):
+    return [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for m in models for p in m.parameters()]
+
+
+def test_config2_joint_step_8_plus_8_scans_full_size():
+    from mopa_amd.common.utils.loss import seg_ce, xm_kl
+    from mopa_amd.step import DualStream
+    B = 8
+    src, trg = _bench_batches(B)
+    assert src["locs"].shape == (B * 34880, 4) and src["img"].shape == (B, 3, 302, 480)
+    m2, m3 = _models()
+    cw = torch.tensor(CLASS_WEIGHTS, device="cuda")
+    dual = DualStream("cuda", order_2d_first=True)
+    ready = torch.cuda.Event()
+    ready.record()
+
+    def half(b, lam, supervised):
+        o2, o3 = dual.forward(m2, m3, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
+                              {"x": [b["locs"], b["feats"]]}, inputs_ready=ready)
+        l2 = lam * xm_kl(o2["seg_logit2"], o3["seg_logit"])
+        if supervised:
+            l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
+        with dual.on_side(o2["seg_logit"]):
+            l3 = lam * xm_kl(o3["seg_logit2"], o2["seg_logit"])
+            if supervised:
+                l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+        l2.backward()
+        l3.backward()
+        dual.join()
+        torch.cuda.synchronize()
+        assert o2["seg_logit_all"].shape == (B, 302, 480, 5) and o3["seg_logit"].shape == (B * 34880, 5)
+        return float(l2), float(l3)
+
+    def zero():
+        for m in (m2, m3):
+            for p in m.parameters():
+                p.grad = None
+
+    # BN running statistics advance with every forward: snapshot and restore so that the three runs see the same state
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (m2, m3)]
+
+    def restore():
+        for m, s in zip((m2, m3), state):
+            m.load_state_dict(s)
+
+    l_src = half(src, 1.0, True)
+    g_src = _grads((m2, m3))
+    zero(); restore()
+    l_trg = half(trg, 0.1, False)
+    g_trg = _grads((m2, m3))
+    zero(); restore()
+    a = half(src, 1.0, True)
+    b = half(trg, 0.1, False)   # gradients accumulate over the two domains of an iteration (train_xmuda_mopa.py:418,578)
+    g_both = _grads((m2, m3))
+    assert all(np.isfinite(x) for x in l_src + l_trg) and a == l_src
+    # same kernels, same order -> the accumulated gradient is the sum of the two halves up to fp32 rounding of one addition
+    for gs, gt, gb in zip(g_src, g_trg, g_both):
+        ref = gs.double() + gt.double()
+        scale = max(1e-12, float(ref.abs().max()))
+        assert float((gb.double() - ref).abs().max()) <= 2e-6 * scale + 1e-12
+    assert abs(b[0] - l_trg[0]) <= 1e-6 * max(1.0, abs(l_trg[0]))
+    # every scan of the batch is computed like the same scan alone (eval mode: no batch statistics couple the scans).
+    # fp32 tolerance 1e-4 of the logit scale: tiles of 64 rows regroup, so the summation order inside a row changes.
+    m2.eval(); m3.eval()
+    with torch.no_grad():
+        o2 = m2({"img": src["img"], "img_indices": src["idx"]})
+        o3 = m3({"x": [src["locs"], src["feats"]]})
+        i = 5
+        n = 34880
+        s = src["scans"][i]
+        c1 = torch.cat([torch.from_numpy(s["coords"]), torch.zeros(n, 1, dtype=torch.int64)], 1)
+        o3_1 = m3({"x": [c1, torch.ones(n, 1)]})
+        o2_1 = m2({"img": src["img"][i:i + 1], "img_indices": [src["idx"][i]]})
+    # 3D: 1e-4 of the logit scale (tiles of 64 rows regroup, so the summation order inside a row changes); 2D: 1e-3 (batch 8 and
+    # batch 1 pick different Winograd / direct kernels per layer, ~1e-5 each over 44 layers)
+    for full, one, tol in ((o3["seg_logit"][i * n:(i + 1) * n], o3_1["seg_logit"], 1e-4),
+                           (o2["seg_logit"][i * n:(i + 1) * n], o2_1["seg_logit"], 1e-3),
+                           (o2["seg_logit_all"][i], o2_1["seg_logit_all"][0], 1e-3)):
+        scale = float(one.abs().max())
+        assert float((full - one).abs().max()) <= tol * scale, float((full - one).abs().max()) / scale
+
+
+def test_config3_mopa_target_loss_of_one_scan_vs_oracle():
+    """The target half of a MoPA iteration (train_xmuda_mopa.py:426-480,558-579) on ONE full-size scan: cross-modal KL +
+    pseudo-label CE + SAM-mask consistency (lambda 0.01) + CE of the third 3D pass on the object-augmented cloud; loss values
+    and the gradient norms of both networks against the fp64 oracle.  Tolerance: 2e-4 relative on the losses (fp32 sums over
+    145 k pixels / 35 k points), 2 % on gradient norms of whole networks (BN-ReLU mask flips, see tests/test_gpu_2d.py)."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import mask_cons_loss, seg_ce, softmax_lastdim, xm_kl
+    from oracle import losses as ol
+    from oracle import net2d, scn3d
+    from oracle.params import det_tensor
+    m2, m3 = _models(dropout=0.0)
+    for m in (m2, m3):
+        m.load_state_dict({k: det_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    s = synth.make_scan(31)
+    b = synth.collate([s])
+    n = 34880
+    rng = np.random.Generator(np.random.PCG64(5))
+    centre = s["coords"][rng.integers(0, n)]
+    obj = np.clip(centre[None, :] + rng.integers(-15, 16, (500, 3)), 0, 4095)
+    vc = np.concatenate([np.concatenate([s["coords"], obj]), np.zeros((n + 500, 1), np.int64)], 1)
+    vlab = torch.from_numpy(np.concatenate([s["pseudo_label_3d"], np.full(500, 1)]).astype(np.int64))
+    pl2, pl3 = b["pseudo_label_2d"], b["pseudo_label_3d"]
+    sd2 = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu()) for k, v in m2.state_dict().items()}
+    sd3 = {k: v.detach().cpu().double() for k, v in scn3d.fold_state_dict(m3.state_dict()).items()}
+
+    o2, o3 = m2(b), m3(b)
+    ov = m3({"x": [torch.from_numpy(vc), torch.ones(n + 500, 1)]})
+    l2 = 0.1 * xm_kl(o2["seg_logit2"], o3["seg_logit"]) + seg_ce(o2["seg_logit"], pl2.cuda()) + \
+        0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam_mask_ls"], True)
+    l3 = 0.1 * xm_kl(o3["seg_logit2"], o2["seg_logit"]) + seg_ce(o3["seg_logit"], pl3.cuda()) + seg_ce(ov["seg_logit"], vlab.cuda())
+    l2.backward()
+    l3.backward()
+    torch.cuda.synchronize()
+
+    for P in (sd2, sd3):
+        for k, v in P.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+    c1 = np.concatenate([s["coords"], np.zeros((n, 1), np.int64)], 1)
+    r2 = net2d.net2dseg_forward(sd2, b["img"].double(), b["img_indices"], training=True, dropout_p=0.0)
+    r3 = scn3d.net3dseg_forward(sd3, scn3d.Geometry(c1, 7), torch.ones(n, 1, dtype=torch.float64), training=True)
+    rv = scn3d.net3dseg_forward(sd3, scn3d.Geometry(vc, 7), torch.ones(n + 500, 1, dtype=torch.float64), training=True)
+    ref2 = 0.1 * ol.xm_kl(r2["seg_logit2"], r3["seg_logit"]) + ol.seg_ce(r2["seg_logit"], pl2) + \
+        0.01 * ol.mask_cons_loss(torch.softmax(r2["seg_logit_all"], 3), b["sam_mask_ls"], True)
+    ref3 = 0.1 * ol.xm_kl(r3["seg_logit2"], r2["seg_logit"]) + ol.seg_ce(r3["seg_logit"], pl3) + ol.seg_ce(rv["seg_logit"], vlab)
+    ref2.backward()
+    ref3.backward()
+    assert abs(float(l2) - float(ref2)) <= 2e-4 * abs(float(ref2)), (float(l2), float(ref2))
+    assert abs(float(l3) - float(ref3)) <= 2e-4 * abs(float(ref3)), (float(l3), float(ref3))
+    for model, P, pre in ((m2, sd2, ""), (m3, sd3, "")):
+        got = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).item()
+        want = float(torch.sqrt(sum((v.grad ** 2).sum() for v in P.values() if v.requires_grad)))
+        assert abs(got - want) <= 2e-2 * want, (got, want)
+    # the heads (no BN between them and the loss) are tight: 1e-3 of the gradient's scale
+    for model, P in ((m2, sd2), (m3, sd3)):
+        named = dict(model.named_parameters())
+        for k in ("linear.weight", "linear2.weight"):
+            g, r = named[k].grad.cpu().double(), P[k].grad
+            assert float((g - r).abs().max()) <= 1e-3 * float(r.abs().max()), k
+
+
+def test_config3_mopa_iteration_4_plus_4_full_size_properties():
+    """One MoPA iteration per GPU at BASELINE configs[3] shape (4 source + 4 target scans): runs through the bench's stream
+    schedule with the EMA teacher's pseudo labels produced on the device, Adam steps lower the loss, and the device pseudo
+    labels equal the oracle's refine_pseudo_labels on the same probabilities (integer outputs: exact)."""
+    from mopa_amd.common.utils.loss import mask_cons_loss, seg_ce, softmax_lastdim, xm_kl
+    from mopa_amd.optim import FlatAdam
+    from mopa_amd.pseudo import FlatEMA, pseudo_labels
+    from mopa_amd.step import DualStream
+    from oracle import pseudo as opseudo
+    B = 4
+    src, trg = _bench_batches(B, seed0=100, with_mopa=True)
+    m2, m3 = _models(dropout=0.4, seed=1)
+    opt2, opt3 = FlatAdam(m2.parameters(), lr=1e-3), FlatAdam(m3.parameters(), lr=1e-3)
+    ema2, ema3 = FlatEMA(opt2, 0.99), FlatEMA(opt3, 0.99)
+    cw = torch.tensor(CLASS_WEIGHTS, device="cuda")
+    dual = DualStream("cuda", order_2d_first=True)
+    ready = torch.cuda.Event()
+    ready.record()
+    # object-augmented third batch: every target scan + a 500-point cluster, re-voxelised by the collate
+    rng = np.random.Generator(np.random.PCG64(9))
+    vl, vlab = [], []
+    for i, s in enumerate(trg["scans"]):
+        c = s["coords"]
+        obj = np.clip(c[rng.integers(0, len(c))][None, :] + rng.integers(-15, 16, (500, 3)), 0, 4095)
+        cc = np.concatenate([c, obj])
+        vl.append(torch.cat([torch.from_numpy(cc), torch.full((len(cc), 1), i, dtype=torch.int64)], 1))
+        vlab.append(torch.from_numpy(np.concatenate([s["pseudo_label_3d"], np.full(500, 1)]).astype(np.int64)))
+    vgi_locs, vgi_lab = torch.cat(vl).cuda(), torch.cat(vlab).cuda()
+    vgi_feats = torch.ones(vgi_locs.shape[0], 1, device="cuda")
+
+    def teacher_labels():
+        """train_xmuda_mopa.py:264-335: EMA weights, eval mode, no grad, entropy-weighted fusion, per-class median refinement."""
+        m2.eval(); m3.eval()
+        with torch.no_grad(), ema2.average_parameters(), ema3.average_parameters():
+            t2 = m2({"img": trg["img"], "point_pix_2d": trg["pix"], "img_indices": None})["seg_logit"]
+            t3 = m3({"x": [trg["locs"], trg["feats"]]})["seg_logit"]
+        m2.train(); m3.train()
+        pl2, pl3 = pseudo_labels(t2, t3, xm=True)
+        return t2, t3, pl2, pl3
+
+    t2, t3, pl2, pl3 = teacher_labels()
+    from mopa_amd.pseudo import fuse
+    maxp, lab = fuse(t2, t3)   # device fusion (fp32); the refinement on top of it is integer logic: exact against the oracle
+    assert torch.equal(pl2.cpu(), opseudo.refine_pseudo_labels(maxp.cpu(), lab.cpu()))
+    assert pl2.shape == (B * 34880,) and int((pl2 >= 0).sum()) > 0 and int((pl2 == -100).sum()) > 0 and torch.equal(pl2, pl3)
+
+    def iteration():
+        opt2.zero_grad(); opt3.zero_grad()
+        tot = []
+        for b, lam, sup in ((src, 1.0, True), (trg, 0.1, False)):
+            o2, o3 = dual.forward(m2, m3, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
+                                  {"x": [b["locs"], b["feats"]]}, inputs_ready=ready)
+            l2 = lam * xm_kl(o2["seg_logit2"], o3["seg_logit"])
+            if sup:
+                l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
+            else:
+                l2 = l2 + seg_ce(o2["seg_logit"], pl2) + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)
+            with dual.on_side(o2["seg_logit"]):
+                l3 = lam * xm_kl(o3["seg_logit2"], o2["seg_logit"])
+                if sup:
+                    l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+                else:
+                    gv = dual.geometry_ahead(m3, vgi_locs, ready)
+                    ov = m3({"x": [vgi_locs, vgi_feats], "geometry_3d": gv})
+                    l3 = l3 + seg_ce(o3["seg_logit"], pl3) + seg_ce(ov["seg_logit"], vgi_lab)
+            l2.backward()
+            l3.backward()
+            tot += [l2.detach(), l3.detach()]
+        dual.join()
+        for t in tot:
+            t.record_stream(torch.cuda.current_stream())
+        opt2.step(); opt3.step()
+        ema2.update(); ema3.update()
+        return float(sum(tot))
+
+    losses = [iteration() for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert ema2.num_updates == 5 and torch.isfinite(ema2.shadow).all() and not torch.equal(ema2.shadow, opt2.flat)
+    # the teacher now differs from the student: its pseudo labels are still valid class ids or ignore
+    _, _, q2, _ = teacher_labels()
+    assert set(torch.unique(q2).tolist()) <= {-100, 0, 1, 2, 3, 4}
