@@ -141,6 +141,21 @@ class Conv2dTimer:
     summary = ConvTimer.summary
 
 
+def _cpu_passes(one_pass, seconds_budget, max_passes, what):
+    """Bounded CPU sample: one warm-up pass, then up to `max_passes` timed passes inside the time
+    budget; value = 1 / median pass time (min and count reported in `sample`)."""
+    warm = one_pass()
+    times = []
+    while len(times) < max_passes and sum(times) + warm < seconds_budget:
+        times.append(one_pass())
+    if not times:
+        times = [warm]
+    med = float(np.median(times))
+    return dict(value=1.0 / med, unit="scans/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(times)} timed passes after 1 warm-up within a {seconds_budget:.0f} s budget, each = {what}; "
+                       f"median {med:.2f} s, min {min(times):.2f} s per scan")
+
+
 def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
     """CPU restatement (oracle, kind 'port') of one scan of the joint step: 2D + 3D forward/backward + CE/KL losses."""
     from mopa_amd import synth
@@ -173,16 +188,8 @@ def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
         l3.backward()
         return time.time() - t0
 
-    warm = one_pass()
-    n, t_total = 0, 0.0
-    while n < 3 and t_total + warm < seconds_budget:
-        t_total += one_pass()
-        n += 1
-    if n == 0:
-        n, t_total = 1, warm
-    return dict(value=n / t_total, unit="scans/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} x (1 synthetic scan: 302x480 image + 34,880 pts, Net2DSeg+Net3DSeg fwd+bwd+CE+KL, "
-                       "torch-CPU fp32 oracle)")
+    return _cpu_passes(one_pass, seconds_budget, 10,
+                       "1 synthetic scan: 302x480 image + 34,880 pts, Net2DSeg+Net3DSeg fwd+bwd+CE+KL, torch-CPU fp32 oracle")
 
 
 def cpu_baseline_3d(model, seconds_budget=25.0):
@@ -210,15 +217,7 @@ def cpu_baseline_3d(model, seconds_budget=25.0):
         (ce(out["seg_logit"], lab) + ce(out["seg_logit2"], lab)).backward()
         return time.time() - t0
 
-    warm = one_pass()
-    n, t_total = 0, 0.0
-    while n < 5 and t_total + warm < seconds_budget:
-        t_total += one_pass()
-        n += 1
-    if n == 0:
-        n, t_total = 1, warm
-    return dict(value=n / t_total, unit="scans/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} x (1 synthetic 34,880-pt scan, Net3DSeg geometry+fwd+bwd, torch-CPU fp32 oracle)")
+    return _cpu_passes(one_pass, seconds_budget, 10, "1 synthetic 34,880-pt scan, Net3DSeg geometry+fwd+bwd, torch-CPU fp32 oracle")
 
 
 def launch_ranks(args) -> int:
@@ -472,14 +471,8 @@ def main():
 
     scans_per_step = 2 * B if joint else B
     t_setup = time.perf_counter()
-    from mopa_amd import dense2d as dense2d_mod
-    wgrad_stream_on = dense2d_mod.WGRAD_STREAM
     for i in range(args.warmup):
-        # the bracketed steps of the timed region run the 2D weight gradients on the main stream (see below): warm that mode up
-        # too (its temporaries come from another stream's pool of the caching allocator)
-        dense2d_mod.WGRAD_STREAM = wgrad_stream_on and not (i == 0 and args.warmup > 1)
         step(i)
-    dense2d_mod.WGRAD_STREAM = wgrad_stream_on
     torch.cuda.synchronize()
     print(f"[bench] rank {rank}: warmup {args.warmup} steps in {time.perf_counter() - t_setup:.2f}s", file=sys.stderr, flush=True)
     if world > 1:
@@ -495,9 +488,9 @@ def main():
     for i in range(args.steps):
         timer.enabled = timer2d.enabled = ev_stride > 0 and i % ev_stride == 0
         n_ev_steps += int(timer.enabled)
-        # on the bracketed steps the 2D weight gradients run on the main stream again: a bracket around a launch would otherwise
-        # time it while a second stream of this same branch shares the chip (the 3D side stream stays, as the note below says)
-        dense2d_mod.WGRAD_STREAM = wgrad_stream_on and not timer.enabled
+        # the bracketed steps run in the SAME stream configuration as every other step (weight-gradient stream and 3D side stream
+        # on): the brackets then time each launch as it runs inside `value`'s step, sharing the chip with the other streams --
+        # which is also what `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r2_final_*)
         loss = step(i)
         if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
             if step_times == "sync":
@@ -531,29 +524,31 @@ def main():
                   "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
-        t3 = os.path.join(ROOT, "profiles", "r1_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d`
+        t3 = os.path.join(ROOT, "profiles", "r2_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d` (profiles/traffic.py)
         if sp and os.path.exists(t3):
             d3 = json.load(open(t3))
             fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
-                sp["traffic_source"] = "profiles/r1_3d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 3d workload)"
+                sp["traffic_source"] = "profiles/r2_3d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload 3d`, per launch)"
         if sp and joint:
             sp["note"] = ("launch times include contention: the 3D branch runs on a second stream concurrently with the 2D "
                           "branch; `--workload 3d` gives the isolated figure")
         roof = sp
         k2 = timer2d.summary() if joint else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tpath = os.path.join(ROOT, "profiles", "r2_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if joint and os.path.exists(tpath):                                  # of this same command (profiles/traffic.py)
             traffic = json.load(open(tpath)).get("k_conv2d_igemm_mfma", {}).get("hbm_bytes_per_launch")
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r1_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
+                    "traffic_source": "profiles/r2_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
                     "kernel": "k_conv2d_igemm_mfma (f32-operand MFMA, exact fp32; conv fwd + bwd-data + convT + the Winograd layers' batched GEMMs)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
-                    "algorithmic_flops_per_launch": round(2 * k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6 / 2)}
+                    "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
+                    "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
+                    "stream_configuration": "as timed for `value`: 2D main stream + weight-gradient stream + 3D side stream"}
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
               "third 3D pass on the VGI-style batch (each target scan + a 500-pt cluster), backward, Adam") if mopa else (

@@ -13,8 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPA_HIP_LIB") or os.path.join(_HERE, "libmopa_hip.so")  # env override: A/B tuning builds only
 
-_P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
-_T = {"p": _P, "i": _I, "l": _L, "z": _Z, "f": _F}
+_P, _I, _L, _Z, _F, _D = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_double
+_T = {"p": _P, "i": _I, "l": _L, "z": _Z, "f": _F, "d": _D}
 
 # name -> (restype, argtypes) ; 'p' pointer, 'i' int32, 'l' int64, 'z' size_t, 'f' float
 SIGNATURES = {
@@ -44,6 +44,19 @@ SIGNATURES = {
     "mopa_spconv_pack_weight": ("i", "piiiiipp"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
+    # ---- VGI (vgi.hip)
+    "mopa_vgi_zslots": ("i", ""),
+    "mopa_vgi_first_points": ("i", "piifiiiiipppp"),
+    "mopa_vgi_box_free_workspace_bytes": ("z", "iii"),
+    "mopa_vgi_box_free": ("i", "piiiiiiiippzp"),
+    "mopa_vgi_ground_cells": ("i", "ppiipp"),
+    "mopa_vgi_candidates": ("i", "piiippiiiippp"),
+    "mopa_vgi_compact_cells": ("i", "piiiippp"),
+    "mopa_vgi_road_height": ("i", "piifppiiiiiiipp"),
+    "mopa_vgi_range_keep_workspace_bytes": ("z", "iii"),
+    "mopa_vgi_range_keep": ("i", "piiddiippzp"),
+    "mopa_voxelize_f64_workspace_bytes": ("z", ""),
+    "mopa_voxelize_f64": ("i", "pippdipilpppzp"),
     # ---- pseudo-label update (pseudo.hip)
     "mopa_pseudo_fuse": ("i", "ppiippp"),
     "mopa_refine_pseudo_labels_workspace_bytes": ("z", "i"),

@@ -297,6 +297,95 @@ def gen_g6():
     print("G6", len(doc["UNetSCN"]["state_dict"]), "tensors;", len(doc["layer_sequence"]), "ops; ED == UNet:", a == b)
 
 
+# ----------------------------------------------------------------------------- G8
+def vgi_case(k: int):
+    """Synthetic VGI inputs of case k (shared by the generator and the tests; nothing reference-derived): a nuScenes-shape
+    scan, a ground mask, two object clusters, a pinhole projection, the front axis."""
+    from mopa_amd import synth
+    front = "y" if k % 2 == 0 else "x"
+    pts = synth.lidar_points(300 + k)
+    if front == "y":   # nuScenes lidar frame: y forward; the generator's sweep is symmetric, so swap axes for variety
+        pts = pts[:, [1, 0, 2]].copy()
+    rng = np.random.Generator(np.random.PCG64(800 + k))
+    ori_pc = np.concatenate([pts, rng.random((len(pts), 1), dtype=np.float32)], 1)   # (N, 4): xyz + intensity
+    g_mask = pts[:, 2] < -1.7
+    objs, labs = [], []
+    for j, (size, c) in enumerate((((4.2, 1.8, 1.5), (6.0, 9.0, -1.0)), ((0.8, 0.8, 1.7), (-3.0, 5.0, -0.9)))):
+        n = 400 + 150 * j
+        o = (rng.random((n, 3)) - 0.5) * np.array(size) + np.array(c)
+        if front == "x":
+            o = o[:, [1, 0, 2]]
+        objs.append(np.concatenate([o, rng.random((n, 1))], 1).astype(np.float32))
+        labs.append(np.full(n, 1 + j, np.int64))
+    fx, fy, cx, cy = 1266.0, 1266.0, 800.0, 450.0
+    if front == "y":
+        proj = np.array([[fx, cx, 0, 0], [0, cy, -fy, 0], [0, 1, 0, 0]], np.float64)
+    else:
+        proj = np.array([[cx, -fx, 0, 0], [cy, 0, -fy, 0], [1, 0, 0, 0]], np.float64)
+    label = rng.integers(0, 5, len(pts)).astype(np.int64)
+    return dict(ori_pc=ori_pc, label=label, g_mask=g_mask, objs=objs, obj_labels=labs, proj=proj, image_size=(1600, 900), front=front)
+
+
+def gen_g8():
+    """VGI pins: the reference's check_overlap / point_mixmatch(ground) / range_projection / post_process on synthetic
+    inputs.  Environment shims (none of them changes the reference's arithmetic): torchsparse.sparse_quantize restated from
+    v1.4.0 (oracle/vgi.py), ``Tensor.cuda()`` -> identity (no GPU in the build container; the reference runs conv3d / where
+    there), ``np.bool8`` (removed in numpy 2) -> ``np.bool_``, the visualisation module stubbed."""
+    from oracle import vgi as ovgi
+    ts = types.ModuleType("torchsparse")
+    ts.SparseTensor = object
+    tsu, tsq, tsc = types.ModuleType("torchsparse.utils"), types.ModuleType("torchsparse.utils.quantize"), types.ModuleType("torchsparse.utils.collate")
+    tsq.sparse_quantize = ovgi.sparse_quantize
+    tsc.sparse_collate = lambda *a, **k: None
+    vis = types.ModuleType("mopa.data.utils.visualize")
+    vis.debug_visualizer = vis.draw_range_image_labels = lambda *a, **k: None
+    sys.modules.update({"torchsparse": ts, "torchsparse.utils": tsu, "torchsparse.utils.quantize": tsq,
+                        "torchsparse.utils.collate": tsc, "pypatchworkpp": types.ModuleType("pypatchworkpp"),
+                        "mopa.data.utils.visualize": vis})
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from mopa.data import mixmatch_ss as ref  # reference
+    from mopa.data.utils.augmentation_3d import range_projection  # reference
+
+    save = {}
+    for k in range(2):
+        c = vgi_case(k)
+        # (a) candidate centres of the larger object
+        vc = ref.check_overlap(c["ori_pc"], c["objs"][0][:, :3], voxel_size=0.5, search_range=[25.0, 25.0], z_min=-2.0,
+                               z_max=None, front_axis=c["front"])
+        g = ovgi.overlap_grid(c["ori_pc"], c["objs"][0][:, :3], 0.5, (25.0, 25.0), -2.0, None, c["front"])
+        assert vc is not None and np.array_equal(vc, ovgi.check_overlap(c["ori_pc"], c["objs"][0][:, :3], 0.5, (25.0, 25.0), -2.0, None, c["front"]))
+        save[f"free_bits{k}"], save[f"free_shape{k}"] = np.packbits(g["free"].reshape(-1)), np.array(g["free"].shape)
+        save[f"n_centers{k}"], save[f"centers_head{k}"], save[f"centers_sum{k}"] = np.array(len(vc)), vc[:64], vc.sum(0)
+        # (b) the whole ground-mode insertion (overlap test -> filters -> ground cells -> placement matrices)
+        np.random.seed(100 + k)
+        cat_pc, cat_label, obj_mask, obj_ps_mask = ref.point_mixmatch(
+            c["ori_pc"], c["label"], [o.copy() for o in c["objs"]], c["obj_labels"], insert_mode="ground", search_voxel_size=0.5,
+            search_range=[25.0, 25.0], search_z_min=-2.0, proj_matrix=c["proj"], image_size=c["image_size"],
+            g_indices=c["g_mask"], front_axis=c["front"])
+        assert obj_mask.any(), "fixture case must insert"
+        n0 = len(c["ori_pc"])
+        save[f"obj_xyz{k}"] = cat_pc[n0:]                  # the transformed object points (float64)
+        save[f"cat_label_tail{k}"] = cat_label[n0:]
+        # (c) range-image occlusion culling on the concatenated cloud
+        pres = range_projection(np.concatenate((cat_pc[:, :3], np.ones((cat_pc.shape[0], 1))), axis=1), 0.05235, -0.43633, 1024, 64,
+                                crop=False, obj_mask=obj_mask)["pres_idx"]
+        save[f"pres_bits{k}"], save[f"n_cat{k}"] = np.packbits(pres), np.array(len(pres))
+        # (d) post_process: culling + augment_and_scale_3d + int cast + field filter + collate
+        np.random.seed(200 + k)
+        aug = {"noisy_rot": 0.1, "flip_y": 0.5, "rot_z": 6.2831, "transl": True}
+        cat_input, cat_ps, om, _ = ref.post_process([cat_pc], [cat_label], [obj_mask], 20, 4096, aug, scan_pth_ls=["g8"], use_proj=True, backbone="SCN")
+        locs = cat_input["x"][0].numpy()
+        key = (locs[:, 0] << 24) | (locs[:, 1] << 12) | locs[:, 2]
+        save[f"locs_n{k}"], save[f"locs_head{k}"] = np.array(len(locs)), locs[:128]
+        save[f"locs_keysum{k}"], save[f"locs_keyxor{k}"] = np.array(int(key.sum())), np.array(int(np.bitwise_xor.reduce(key)))
+        save[f"ps_sum{k}"], save[f"om_sum{k}"] = np.array(int(cat_ps.sum())), np.array(int(om.sum()))
+        print("G8 case", k, c["front"], "centres", len(vc), "inserted", int(obj_mask.sum()), "kept", int(pres.sum()), "of", len(pres),
+              "locs", len(locs))
+    np.savez_compressed(os.path.join(OUT, "g8_vgi.npz"), **save)
+
+
 # ----------------------------------------------------------------------------- G7
 def gen_g7():
     """Integer pins of the synthetic scan (our own generator; not reference-derived)."""
@@ -324,4 +413,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
     else:
-        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7()
+        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7(), gen_g8()
