@@ -27,6 +27,7 @@ SIGNATURES = {
     "mopa_rulebook_updown": ("i", "ppiippp"),
     "mopa_points_csr_workspace_bytes": ("z", "l"),
     "mopa_points_csr": ("i", "piipppzp"),
+    "mopa_rotate_points_f32": ("i", "pippp"),
     "mopa_voxelize_workspace_bytes": ("z", ""),
     "mopa_voxelize": ("i", "pifipilpppzp"),
     "mopa_scan_workspace_bytes": ("z", "l"),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "mopa_bnrelu_rows_fwd": ("i", "pipiiippppfffippzp"),
     "mopa_bnrelu_rows_bwd_workspace_bytes": ("z", "ii"),
     "mopa_bnrelu_rows_bwd": ("i", "pipipiiipfippiipzp"),
+    "mopa_rows_add": ("i", "pipipiiip"),
     "mopa_input_layer_fwd": ("i", "pippipip"),
     "mopa_input_layer_bwd": ("i", "pippiipp"),
     "mopa_output_layer_heads_fwd": ("i", "pipiiipppppppp"),

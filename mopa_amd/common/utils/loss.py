@@ -13,6 +13,10 @@ import torch
 
 from ..._lib import call, ptr, query, stream, workspace
 
+import os as _os
+
+VALIDATE_LABELS = _os.environ.get("MOPA_VALIDATE_LABELS", "0") == "1"   # host-syncing range checks (see seg_ce)
+
 
 def _ws(n, dev):
     return workspace.get(max(int(n), 256), dev)
@@ -62,6 +66,9 @@ class _WeightedCE(torch.autograd.Function):
              ws.numel(), stream())
         ctx.save_for_backward(z, y, out)
         ctx.w, ctx.ignore_index, ctx.status = w, ignore_index, status
+        if VALIDATE_LABELS and int(status.item()) != 0:   # a host sync: debugging / validation runs only
+            raise IndexError(f"seg_ce: a label is outside [0, {C}) and is not ignore_index {ignore_index} "
+                             "(F.cross_entropy raises 'Target out of bounds' here)")
         return out[0]
 
     @staticmethod
@@ -78,6 +85,12 @@ def seg_ce(logits, labels, weight=None, ignore_index: int = -100) -> torch.Tenso
 
     Rows with label == ignore_index are skipped in-kernel, so the boolean-mask compaction the reference does
     for pseudo labels (:452-465, a device sync) is unnecessary: pass the full tensors.
+
+    Deviation from ``F.cross_entropy``: a label outside ``[0, C)`` that is not ``ignore_index`` (e.g. 255, or a class-count
+    mismatch) is dropped from numerator and normaliser instead of raising -- raising needs a device sync per call.  The kernel
+    records the condition; set ``mopa_amd.common.utils.loss.VALIDATE_LABELS = True`` (or ``MOPA_VALIDATE_LABELS=1``) to check
+    it after every call, e.g. for the first iterations of a new dataset.  The same switch validates SAM mask ids (> 255) in
+    ``mask_cons_loss``.
     """
     if logits.shape[0] == 0:
         return logits.sum() * float("nan")
@@ -144,6 +157,8 @@ def mask_cons_loss(all_logits: torch.Tensor, sam_mask_ls: List[torch.Tensor], mi
         return 0
     dev = all_logits.device
     masks = torch.stack([torch.as_tensor(m).to(device=dev, dtype=torch.int32) for m in sam_mask_ls]).contiguous()
+    if VALIDATE_LABELS and int(masks.max().item()) > 255:
+        raise IndexError("mask_cons_loss: mask id > 255 (ids come from uint8 SAM files; larger ids would be treated as ignore)")
     if masks.shape[0] != all_logits.shape[0] or masks.numel() * all_logits.shape[-1] != all_logits.numel():
         raise RuntimeError(f"mask_cons_loss: probs {tuple(all_logits.shape)} vs masks {tuple(masks.shape)}")
     return _MaskCons.apply(all_logits, masks, bool(min_entropy))

@@ -485,6 +485,27 @@ __global__ void k_vox_coords(const float* __restrict__ pts, int n, float scale, 
   }
 }
 
+// The rotation / flip stage of augment_and_scale_3d (mopa/data/utils/augmentation_3d.py:26-50): out = points @ R for a
+// 3x3 float32 matrix drawn by the caller (numpy's global RNG, like the reference).  float32 like numpy's float32 dot
+// (sgemm: acc = fma(a_k, b_k, acc) over k); a last-ulp difference against a particular BLAS is possible, the voxel
+// coordinates downstream are pinned by fixture G4.
+__global__ void k_rotate_f32(const float* __restrict__ pts, int n, float r00, float r01, float r02, float r10, float r11, float r12,
+                             float r20, float r21, float r22, float* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float x = pts[3 * (int64_t)i], y = pts[3 * (int64_t)i + 1], z = pts[3 * (int64_t)i + 2];
+    out[3 * (int64_t)i] = fmaf(z, r20, fmaf(y, r10, __fmul_rn(x, r00)));
+    out[3 * (int64_t)i + 1] = fmaf(z, r21, fmaf(y, r11, __fmul_rn(x, r01)));
+    out[3 * (int64_t)i + 2] = fmaf(z, r22, fmaf(y, r12, __fmul_rn(x, r02)));
+  }
+}
+MOPA_API int mopa_rotate_points_f32(const float* points, int32_t n, const float* rot_host /*[9] row-major*/, float* out, void* stream) {
+  if (n <= 0 || !rot_host) return MOPA_ERR_ARG;
+  const float* r = rot_host;
+  k_rotate_f32<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(points, n, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
 MOPA_API size_t mopa_voxelize_workspace_bytes(void) { return 256; }
 
 // points [n][3] fp32 (already rotated / scaled by the augmentation), u_host: the 3 uniform draws of the translation.

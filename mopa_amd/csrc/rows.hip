@@ -355,6 +355,25 @@ __global__ void k_input_layer_fwd(const float* __restrict__ feats, int cin, cons
   }
 }
 
+// out[r][c] = a[r][c] + b[r][c] over [rows][C] slices of wider buffers (scn.AddTable of the ResNet-style UNet blocks,
+// SURVEY A.7 / oracle/scn3d.py::unet_forward(residual_blocks=True)); C % 4 == 0, 16-byte aligned rows.
+__global__ void k_rows_add(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ out, int ldo,
+                           int rows, int C4) {
+  const int64_t total = (int64_t)rows * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C4), c = (int)(i - (int64_t)r * C4) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(a + (int64_t)r * lda + c), y = *reinterpret_cast<const float4*>(b + (int64_t)r * ldb + c);
+    *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+MOPA_API int mopa_rows_add(const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo, int32_t rows, int32_t C,
+                           void* stream) {
+  if (rows <= 0 || C <= 0 || C % 4 || lda % 4 || ldb % 4 || ldo % 4 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return MOPA_ERR_ARG;
+  k_rows_add<<<stream_grid((int64_t)rows * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(a, lda, b, ldb, out, ldo, rows, C / 4);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
 MOPA_API int mopa_input_layer_fwd(const float* feats, int32_t cin, const int32_t* row_start, const int32_t* row_points,
                                   int32_t num_rows, float* out, int32_t ld_out, void* stream) {
   if (cin <= 0 || num_rows <= 0 || ld_out < cin) return MOPA_ERR_ARG;

@@ -60,6 +60,14 @@ class _SparseConvParams(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
+class _NiNParams(nn.Module):
+    """scn.NetworkInNetwork(nIn, nOut, bias=False): weight (nIn, nOut), init normal(0, sqrt(2 / nIn))."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n_in, n_out) * math.sqrt(2.0 / n_in))
+
+
 class _BNParams(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -73,24 +81,36 @@ class UNetSCN(nn.Module):
     def __init__(self, in_channels, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7,
                  pretrained=False):
         super().__init__()
-        if residual_blocks:
-            raise NotImplementedError("residual_blocks=True is not on the shipped hot path (config/xmuda.py:220)")
         if m not in (16, 32, 64):
             raise NotImplementedError("m must be 16, 32 or 64 (MFMA tile width; the output-head kernels split a row over "
                                       "m/4 lanes, a power of two <= 16); the reference ships m=16")
         self.in_channels, self.out_channels = in_channels, m
         self.m, self.block_reps, self.full_scale, self.num_planes = m, block_reps, full_scale, num_planes
+        self.residual_blocks = bool(residual_blocks)
         planes = [(i + 1) * m for i in range(num_planes)]
         sm = self.sparseModel = _Slot()
         sm.put(1, _SparseConvParams(27, in_channels, m))
 
+        def block(node, idx, a, b):
+            """scn.UNet's block(m, a, b): VGG = Sequential(BN, SubM); ResNet = ConcatTable(Identity | NiN,
+            Sequential(BN, SubM, BN, SubM)) + AddTable -- returns the next free index."""
+            if not residual_blocks:
+                blk = node.put(idx, _Slot())
+                blk.put(0, _BNParams(a))
+                blk.put(1, _SparseConvParams(27, a, b))
+                return idx + 1
+            ct = node.put(idx, _Slot())
+            if a != b:
+                ct.put(0, _NiNParams(a, b))
+            seq = ct.put(1, _Slot())
+            seq.put(0, _BNParams(a)); seq.put(1, _SparseConvParams(27, a, b))
+            seq.put(2, _BNParams(b)); seq.put(3, _SparseConvParams(27, b, b))
+            return idx + 2   # ConcatTable, AddTable
+
         def U(node, pl):
             idx = 0
             for _ in range(block_reps):
-                blk = node.put(idx, _Slot())
-                blk.put(0, _BNParams(pl[0]))
-                blk.put(1, _SparseConvParams(27, pl[0], pl[0]))
-                idx += 1
+                idx = block(node, idx, pl[0], pl[0])
             if len(pl) > 1:
                 seq = node.put(idx, _Slot()).put(1, _Slot())
                 seq.put(0, _BNParams(pl[0]))
@@ -100,11 +120,7 @@ class UNetSCN(nn.Module):
                 seq.put(4, _SparseConvParams(8, pl[1], pl[0]))
                 idx += 2
                 for i in range(block_reps):
-                    a = pl[0] * (2 if i == 0 else 1)
-                    blk = node.put(idx, _Slot())
-                    blk.put(0, _BNParams(a))
-                    blk.put(1, _SparseConvParams(27, a, pl[0]))
-                    idx += 1
+                    idx = block(node, idx, pl[0] * (2 if i == 0 else 1), pl[0])
 
         U(sm.put(2, _Slot()), planes)
         sm.put(3, _BNParams(m))

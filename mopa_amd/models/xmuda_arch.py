@@ -138,16 +138,17 @@ class Net3DSeg(nn.Module):
         if dual_head:
             self.linear2 = nn.Linear(m, num_classes)
         self.da_method = da_method
-        if da_method == "MCD":
-            raise NotImplementedError("da_method='MCD' (linear3) is not on the shipped hot path")
+        if da_method == "MCD":   # a third head that the reference creates but never uses in forward (xmuda_arch.py:110-126)
+            self.linear3 = nn.Linear(m, num_classes)
         self._order = None
 
     def _spec(self):
         if self._order is None:
-            self._order = [k for k, _ in self.named_parameters()] + [k for k, _ in self.named_buffers()]
+            self._order = [k for k, _ in self.named_parameters() if not k.startswith("linear3.")] + [k for k, _ in self.named_buffers()]
         n = self.net_3d
         return _Spec(order=self._order, prefix="net_3d.sparseModel.", in_channels=n.in_channels, m=n.m,
-                     num_planes=n.num_planes, block_reps=n.block_reps, num_classes=self.num_classes,
+                     num_planes=n.num_planes, block_reps=n.block_reps, residual_blocks=n.residual_blocks,
+                     num_classes=self.num_classes,
                      dual_head=bool(self.dual_head))
 
     def forward(self, data_batch):

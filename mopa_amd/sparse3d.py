@@ -276,26 +276,114 @@ def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta
 
 
 # --------------------------------------------------------------------------------------- the network
-def unet_param_names(num_planes=7, block_reps=1, prefix="sparseModel."):
-    """Parameter/buffer names in scn.Sequential index naming, traversal order."""
-    convs, bns = [prefix + "1"], []
+class Val:
+    """A symbolic activation of the layer program: columns [col, col + C) of buffer `buf` at UNet level `level`."""
 
-    def U(pre, depth):
-        idx = 0
-        for _ in range(block_reps):
-            bns.append(f"{pre}{idx}.0"); convs.append(f"{pre}{idx}.1"); idx += 1
-        if depth < num_planes - 1:
-            p = f"{pre}{idx}.1."
-            bns.append(p + "0"); convs.append(p + "1")
-            U(p + "2.", depth + 1)
-            bns.append(p + "3"); convs.append(p + "4")
-            idx += 2
-            for _ in range(block_reps):
-                bns.append(f"{pre}{idx}.0"); convs.append(f"{pre}{idx}.1"); idx += 1
+    __slots__ = ("buf", "col", "C", "level")
 
-    U(prefix + "2.", 0)
-    bns.append(prefix + "3")
-    return convs, bns
+    def __init__(self, buf, col, C, level):
+        self.buf, self.col, self.C, self.level = buf, col, C, level
+
+    @property
+    def key(self):
+        return (self.buf, self.col, self.C)
+
+
+class Program:
+    """The layer sequence of ``UNetSCN`` as data: ``scn.Sequential(InputLayer, SubMConv, scn.UNet, BatchNormReLU, OutputLayer)``
+    of ``mopa/models/scn_unet.py:25-30`` with ``scn.UNet`` unrolled (VGG blocks, or ResNet blocks for ``residual_blocks=True``)
+    exactly as the reference's own ``UNetSCN_ED`` unrolls it (``scn_unet.py:38-219``).  Pinned against fixture G6
+    (tests/test_scn_structure.py: names, channel counts, order, JoinTable operand order).
+
+    ops: ("bn", name, src, dst) | ("conv", name, kind, level, src, dst) with kind subm / down / up / nin |
+         ("add", a, b, dst).  JoinTable([skip, up]) costs nothing: both producers write halves of one buffer.
+    Order inside a ResNet block: the shortcut's NetworkInNetwork is recorded AFTER the residual branch, so that in the
+    reversed (backward) order it is the first writer of the block input's gradient and BatchNorm's backward accumulates."""
+
+    def __init__(self, in_channels, m, num_planes, block_reps, residual_blocks, prefix):
+        self.ops, self.bufs = [], []   # bufs: (level, width)
+        planes = [(i + 1) * m for i in range(num_planes)]
+
+        def val(level, C, buf=None, col=0):
+            if buf is None:
+                self.bufs.append((level, C))
+                buf = len(self.bufs) - 1
+            return Val(buf, col, C, level)
+
+        def block(pre, idx, x, a, b, l, dst=None):
+            if not residual_blocks:   # VGG style: Sequential(BNReLU(a), SubMConv(a -> b))
+                y = val(l, a)
+                self.ops.append(("bn", f"{pre}{idx}.0", x, y))
+                out = dst or val(l, b)
+                self.ops.append(("conv", f"{pre}{idx}.1", "subm", l, y, out))
+                return out, idx + 1
+            p = f"{pre}{idx}."       # ConcatTable(Identity | NiN(a -> b), Seq(BN, SubM(a -> b), BN, SubM(b -> b))), AddTable
+            y1 = val(l, a); self.ops.append(("bn", p + "1.0", x, y1))
+            c1 = val(l, b); self.ops.append(("conv", p + "1.1", "subm", l, y1, c1))
+            y2 = val(l, b); self.ops.append(("bn", p + "1.2", c1, y2))
+            c2 = val(l, b); self.ops.append(("conv", p + "1.3", "subm", l, y2, c2))
+            sc = x
+            if a != b:
+                sc = val(l, b)
+                self.ops.append(("conv", p + "0", "nin", l, x, sc))
+            out = dst or val(l, b)
+            self.ops.append(("add", sc, c2, out))
+            return out, idx + 2
+
+        def U(pre, l, x):
+            P = planes[l]
+            idx = 0
+            has_down = l < num_planes - 1
+            join = None
+            if has_down:
+                self.bufs.append((l, 2 * P))
+                join = len(self.bufs) - 1
+            for rep in range(block_reps):
+                dst = Val(join, 0, P, l) if (has_down and rep == block_reps - 1) else None
+                x, idx = block(pre, idx, x, P, P, l, dst)
+            if has_down:
+                p = f"{pre}{idx}.1."
+                y = val(l, P); self.ops.append(("bn", p + "0", x, y))
+                d = val(l + 1, planes[l + 1]); self.ops.append(("conv", p + "1", "down", l, y, d))
+                d = U(p + "2.", l + 1, d)
+                y = val(l + 1, planes[l + 1]); self.ops.append(("bn", p + "3", d, y))
+                self.ops.append(("conv", p + "4", "up", l, y, Val(join, P, P, l)))
+                x = Val(join, 0, 2 * P, l)     # JoinTable([skip, up])
+                idx += 2
+                for rep in range(block_reps):
+                    x, idx = block(pre, idx, x, 2 * P if rep == 0 else P, P, l)
+            return x
+
+        self.x0 = val(0, in_channels)
+        stem = val(0, m)
+        self.ops.append(("conv", prefix + "1", "subm", 0, self.x0, stem))
+        x = U(prefix + "2.", 0, stem)
+        self.out = val(0, m)
+        self.ops.append(("bn", prefix + "3", x, self.out))
+
+    def layer_sequence(self):
+        """The arithmetic layers in execution order, in the vocabulary of tests/golden/g6_scn_structure.json."""
+        seq = [["InputLayer", self.x0.C, self.x0.C, None, 0]]
+        kinds = {"subm": "SubmanifoldConvolution", "down": "Convolution", "up": "Deconvolution", "nin": "NetworkInNetwork"}
+        for op in self.ops:
+            if op[0] == "bn":
+                seq.append(["BatchNormReLU", op[2].C, op[3].C, op[2].level, op[3].level])
+            elif op[0] == "conv":
+                seq.append([kinds[op[2]], op[4].C, op[5].C, op[4].level, op[5].level])
+            else:
+                seq.append(["AddTable", op[3].C, op[3].level])
+        seq.append(["OutputLayer", self.out.C, self.out.C, 0, 0])
+        return seq
+
+
+_programs = {}
+
+
+def program_for(spec) -> Program:
+    key = (spec.in_channels, spec.m, spec.num_planes, spec.block_reps, bool(getattr(spec, "residual_blocks", False)), spec.prefix)
+    if key not in _programs:
+        _programs[key] = Program(*key)
+    return _programs[key]
 
 
 class SCNNetFunction(torch.autograd.Function):
@@ -310,57 +398,46 @@ class SCNNetFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # an output that no loss uses arrives as None in backward, not as a zero tensor
         dev = geom.device
         P = dict(zip(spec.order, flat))
-        A, m, L, reps = geom.num_active, spec.m, spec.num_planes, spec.block_reps
-        planes = [(i + 1) * m for i in range(L)]
-        tape = []
-        pre = spec.prefix
+        A, m = geom.num_active, spec.m
+        prog = program_for(spec)
+        bufs = [None] * len(prog.bufs)
 
-        def bn(name, x: View, y: View | None = None):
-            y = y or new_view(x.rows, x.C, dev)
-            stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
-            bnrelu_fwd(x, y, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
-                       P[name + ".running_var"], training, stats)
-            tape.append(("bn", name, x, y, stats))
-            return y
+        def view(v: Val) -> View:
+            if bufs[v.buf] is None:
+                level, width = prog.bufs[v.buf]
+                bufs[v.buf] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
+            return View(bufs[v.buf], v.col, v.C)
 
-        def conv(name, table, x: View, out: View, kind):
-            spconv_fwd(table, x, P[name + ".weight"], out, rb=geom.rulebook(table))
-            tape.append(("conv", name, table, x, out, kind))
-            return out
-
-        def U(pfx, l, x: View) -> View:
-            idx = 0
-            has_down = l < L - 1
-            join = torch.empty(A[l], 2 * planes[l], dtype=torch.float32, device=dev) if has_down else None
-            for rep in range(reps):
-                last = rep == reps - 1
-                out = View(join, 0, planes[l]) if (has_down and last) else new_view(A[l], planes[l], dev)
-                x = conv(f"{pfx}{idx}.1", geom.nbr27[l], bn(f"{pfx}{idx}.0", x), out, ("subm", l))
-                idx += 1
-            if has_down:
-                p = f"{pfx}{idx}.1."
-                d = conv(p + "1", geom.ch[l], bn(p + "0", x), new_view(A[l + 1], planes[l + 1], dev), ("down", l))
-                d = U(p + "2.", l + 1, d)
-                conv(p + "4", geom.up[l], bn(p + "3", d), View(join, planes[l], planes[l]), ("up", l))
-                tape.append(("join", l, x, View(join, planes[l], planes[l])))
-                x = View(join, 0, 2 * planes[l])
-                idx += 2
-                for rep in range(reps):
-                    x = conv(f"{pfx}{idx}.1", geom.nbr27[l], bn(f"{pfx}{idx}.0", x), new_view(A[l], planes[l], dev),
-                             ("subm", l))
-                    idx += 1
-            return x
+        def table(kind, l):
+            return {"subm": geom.nbr27[l], "down": geom.ch[l], "up": geom.up[l], "nin": geom.nbr27[l][13:14]}[kind]
 
         feats = feats.contiguous().float()
         cin = spec.in_channels
         if feats.shape[1] != cin or feats.shape[0] < geom.n_points:
             raise RuntimeError(f"feats must be (>= {geom.n_points}, {cin}), got {tuple(feats.shape)}")
-        x0 = new_view(A[0], cin, dev)
+        x0 = view(prog.x0)
         call("mopa_input_layer_fwd", ptr(feats), cin, ptr(geom.row_start), ptr(geom.row_points), A[0], x0.p, x0.ld,
              stream())
-        x = conv(pre + "1", geom.nbr27[0], x0, new_view(A[0], m, dev), ("subm", 0))
-        x = U(pre + "2.", 0, x)
-        y = bn(pre + "3", x)
+        stats = {}
+        for op in prog.ops:
+            if op[0] == "bn":
+                _, name, src, dst = op
+                st = torch.empty(4, src.C, dtype=torch.float32, device=dev)
+                bnrelu_fwd(view(src), view(dst), P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                           P[name + ".running_var"], training, st)
+                stats[name] = st
+            elif op[0] == "conv":
+                _, name, kind, l, src, dst = op
+                w = P[name + ".weight"]
+                t = table(kind, l)
+                if kind == "nin":   # NetworkInNetwork == a one-offset convolution on the identity rule (the centre offset's row)
+                    w = w.view(1, w.shape[0], w.shape[1])
+                spconv_fwd(t, view(src), w, view(dst), rb=geom.rulebook(t))
+            else:
+                _, a, b, dst = op
+                va, vb, vd = view(a), view(b), view(dst)
+                call("mopa_rows_add", va.p, va.ld, vb.p, vb.ld, vd.p, vd.ld, vd.rows, vd.C, stream())
+        y = view(prog.out)
         N, C = geom.n_points, spec.num_classes
         out_feats = torch.empty(N, m, dtype=torch.float32, device=dev)
         l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
@@ -370,31 +447,61 @@ class SCNNetFunction(torch.autograd.Function):
         call("mopa_output_layer_heads_fwd", y.p, y.ld, ptr(geom.point_row), N, m, C, ptr(P["linear.weight"]),
              ptr(P["linear.bias"]), ptr(w2), ptr(b2), ptr(out_feats), ptr(l1), ptr(l2) if spec.dual_head else None,
              stream())
-        U = None   # the recursive closure refers to itself through its own cell: a cycle that pins `tape` until the cyclic GC runs
-        ctx.spec, ctx.geom, ctx.training, ctx.tape = spec, geom, training, tape
+        ctx.spec, ctx.geom, ctx.training = spec, geom, training
+        ctx.prog, ctx.bufs, ctx.stats = prog, bufs, stats
         # a detached alias: the returned tensor itself gets this node as grad_fn, and keeping it on ctx would be a reference
         # cycle (node -> ctx -> output -> node) that only the cyclic GC frees -- ~2 GB of activations per step
-        ctx.P, ctx.y_final, ctx.out_feats = P, y, out_feats.detach()
+        ctx.P, ctx.out_feats = P, out_feats.detach()
         ctx.feats_needs_grad = feats.requires_grad
-        ctx.x0 = x0
         return out_feats, l1, l2
 
     @staticmethod
     def backward(ctx, dfeats, dl1, dl2):
         if dfeats is None and dl1 is None and dl2 is None:   # nothing flows back (e.g. only used as a detached KL target)
             return (None,) * (4 + len(ctx.spec.order))
-        spec, geom, P, tape = ctx.spec, ctx.geom, ctx.P, ctx.tape
+        spec, geom, P, prog, bufs = ctx.spec, ctx.geom, ctx.P, ctx.prog, ctx.bufs
         dev = geom.device
         N, m, C = geom.n_points, spec.m, spec.num_classes
-        A0 = geom.num_active[0]
+        A = geom.num_active
+        A0 = A[0]
         sink = GradSink(P, spec.order)   # gradients go straight into attached .grad buffers (accumulating)
 
         def cont(t):
             return None if t is None else t.contiguous().float()
 
+        # gradient buffers mirror the activation buffers; a value's gradient is the same column slice of its buffer's mirror
+        gbufs = [None] * len(prog.bufs)
+        written = [[] for _ in prog.bufs]    # column intervals of each gradient buffer that already hold a contribution
+        alias = {}                            # value key -> View standing in for its gradient (AddTable fans one gradient out)
+
+        def fwd(v: Val) -> View:
+            return View(bufs[v.buf], v.col, v.C)
+
+        def grad_read(v: Val) -> View:
+            if v.key in alias:
+                return alias[v.key]
+            assert gbufs[v.buf] is not None, "gradient requested before it was produced"
+            return View(gbufs[v.buf], v.col, v.C)
+
+        def grad_write(v: Val):
+            """-> (view, accumulate): accumulate when (part of) the slice already holds a gradient."""
+            if v.key in alias:
+                return alias[v.key], True
+            if gbufs[v.buf] is None:
+                level, width = prog.bufs[v.buf]
+                gbufs[v.buf] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
+            acc = any(c < v.col + v.C and v.col < c + n for c, n in written[v.buf])
+            if acc:
+                assert any(c <= v.col and v.col + v.C <= c + n for c, n in written[v.buf]), "partial overlap of gradient slices"
+            written[v.buf].append((v.col, v.C))
+            return View(gbufs[v.buf], v.col, v.C), acc
+
+        def table(kind, l):
+            return {"subm": geom.nbr27[l], "down": geom.ch[l], "up": geom.up[l], "nin": geom.nbr27[l][13:14]}[kind]
+
         dfeats, dl1 = cont(dfeats), cont(dl1)
         dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
-        dy = new_view(A0, m, dev)
+        dy, _ = grad_write(prog.out)
         wsb = query("mopa_output_layer_heads_bwd_workspace_bytes", N, m, C)
         ws = _ws(wsb, dev)
         hnames = (["linear.weight", "linear.bias"] if dl1 is not None else []) + \
@@ -406,55 +513,43 @@ class SCNNetFunction(torch.autograd.Function):
              ptr(geom.row_points), A0, N, m, C, dy.p, dy.ld, ptr(hg.get("linear.weight")), ptr(hg.get("linear.bias")),
              ptr(hg.get("linear2.weight")), ptr(hg.get("linear2.bias")), int(hacc), ptr(ws), ws.numel(), stream())
 
-        # gradient w.r.t. activation buffers, keyed by (storage ptr, col, C)
-        gmap = {}
-
-        def key(v: View):
-            return (v.t.data_ptr(), v.col, v.C)
-
-        gmap[key(ctx.y_final)] = dy
-        for rec in reversed(tape):
-            kind = rec[0]
-            if kind == "bn":
-                _, name, x, y, stats = rec
-                dyv = gmap.pop(key(y))
-                k = key(x)
-                if k in gmap:  # skip half of a join buffer: accumulate into the existing gradient
-                    dx, acc = gmap[k], True
-                else:
-                    dx, acc = new_view(x.rows, x.C, dev), False
-                    gmap[k] = dx
+        stem_name = spec.prefix + "1"
+        for op in reversed(prog.ops):
+            if op[0] == "bn":
+                _, name, src, dst = op
+                dyv = grad_read(dst)
+                dx, acc = grad_write(src)
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-                bnrelu_bwd(dyv, x, dx, stats, ctx.training, dg, db, acc, pacc)
-            elif kind == "conv":
-                _, name, table, x, out, ckind = rec
-                dout = gmap.pop(key(out))
+                bnrelu_bwd(dyv, fwd(src), dx, ctx.stats[name], ctx.training, dg, db, acc, pacc)
+            elif op[0] == "conv":
+                _, name, kind, l, src, dst = op
+                dout = grad_read(dst)
                 w = P[name + ".weight"]
                 (dw,), wacc = sink.take(name + ".weight")
-                spconv_bwd_weight(table, x, dout, dw, accumulate=wacc)
-                if name == spec.prefix + "1" and not ctx.feats_needs_grad:
+                t = table(kind, l)
+                if kind == "nin":
+                    w, dw = w.view(1, w.shape[0], w.shape[1]), dw.view(1, dw.shape[0], dw.shape[1])
+                spconv_bwd_weight(t, fwd(src), dout, dw, accumulate=wacc)
+                if name == stem_name and not ctx.feats_needs_grad:
                     continue
-                dx = new_view(x.rows, x.C, dev)
-                if ckind[0] == "subm":      # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
-                    spconv_fwd(table, dout, w, dx, w_flip=True, rb=geom.rulebook(table), w_transposed=True)
-                elif ckind[0] == "down":    # rules reversed = the up table of the same level
-                    rt = geom.up[ckind[1]]
+                dx, acc = grad_write(src)
+                assert not acc, "a convolution's backward-data must be the first writer of its input gradient"
+                if kind == "subm":        # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
+                    spconv_fwd(t, dout, w, dx, w_flip=True, rb=geom.rulebook(t), w_transposed=True)
+                elif kind == "nin":
+                    spconv_fwd(t, dout, w, dx, rb=geom.rulebook(t), w_transposed=True)
+                else:                     # rules reversed: conv <-> deconv swap tables
+                    rt = geom.up[l] if kind == "down" else geom.ch[l]
                     spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
-                else:                        # deconv: reversed rules = the children table
-                    rt = geom.ch[ckind[1]]
-                    spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
-                gmap[key(x)] = dx
-            elif kind == "join":
-                # dec-block BN produced d(join) for all 2P columns; expose its halves under the keys of the
-                # two producers (skip conv output / deconv output), which are column views of the same buffer.
-                _, l, skip, upv = rec
-                full = gmap.pop((skip.t.data_ptr(), 0, 2 * skip.C))
-                gmap[key(skip)] = View(full.t, 0, skip.C)
-                gmap[key(upv)] = View(full.t, skip.C, skip.C)
+            else:                         # AddTable: both operands receive the output's gradient
+                _, a, b, dst = op
+                g = grad_read(dst)
+                alias[a.key] = g
+                alias[b.key] = g
         dfeat_in = None
         if ctx.feats_needs_grad:
             cin = spec.in_channels
-            dx0 = gmap[key(ctx.x0)]
+            dx0 = grad_read(prog.x0)
             dfeat_in = torch.zeros(N, cin, dtype=torch.float32, device=dev)
             call("mopa_input_layer_bwd", dx0.p, dx0.ld, ptr(geom.point_row), ptr(geom.row_start), N, cin,
                  ptr(dfeat_in), stream())

@@ -195,8 +195,8 @@ def fold_state_dict(sd: dict) -> dict:
                                                                  and "sparseModel" in k) else v) for k, v in sd.items()}
 
 
-def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="sparseModel."):
-    """Ordered {name: shape} for UNetSCN (scn_unet.py:25-30 + scn.UNet A.7)."""
+def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="sparseModel.", residual_blocks=False):
+    """Ordered {name: shape} for UNetSCN (scn_unet.py:25-30 + scn.UNet A.7; VGG or ResNet style blocks)."""
     planes = [(i + 1) * m for i in range(num_planes)]
     out = {}
 
@@ -206,12 +206,23 @@ def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="s
         out[name + ".running_mean"] = (c,)
         out[name + ".running_var"] = (c,)
 
+    def block(pre, idx, a, b):
+        if not residual_blocks:
+            bn(f"{pre}{idx}.0", a)
+            out[f"{pre}{idx}.1.weight"] = (27, a, b)
+            return idx + 1
+        if a != b:
+            out[f"{pre}{idx}.0.weight"] = (a, b)   # NetworkInNetwork shortcut
+        bn(f"{pre}{idx}.1.0", a)
+        out[f"{pre}{idx}.1.1.weight"] = (27, a, b)
+        bn(f"{pre}{idx}.1.2", b)
+        out[f"{pre}{idx}.1.3.weight"] = (27, b, b)
+        return idx + 2   # ConcatTable, AddTable
+
     def U(pre, pl):
         idx = 0
         for _ in range(block_reps):
-            bn(f"{pre}{idx}.0", pl[0])
-            out[f"{pre}{idx}.1.weight"] = (27, pl[0], pl[0])
-            idx += 1
+            idx = block(pre, idx, pl[0], pl[0])
         if len(pl) > 1:
             p = f"{pre}{idx}.1."
             bn(p + "0", pl[0])
@@ -221,10 +232,7 @@ def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="s
             out[p + "4.weight"] = (8, pl[1], pl[0])
             idx += 2  # ConcatTable, JoinTable
             for i in range(block_reps):
-                a = pl[0] * (2 if i == 0 else 1)
-                bn(f"{pre}{idx}.0", a)
-                out[f"{pre}{idx}.1.weight"] = (27, a, pl[0])
-                idx += 1
+                idx = block(pre, idx, pl[0] * (2 if i == 0 else 1), pl[0])
 
     out[prefix + "1.weight"] = (27, in_channels, m)
     U(prefix + "2.", planes)
@@ -234,7 +242,7 @@ def unet_param_shapes(in_channels=1, m=16, num_planes=7, block_reps=1, prefix="s
 
 def unet_forward(params: dict, geom: Geometry, feats: torch.Tensor, *, m=16, num_planes=7,
                  block_reps=1, training=True, prefix="sparseModel.", taps: dict | None = None,
-                 trace: list | None = None):
+                 trace: list | None = None, residual_blocks=False):
     """UNetSCN.forward (scn_unet.py:32-34): returns per-point features (N, m).
 
     `trace` (optional list) receives the executed layer sequence as tuples in the vocabulary of
@@ -251,13 +259,30 @@ def unet_forward(params: dict, geom: Geometry, feats: torch.Tensor, *, m=16, num
         return bn_relu(x, P(name + ".weight"), P(name + ".bias"), P(name + ".running_mean"),
                        P(name + ".running_var"), training)
 
-    def U(pre, l, x):
-        idx = 0
-        for _ in range(block_reps):
+    def block(pre, idx, x, l):
+        """scn.UNet block (A.7): VGG = BN -> SubM; ResNet = (Identity | NiN)(x) + SubM(BN(SubM(BN(x))))."""
+        if not residual_blocks:
             w = P(f"{pre}{idx}.1.weight")
             x = sparse_conv(bn(f"{pre}{idx}.0", x, l), geom.nbr27[l], w)
             rec("SubmanifoldConvolution", w.shape[1], w.shape[2], l, l)
-            idx += 1
+            return x, idx + 1
+        w1, w2 = P(f"{pre}{idx}.1.1.weight"), P(f"{pre}{idx}.1.3.weight")
+        sc = x
+        if w1.shape[1] != w1.shape[2]:
+            wn = P(f"{pre}{idx}.0.weight")
+            rec("NetworkInNetwork", wn.shape[0], wn.shape[1], l, l)
+            sc = x @ wn
+        y = sparse_conv(bn(f"{pre}{idx}.1.0", x, l), geom.nbr27[l], w1)
+        rec("SubmanifoldConvolution", w1.shape[1], w1.shape[2], l, l)
+        y = sparse_conv(bn(f"{pre}{idx}.1.2", y, l), geom.nbr27[l], w2)
+        rec("SubmanifoldConvolution", w2.shape[1], w2.shape[2], l, l)
+        rec("AddTable", w2.shape[2], l)
+        return sc + y, idx + 2
+
+    def U(pre, l, x):
+        idx = 0
+        for _ in range(block_reps):
+            x, idx = block(pre, idx, x, l)
         if l < num_planes - 1:
             p = f"{pre}{idx}.1."
             y = sparse_conv(bn(p + "0", x, l), geom.ch[l], P(p + "1.weight"))
@@ -266,14 +291,11 @@ def unet_forward(params: dict, geom: Geometry, feats: torch.Tensor, *, m=16, num
             y = bn(p + "3", y, l + 1)
             rec("Deconvolution", y.shape[1], P(p + "4.weight").shape[2], l + 1, l)
             y = sparse_conv(y, geom.up[l], P(p + "4.weight"))
-            rec("JoinTable", [x.shape[1], y.shape[1]], ["SubmanifoldConvolution", "Deconvolution"], l)
+            rec("JoinTable", [x.shape[1], y.shape[1]], ["AddTable" if residual_blocks else "SubmanifoldConvolution", "Deconvolution"], l)
             x = torch.cat([x, y], 1)  # JoinTable([skip, up])
             idx += 2
             for _ in range(block_reps):
-                w = P(f"{pre}{idx}.1.weight")
-                x = sparse_conv(bn(f"{pre}{idx}.0", x, l), geom.nbr27[l], w)
-                rec("SubmanifoldConvolution", w.shape[1], w.shape[2], l, l)
-                idx += 1
+                x, idx = block(pre, idx, x, l)
         if taps is not None:
             taps[f"level{l}"] = x
         return x

