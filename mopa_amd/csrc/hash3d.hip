@@ -20,6 +20,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t k) {
   return k;
 }
 
+// Home slot of a voxel key: the voxel's 4x4x4 block picks a 64-slot bucket (512 B of keys, 256 B of values) and the
+// position inside the block the slot within it.  The 27 probes of a submanifold rule row then touch at most 8 buckets, and
+// rows that are neighbours in space (consecutive rows of a lidar ring) probe the same ones -- with a plain mix64(key) home
+// every probe was its own 64-byte sector: k_rulebook_subm moved 11x its algorithmic bytes (profiles/r1_joint_hbm_traffic.json).
+// Voxels of one block never collide with each other; two blocks sharing a bucket do, and linear probing resolves it inside the
+// bucket's lines.  The table is an index only: row numbers and rule tables do not depend on it.
+__device__ __forceinline__ uint32_t home_slot(uint64_t key, uint32_t mask) {
+  const uint64_t blk = key & ~0x003003003ull;   // low 2 bits of x, y, z cleared
+  const uint32_t local = (uint32_t)((((key >> 24) & 3) << 4) | (((key >> 12) & 3) << 2) | (key & 3));
+  return ((((uint32_t)mix64(blk)) << 6) | local) & mask;
+}
+
 __device__ __forceinline__ int resolve_n(int n_host, const int* n_dev) { return n_dev ? *n_dev : n_host; }
 
 // ---------------------------------------------------------------- key packing
@@ -62,7 +74,7 @@ __global__ void k_insert(const uint64_t* __restrict__ keys, int n_host, const in
   int n = resolve_n(n_host, n_dev);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     uint64_t key = keys[i];
-    uint32_t s = (uint32_t)mix64(key) & mask;
+    uint32_t s = home_slot(key, mask);
     while (true) {
       unsigned long long prev = atomicCAS((unsigned long long*)&tk[s], (unsigned long long)KEY_EMPTY,
                                           (unsigned long long)key);
@@ -297,7 +309,7 @@ MOPA_API int mopa_coarsen_build(const uint64_t* fine_keys, int32_t n_fine_cap, c
 // ---------------------------------------------------------------- rule tables
 __device__ __forceinline__ int table_lookup(const uint64_t* __restrict__ tk, const int* __restrict__ tv,
                                             uint32_t mask, uint64_t key) {
-  uint32_t s = (uint32_t)mix64(key) & mask;
+  uint32_t s = home_slot(key, mask);
   while (true) {
     uint64_t k = tk[s];
     if (k == key) return tv[s];

@@ -131,35 +131,44 @@ MOPA_API int mopa_dropout_rows(const float* x, int32_t ldx, float* y, int32_t ld
 
 // ------------------------------------------------------------------------------------------ full-image linear head
 // pred[b][h][w][k] = x[b][h][w][:] . W[k][:] + bias[k] for h < H, w < W of the padded (Hp, Wp) feature map
-// (xmuda_arch.py:58-60 on the cropped map, resnet34_unet.py:185-186).  One thread per pixel, W in LDS.
+// (xmuda_arch.py:58-60 on the cropped map, resnet34_unet.py:185-186).  M / 4 lanes per pixel (16 for the 64-channel map): a
+// pixel's row is ONE coalesced 256-byte read across its lanes, each lane keeps its float4 of every W[k] in registers and a
+// 4-step shuffle tree sums the partial dot products (round 1: one thread per pixel walked the 256-B row by itself and the
+// kernel moved 5.5x its algorithmic bytes -- profiles/r1_joint_hbm_traffic.json).
 __global__ __launch_bounds__(256) void k_pixel_head_fwd(const float* __restrict__ x, int ld, int B, int Hp, int Wp, int H, int W,
                                                          int M, int NC, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ pred) {
-  extern __shared__ float lw[];  // w[NC][M] | bias[NC]
-  for (int i = threadIdx.x; i < NC * M; i += 256) lw[i] = w[i];
-  for (int i = threadIdx.x; i < NC; i += 256) lw[NC * M + i] = bias[i];
-  __syncthreads();
+  const int MQ = M >> 2;                       // lanes per pixel: 4, 8 or 16 (power of two, checked by the launcher)
+  const int cq = threadIdx.x % MQ;
+  float4 wr[PH_MAXNC];
+  float bk[PH_MAXNC];
+#pragma unroll
+  for (int k = 0; k < PH_MAXNC; ++k) {
+    wr[k] = k < NC ? *reinterpret_cast<const float4*>(w + k * M + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bk[k] = k < NC ? bias[k] : 0.f;
+  }
+  const int PPB = 256 / MQ;                    // pixels per block and iteration
   const int64_t total = (int64_t)B * H * W;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)blockIdx.x * PPB + threadIdx.x / MQ; i < total; i += (int64_t)gridDim.x * PPB) {
     const int wq = (int)(i % W);
     const int64_t r = i / W;
     const int h = (int)(r % H), b = (int)(r / H);
-    const float* src = x + ((int64_t)(b * Hp + h) * Wp + wq) * ld;
+    const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * Hp + h) * Wp + wq) * ld + cq * 4);
     float acc[PH_MAXNC];
 #pragma unroll
-    for (int k = 0; k < PH_MAXNC; ++k) acc[k] = k < NC ? lw[NC * M + k] : 0.f;
-    for (int c = 0; c < M; c += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(src + c);
-#pragma unroll
-      for (int k = 0; k < PH_MAXNC; ++k)
-        if (k < NC) {
-          const float* wr = lw + k * M + c;
-          acc[k] = fmaf(v.x, wr[0], fmaf(v.y, wr[1], fmaf(v.z, wr[2], fmaf(v.w, wr[3], acc[k]))));
-        }
+    for (int k = 0; k < PH_MAXNC; ++k) {
+      acc[k] = 0.f;
+      if (k < NC) {   // uniform
+        acc[k] = fmaf(v.x, wr[k].x, fmaf(v.y, wr[k].y, fmaf(v.z, wr[k].z, v.w * wr[k].w)));
+        for (int o = MQ >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+      }
     }
+    if (cq < NC) {
+      float out = 0.f;
 #pragma unroll
-    for (int k = 0; k < PH_MAXNC; ++k)
-      if (k < NC) pred[i * NC + k] = acc[k];
+      for (int k = 0; k < PH_MAXNC; ++k) out = cq == k ? acc[k] + bk[k] : out;
+      pred[i * NC + cq] = out;
+    }
   }
 }
 // dx[pix][c] (+)= sum_k dpred[pix][k] W[k][c] inside the H x W window (rows outside are left untouched).
@@ -254,8 +263,10 @@ MOPA_API int mopa_pixel_head_fwd(const float* x, int32_t ld, int32_t B, int32_t 
                                  int32_t num_classes, const float* w, const float* bias, float* pred, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || H > Hp || W > Wp || M <= 0 || (M & 3) || num_classes <= 0 || num_classes > PH_MAXNC || ld < M || (ld & 3))
     return MOPA_ERR_ARG;
-  k_pixel_head_fwd<<<stream_grid((int64_t)B * H * W, 256), 256, (size_t)(num_classes * M + num_classes) * sizeof(float),
-                     (hipStream_t)stream>>>(x, ld, B, Hp, Wp, H, W, M, num_classes, w, bias, pred);
+  const int MQ = M >> 2;   // lanes per pixel: a power of two <= 64 that holds every class (lane k writes class k)
+  if ((MQ & (MQ - 1)) != 0 || MQ > 64 || MQ < num_classes || (((uintptr_t)x | (uintptr_t)w) & 15)) return MOPA_ERR_ARG;
+  k_pixel_head_fwd<<<stream_grid(cdiv64((int64_t)B * H * W, 256 / MQ) * 256, 256), 256, 0, (hipStream_t)stream>>>(
+      x, ld, B, Hp, Wp, H, W, M, num_classes, w, bias, pred);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

@@ -125,6 +125,17 @@ class Geometry3D:
         call("mopa_points_csr", ptr(self.point_row), N, A[0], ptr(self.row_start), ptr(self.row_points), ptr(ws),
              ws.numel(), st)
 
+    def rule_table(self, kind: str, l: int) -> torch.Tensor:
+        """subm: 27 offsets at level l; down / up: the stride-2 tables between levels l and l + 1; nin: the identity rule
+        (the centre offset's row of the 27-offset table), for NetworkInNetwork as a one-offset convolution."""
+        if kind == "subm":
+            return self.nbr27[l]
+        if kind == "down":
+            return self.ch[l]
+        if kind == "up":
+            return self.up[l]
+        return self.nbr27[l][13:14]
+
     def rulebook(self, table: torch.Tensor):
         return self._rb.get(table.data_ptr())
 
@@ -409,7 +420,7 @@ class SCNNetFunction(torch.autograd.Function):
             return View(bufs[v.buf], v.col, v.C)
 
         def table(kind, l):
-            return {"subm": geom.nbr27[l], "down": geom.ch[l], "up": geom.up[l], "nin": geom.nbr27[l][13:14]}[kind]
+            return geom.rule_table(kind, l)
 
         feats = feats.contiguous().float()
         cin = spec.in_channels
@@ -497,7 +508,7 @@ class SCNNetFunction(torch.autograd.Function):
             return View(gbufs[v.buf], v.col, v.C), acc
 
         def table(kind, l):
-            return {"subm": geom.nbr27[l], "down": geom.ch[l], "up": geom.up[l], "nin": geom.nbr27[l][13:14]}[kind]
+            return geom.rule_table(kind, l)
 
         dfeats, dl1 = cont(dfeats), cont(dl1)
         dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
