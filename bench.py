@@ -451,19 +451,21 @@ def main():
     # outside the timed region; with equal counts (this synthetic workload) every weight is exactly 1.
     from mopa_amd.step import global_mean_weight
     rank_weight = global_mean_weight(sum(int(b["locs"].shape[0]) for b in batches))
-    overlap_3d = os.environ.get("MOPA_BENCH_OVERLAP_AR", "1") != "0"
+    # (RCCL only: the gloo plumbing mode stages device tensors through host memory inside the collective -- nothing to overlap)
+    overlap_3d = os.environ.get("MOPA_BENCH_OVERLAP_AR", "1") != "0" and world > 1 and dist.get_backend() == "nccl"
 
     # ---- the reference boundary's real hand-off (mopa/data/collate.py:183-186,233-235): coords int64 / feats / labels / images as
     # HOST tensors and img_indices as numpy arrays.  A copy stream uploads the next half's inputs (pageable copies, see
     # _lib.upload) while the current half computes; an event orders the consumers.  Timed AFTER the main region and reported as
     # `value_with_host_inputs` beside `value` (which by contract has its inputs resident in HBM).
     host_batches = None
-    if joint and not mopa and os.environ.get("MOPA_BENCH_HOST_INPUTS", "1") != "0":
+    shared_gpu = world > 1 and dist.get_backend() != "nccl"   # plumbing mode: several ranks on one device, keep the stream count down
+    if joint and not mopa and not shared_gpu and os.environ.get("MOPA_BENCH_HOST_INPUTS", "1") != "0":
         host_batches = []
         for bt in batches:
             host_batches.append(dict(locs=bt["locs"].cpu(), feats=bt["feats"].cpu(), label=bt["label"].cpu(), img=bt["img"].cpu(),
                                      idx=[np.ascontiguousarray(a) for a in bt.pop("idx_host")]))
-    copy_stream = torch.cuda.Stream(device=dev)
+    copy_stream = torch.cuda.Stream(device=dev) if host_batches is not None else None
 
     def stage(hb):
         """Upload one half's inputs on the copy stream -> (device batch, event)."""

@@ -26,7 +26,11 @@ __device__ __forceinline__ uint64_t mix64(uint64_t k) {
 // every probe was its own 64-byte sector: k_rulebook_subm moved 11x its algorithmic bytes (profiles/r1_joint_hbm_traffic.json).
 // Voxels of one block never collide with each other; two blocks sharing a bucket do, and linear probing resolves it inside the
 // bucket's lines.  The table is an index only: row numbers and rule tables do not depend on it.
+#ifndef MOPA_HASH_LOCAL
+#define MOPA_HASH_LOCAL 1   // 0: plain mix64(key) home (round 1) -- A/B builds only (profiles/ab)
+#endif
 __device__ __forceinline__ uint32_t home_slot(uint64_t key, uint32_t mask) {
+  if (!MOPA_HASH_LOCAL) return (uint32_t)mix64(key) & mask;
   const uint64_t blk = key & ~0x003003003ull;   // low 2 bits of x, y, z cleared
   const uint32_t local = (uint32_t)((((key >> 24) & 3) << 4) | (((key >> 12) & 3) << 2) | (key & 3));
   return ((((uint32_t)mix64(blk)) << 6) | local) & mask;

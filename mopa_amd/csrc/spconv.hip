@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -895,11 +896,13 @@ static int launch_t4(const int* gs, const int* go, const int* gi, const int* gou
 #define T4_GO(P)                                                                                                          \
   {                                                                                                                       \
     auto kern = k_spconv_t4<NTW, NKU, D, P, NWV>;                                                                         \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set && lds > 64 * 1024) {                                                                                   \
+    /* > 64 KB of dynamic LDS needs the attribute once per kernel; the flag only caches that idempotent call (atomic: any   \
+       host thread may be the first) -- it carries no state that a result depends on */                                   \
+    static std::atomic<bool> attr_set{false};                                                                             \
+    if (lds > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return MOPA_ERR_LAUNCH;                                                                                           \
-      attr_set = true;                                                                                                    \
+      attr_set.store(true, std::memory_order_release);                                                                    \
     }                                                                                                                     \
     kern<<<grid, 64 * NWV, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, cin, Wp, w_flip, out, ld_out);               \
   }

@@ -372,6 +372,53 @@ class Program:
         self.out = val(0, m)
         self.ops.append(("bn", prefix + "3", x, self.out))
 
+    def backward_plan(self):
+        """The backward schedule, resolved ONCE per program (it depends on the structure only): for every op in reverse order
+        where its output gradient is read from and where its input gradient goes -- `(buffer, col, C)` slices of gradient
+        buffers that mirror the activation buffers -- and whether that write accumulates (the slice already holds a
+        contribution: the skip half of a join buffer, the input of a ResNet block).  AddTable hands its output gradient to
+        both operands by aliasing.  The 3D step is host-paced, so none of this bookkeeping is redone per step."""
+        if getattr(self, "_bwd", None) is not None:
+            return self._bwd
+        written = [[] for _ in self.bufs]
+        alias = {}
+
+        def ref(v):      # where the gradient of value v lives
+            return alias.get(v.key, (v.buf, v.col, v.C))
+
+        def write(v):
+            if v.key in alias:
+                return alias[v.key], True
+            acc = any(c < v.col + v.C and v.col < c + n for c, n in written[v.buf])
+            assert not acc or any(c <= v.col and v.col + v.C <= c + n for c, n in written[v.buf]), "partial overlap of gradient slices"
+            written[v.buf].append((v.col, v.C))
+            return (v.buf, v.col, v.C), acc
+
+        plan = []
+        out_ref, _ = write(self.out)
+        for op in reversed(self.ops):
+            if op[0] == "bn":
+                _, name, src, dst = op
+                dy = ref(dst)
+                dx, acc = write(src)
+                plan.append(("bn", name, src, dy, dx, acc))
+            elif op[0] == "conv":
+                _, name, kind, l, src, dst = op
+                dout = ref(dst)
+                if src is self.x0:     # the stem: its input gradient exists only when the caller wants d(feats)
+                    plan.append(("conv", name, kind, l, src, dout, (src.buf, src.col, src.C)))
+                    continue
+                dx, acc = write(src)
+                assert not acc, "a convolution's backward-data must be the first writer of its input gradient"
+                plan.append(("conv", name, kind, l, src, dout, dx))
+            else:
+                _, a, b, dst = op
+                g = ref(dst)
+                alias[a.key] = g
+                alias[b.key] = g
+        self._bwd = (out_ref, plan)
+        return self._bwd
+
     def layer_sequence(self):
         """The arithmetic layers in execution order, in the vocabulary of tests/golden/g6_scn_structure.json."""
         seq = [["InputLayer", self.x0.C, self.x0.C, None, 0]]
@@ -412,12 +459,16 @@ class SCNNetFunction(torch.autograd.Function):
         A, m = geom.num_active, spec.m
         prog = program_for(spec)
         bufs = [None] * len(prog.bufs)
+        views = {}
 
         def view(v: Val) -> View:
-            if bufs[v.buf] is None:
-                level, width = prog.bufs[v.buf]
-                bufs[v.buf] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
-            return View(bufs[v.buf], v.col, v.C)
+            vw = views.get(v.key)
+            if vw is None:
+                if bufs[v.buf] is None:
+                    level, width = prog.bufs[v.buf]
+                    bufs[v.buf] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
+                vw = views[v.key] = View(bufs[v.buf], v.col, v.C)
+            return vw
 
         def table(kind, l):
             return geom.rule_table(kind, l)
@@ -459,7 +510,7 @@ class SCNNetFunction(torch.autograd.Function):
              ptr(P["linear.bias"]), ptr(w2), ptr(b2), ptr(out_feats), ptr(l1), ptr(l2) if spec.dual_head else None,
              stream())
         ctx.spec, ctx.geom, ctx.training = spec, geom, training
-        ctx.prog, ctx.bufs, ctx.stats = prog, bufs, stats
+        ctx.prog, ctx.views, ctx.stats = prog, views, stats
         # a detached alias: the returned tensor itself gets this node as grad_fn, and keeping it on ctx would be a reference
         # cycle (node -> ctx -> output -> node) that only the cyclic GC frees -- ~2 GB of activations per step
         ctx.P, ctx.out_feats = P, out_feats.detach()
@@ -470,7 +521,7 @@ class SCNNetFunction(torch.autograd.Function):
     def backward(ctx, dfeats, dl1, dl2):
         if dfeats is None and dl1 is None and dl2 is None:   # nothing flows back (e.g. only used as a detached KL target)
             return (None,) * (4 + len(ctx.spec.order))
-        spec, geom, P, prog, bufs = ctx.spec, ctx.geom, ctx.P, ctx.prog, ctx.bufs
+        spec, geom, P, prog, views = ctx.spec, ctx.geom, ctx.P, ctx.prog, ctx.views
         dev = geom.device
         N, m, C = geom.n_points, spec.m, spec.num_classes
         A = geom.num_active
@@ -480,39 +531,23 @@ class SCNNetFunction(torch.autograd.Function):
         def cont(t):
             return None if t is None else t.contiguous().float()
 
-        # gradient buffers mirror the activation buffers; a value's gradient is the same column slice of its buffer's mirror
+        out_ref, plan = prog.backward_plan()
         gbufs = [None] * len(prog.bufs)
-        written = [[] for _ in prog.bufs]    # column intervals of each gradient buffer that already hold a contribution
-        alias = {}                            # value key -> View standing in for its gradient (AddTable fans one gradient out)
+        gviews = {}
 
-        def fwd(v: Val) -> View:
-            return View(bufs[v.buf], v.col, v.C)
-
-        def grad_read(v: Val) -> View:
-            if v.key in alias:
-                return alias[v.key]
-            assert gbufs[v.buf] is not None, "gradient requested before it was produced"
-            return View(gbufs[v.buf], v.col, v.C)
-
-        def grad_write(v: Val):
-            """-> (view, accumulate): accumulate when (part of) the slice already holds a gradient."""
-            if v.key in alias:
-                return alias[v.key], True
-            if gbufs[v.buf] is None:
-                level, width = prog.bufs[v.buf]
-                gbufs[v.buf] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
-            acc = any(c < v.col + v.C and v.col < c + n for c, n in written[v.buf])
-            if acc:
-                assert any(c <= v.col and v.col + v.C <= c + n for c, n in written[v.buf]), "partial overlap of gradient slices"
-            written[v.buf].append((v.col, v.C))
-            return View(gbufs[v.buf], v.col, v.C), acc
-
-        def table(kind, l):
-            return geom.rule_table(kind, l)
+        def gview(ref) -> View:   # (buffer, col, C) slice of the gradient buffer mirroring activation buffer `buffer`
+            vw = gviews.get(ref)
+            if vw is None:
+                b = ref[0]
+                if gbufs[b] is None:
+                    level, width = prog.bufs[b]
+                    gbufs[b] = torch.empty(A[level], width, dtype=torch.float32, device=dev)
+                vw = gviews[ref] = View(gbufs[b], ref[1], ref[2])
+            return vw
 
         dfeats, dl1 = cont(dfeats), cont(dl1)
         dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
-        dy, _ = grad_write(prog.out)
+        dy = gview(out_ref)
         wsb = query("mopa_output_layer_heads_bwd_workspace_bytes", N, m, C)
         ws = _ws(wsb, dev)
         hnames = (["linear.weight", "linear.bias"] if dl1 is not None else []) + \
@@ -524,27 +559,23 @@ class SCNNetFunction(torch.autograd.Function):
              ptr(geom.row_points), A0, N, m, C, dy.p, dy.ld, ptr(hg.get("linear.weight")), ptr(hg.get("linear.bias")),
              ptr(hg.get("linear2.weight")), ptr(hg.get("linear2.bias")), int(hacc), ptr(ws), ws.numel(), stream())
 
-        stem_name = spec.prefix + "1"
-        for op in reversed(prog.ops):
-            if op[0] == "bn":
-                _, name, src, dst = op
-                dyv = grad_read(dst)
-                dx, acc = grad_write(src)
+        for step in plan:
+            if step[0] == "bn":
+                _, name, src, dy_ref, dx_ref, acc = step
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-                bnrelu_bwd(dyv, fwd(src), dx, ctx.stats[name], ctx.training, dg, db, acc, pacc)
-            elif op[0] == "conv":
-                _, name, kind, l, src, dst = op
-                dout = grad_read(dst)
+                bnrelu_bwd(gview(dy_ref), views[src.key], gview(dx_ref), ctx.stats[name], ctx.training, dg, db, acc, pacc)
+            else:
+                _, name, kind, l, src, dout_ref, dx_ref = step
+                dout = gview(dout_ref)
                 w = P[name + ".weight"]
                 (dw,), wacc = sink.take(name + ".weight")
-                t = table(kind, l)
+                t = geom.rule_table(kind, l)
                 if kind == "nin":
                     w, dw = w.view(1, w.shape[0], w.shape[1]), dw.view(1, dw.shape[0], dw.shape[1])
-                spconv_bwd_weight(t, fwd(src), dout, dw, accumulate=wacc)
-                if name == stem_name and not ctx.feats_needs_grad:
+                spconv_bwd_weight(t, views[src.key], dout, dw, accumulate=wacc)
+                if src is prog.x0 and not ctx.feats_needs_grad:
                     continue
-                dx, acc = grad_write(src)
-                assert not acc, "a convolution's backward-data must be the first writer of its input gradient"
+                dx = gview(dx_ref)
                 if kind == "subm":        # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
                     spconv_fwd(t, dout, w, dx, w_flip=True, rb=geom.rulebook(t), w_transposed=True)
                 elif kind == "nin":
@@ -552,15 +583,10 @@ class SCNNetFunction(torch.autograd.Function):
                 else:                     # rules reversed: conv <-> deconv swap tables
                     rt = geom.up[l] if kind == "down" else geom.ch[l]
                     spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
-            else:                         # AddTable: both operands receive the output's gradient
-                _, a, b, dst = op
-                g = grad_read(dst)
-                alias[a.key] = g
-                alias[b.key] = g
         dfeat_in = None
         if ctx.feats_needs_grad:
             cin = spec.in_channels
-            dx0 = grad_read(prog.x0)
+            dx0 = gview((prog.x0.buf, prog.x0.col, prog.x0.C))
             dfeat_in = torch.zeros(N, cin, dtype=torch.float32, device=dev)
             call("mopa_input_layer_bwd", dx0.p, dx0.ld, ptr(geom.point_row), ptr(geom.row_start), N, cin,
                  ptr(dfeat_in), stream())

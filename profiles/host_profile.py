@@ -16,11 +16,16 @@ opt = FlatAdam(m.parameters())
 batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
+locs_dev = b["x"][0].cuda()
+
+
 def step(n):
     for _ in range(n):
-        batch["geometry_3d"] = Geometry3D(b["x"][0], 7, 4096, "cuda")
+        opt.zero_grad()
+        batch["geometry_3d"] = Geometry3D(locs_dev, 7, 4096, "cuda")
         out = m(batch)
         (out["seg_logit"].square().mean() + out["seg_logit2"].square().mean()).backward()
+        opt.step()
     torch.cuda.synchronize()
 
 
@@ -29,4 +34,5 @@ pr = cProfile.Profile()
 pr.enable()
 step(10)
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(25)
