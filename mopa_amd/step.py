@@ -8,6 +8,8 @@ Results are bit-identical to sequential execution (same kernels, same per-networ
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -34,7 +36,9 @@ def global_mean_weight(n_local: int, group=None) -> float:
 class DualStream:
     def __init__(self, device, order_2d_first: bool = False):
         self.device = torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device)
+        # MOPA_SIDE_PRIORITY=-1: a high-priority HIP stream for the 3D branch / the geometry builds (tuning switch)
+        prio = int(os.environ.get("MOPA_SIDE_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(device=self.device, priority=prio)
         self.order_2d_first = order_2d_first
 
     def on_side(self, *tensors_from_main):

