@@ -13,7 +13,9 @@ before the timed region.  value = scans/s over all ranks (weak scaling: per-GPU 
 
 A/B switches (environment; the defaults are what the numbers in DESIGN.md were measured with):
   MOPA_BENCH_EVENT_STRIDE=5   HIP-event brackets (roofline figures) on every n-th timed step; 0 = none, 1 = every step
-  MOPA_BENCH_STEP_TIMES=1     per-step host clock + caching-allocator counters of the timed region on stderr
+  MOPA_BENCH_STEP_TIMES=1     per-step host clock + caching-allocator counters + cyclic-GC passes of the timed region on stderr
+  MOPA_BENCH_GC_FREEZE=0      skip mopa_amd.step.freeze_host_heap() after the warm-up (then one 70-100 ms full GC pass lands in
+                              the timed region: -20 % on the launch-bound 3D-only workload, nothing on the joint one)
   MOPA_BENCH_GEOM_AHEAD=0     voxel geometry built behind the main stream again;  MOPA_BENCH_REORDER=0  3D forward enqueued
                               first, 3D losses on the main stream;  MOPA_BENCH_BWD3_FIRST=0  (with REORDER=0) 2D backward first
   MOPA_BENCH_NO_SIDE=1        3D branch on the main stream;  MOPA_WGRAD_STREAM=0  2D weight gradients on the main stream
@@ -525,6 +527,11 @@ def main():
         step(i)
     torch.cuda.synchronize()
     print(f"[bench] rank {rank}: warmup {args.warmup} steps in {time.perf_counter() - t_setup:.2f}s", file=sys.stderr, flush=True)
+    if os.environ.get("MOPA_BENCH_GC_FREEZE", "1") != "0":
+        # what a trainer does once before its iteration loop (mopa_amd.step.freeze_host_heap): without it one full pass of
+        # Python's cyclic collector (70-100 ms over torch's ~2 M module-level objects) lands somewhere in the timed region
+        from mopa_amd.step import freeze_host_heap
+        freeze_host_heap()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -535,6 +542,16 @@ def main():
     t0 = time.perf_counter()
     per_step, step_times = [], os.environ.get("MOPA_BENCH_STEP_TIMES")
     ms0 = torch.cuda.memory_stats() if step_times else None
+    gc_log = []
+    if step_times:   # diagnostics: cyclic-GC passes inside the timed region (generation, duration)
+        import gc
+
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], time.perf_counter() - t0, time.perf_counter() - _t[0]))
+        gc.callbacks.append(_gc_cb)
     for i in range(args.steps):
         timer.enabled = timer2d.enabled = ev_stride > 0 and i % ev_stride == 0
         n_ev_steps += int(timer.enabled)
@@ -552,6 +569,8 @@ def main():
               "freed", ms1["segment.all.freed"] - ms0["segment.all.freed"], "retries", ms1["num_alloc_retries"] - ms0["num_alloc_retries"],
               "reserved GB", round(ms1["reserved_bytes.all.current"] / 1e9, 2), "was", round(ms0["reserved_bytes.all.current"] / 1e9, 2),
               file=sys.stderr, flush=True)
+        print("[bench] cyclic-GC passes >1 ms (generation, at s, lasted ms):",
+              [(g, round(at, 3), round(1e3 * d, 1)) for g, at, d in gc_log if d > 1e-3], file=sys.stderr, flush=True)
         print("[bench] cumulative step times:", " ".join(f"{t:.3f}" for t in per_step), file=sys.stderr, flush=True)
     t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
     torch.cuda.synchronize()

@@ -33,6 +33,20 @@ def global_mean_weight(n_local: int, group=None) -> float:
     return float(n_local) * dist.get_world_size(group) / total if total > 0 else 1.0
 
 
+def freeze_host_heap() -> int:
+    """Call once after the models, optimizers and the first iterations exist (the trainer: after building everything at
+    ``train_xmuda_mopa.py:135-170``, before the iteration loop).  ``import torch`` and the model graph leave ~2 M tracked
+    Python objects behind; every full (generation-2) pass of the cyclic collector walks all of them -- 70-100 ms on this
+    host, during which nothing is enqueued and a launch-bound step (3D-only: 4.8 ms) idles the GPU for 15-20 steps' worth
+    of time (``MOPA_BENCH_STEP_TIMES=1 python bench.py --workload 3d`` prints the passes).  ``gc.freeze()`` moves what
+    exists now into the permanent generation: later passes only walk what the iterations allocate.  Nothing is disabled --
+    cycles created afterwards are still collected.  Returns the number of objects frozen."""
+    import gc
+    gc.collect()
+    gc.freeze()
+    return gc.get_freeze_count()
+
+
 class DualStream:
     def __init__(self, device, order_2d_first: bool = False):
         self.device = torch.device(device)
