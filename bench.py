@@ -280,6 +280,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # MOPA_FORCE_COLLECTIVES=1: run the process group, the gradient all-reduces (RCCL, the 3D one asynchronously on the side
+    # stream) and the data-parallel stream configuration even with ONE rank -- the only way to exercise the N-GPU code path
+    # on a 1-GPU box with the real backend (python -m torch.distributed.run --nproc-per-node 1 bench.py)
+    multi = world > 1 or os.environ.get("MOPA_FORCE_COLLECTIVES") == "1"
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
     if os.environ.get("MOPA_BENCH_DRY") == "1":
@@ -288,7 +292,7 @@ def main():
     local = local % max(ndev, 1)  # (only differs from LOCAL_RANK in the single-GPU plumbing test below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL over xGMI by default; MOPA_BENCH_BACKEND=gloo lets two ranks share one GPU to test the multi-process
         # plumbing on a 1-GPU box (RCCL refuses two ranks on one device).
@@ -319,7 +323,7 @@ def main():
         model2d, _ = build_model_2d(cfg)
         model2d = model2d.to(dev).train()
         models.append(model2d)
-    if world > 1:  # identical initial weights on every rank
+    if multi:  # identical initial weights on every rank
         for m in models:
             for p in m.parameters():
                 dist.broadcast(p.data, 0)
@@ -454,14 +458,14 @@ def main():
     from mopa_amd.step import global_mean_weight
     rank_weight = global_mean_weight(sum(int(b["locs"].shape[0]) for b in batches))
     # (RCCL only: the gloo plumbing mode stages device tensors through host memory inside the collective -- nothing to overlap)
-    overlap_3d = os.environ.get("MOPA_BENCH_OVERLAP_AR", "1") != "0" and world > 1 and dist.get_backend() == "nccl"
+    overlap_3d = os.environ.get("MOPA_BENCH_OVERLAP_AR", "1") != "0" and multi and dist.get_backend() == "nccl"
 
     # ---- the reference boundary's real hand-off (mopa/data/collate.py:183-186,233-235): coords int64 / feats / labels / images as
     # HOST tensors and img_indices as numpy arrays.  A copy stream uploads the next half's inputs (pageable copies, see
     # _lib.upload) while the current half computes; an event orders the consumers.  Timed AFTER the main region and reported as
     # `value_with_host_inputs` beside `value` (which by contract has its inputs resident in HBM).
     host_batches = None
-    shared_gpu = world > 1 and dist.get_backend() != "nccl"   # plumbing mode: several ranks on one device, keep the stream count down
+    shared_gpu = multi and dist.get_backend() != "nccl"   # plumbing mode: several ranks on one device, keep the stream count down
     if joint and not mopa and not shared_gpu and os.environ.get("MOPA_BENCH_HOST_INPUTS", "1") != "0":
         host_batches = []
         for bt in batches:
@@ -494,7 +498,7 @@ def main():
             parts = pa + half(d1, 0.1, False, ready=e1)
         elif joint:
             parts = half(batches[0], 1.0, True) + half(batches[1], 0.1, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
-            if world > 1 and overlap_3d and not host_fed:
+            if multi and overlap_3d and not host_fed:
                 # the 3D network's gradients are complete when the side stream drains: reduce them there, under the tail of the
                 # 2D backward on the main stream (RCCL orders its own stream behind the stream current at the call)
                 with torch.cuda.stream(dual.side):
@@ -532,7 +536,7 @@ def main():
         # Python's cyclic collector (70-100 ms over torch's ~2 M module-level objects) lands somewhere in the timed region
         from mopa_amd.step import freeze_host_heap
         freeze_host_heap()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     # HIP-event brackets for the roofline figures on every EVENT_STRIDE-th timed step: on every step they cost 2.8 % (joint) /
@@ -574,12 +578,12 @@ def main():
         print("[bench] cumulative step times:", " ".join(f"{t:.3f}" for t in per_step), file=sys.stderr, flush=True)
     t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = timer2d.enabled = False
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -590,14 +594,14 @@ def main():
         for i in range(2):
             step(i, host_fed=True)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         th = time.perf_counter()
         for i in range(n_host):
             step(i, host_fed=True)
         torch.cuda.synchronize()
         el_h = time.perf_counter() - th
-        if world > 1:
+        if multi:
             t = torch.tensor([el_h], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_h = t.item()
@@ -668,7 +672,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d) if joint else cpu_baseline_3d(model3d)
             print(f"[bench] cpu baseline took {time.perf_counter() - t_cpu:.1f}s", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

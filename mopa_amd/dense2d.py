@@ -201,7 +201,7 @@ WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may
 
 def _distributed():
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("MOPA_FORCE_COLLECTIVES") == "1")
 
 
 def wgrad_stream(dev):

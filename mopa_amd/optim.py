@@ -15,11 +15,15 @@ checkpoints move between the reference and this build in both directions.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.distributed as dist
 
 from ._lib import WEIGHTS_EPOCH, call, ptr, stream
+
+# MOPA_FORCE_COLLECTIVES=1: issue the all-reduce in a one-rank process group too (exercises the RCCL path on a 1-GPU box)
+_FORCE_COLLECTIVES = os.environ.get("MOPA_FORCE_COLLECTIVES") == "1"
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -99,7 +103,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def all_reduce(self, async_op=False):
         """Sum the flat gradient over ranks (RCCL when the process group backend is 'nccl')."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
             self._check_grads()
             self._checked = True   # once per iteration (~0.1 ms of host time for 200 parameters)
             return dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=async_op)
