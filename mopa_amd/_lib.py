@@ -76,6 +76,10 @@ SIGNATURES = {
     "mopa_output_layer_heads_bwd": ("i", "ppppppppiiiipippppipzp"),
     "mopa_bn_act_fwd": ("i", "pipiiippppfffipiippzp"),
     "mopa_bn_act_bwd": ("i", "pipipiiipfipipiiippiipzp"),
+    "mopa_bn_sync_moments": ("i", "piiippzp"),
+    "mopa_bn_act_fwd_sync": ("i", "pipiiippppfffipipipp"),
+    "mopa_bn_sync_bwd_sums": ("i", "pipiiipfipippippzp"),
+    "mopa_bn_act_bwd_sync": ("i", "pipipiiipfipipiippiipp"),
     # ---- dense 2D branch (conv2d.hip, ops2d.hip)
     "mopa_conv2d_igemm": ("i", "pppppip"),
     "mopa_conv2d_igemm_batched": ("i", "ppppilllip"),
@@ -96,6 +100,7 @@ SIGNATURES = {
     "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),
     "mopa_conv2d_stem_relayout": ("i", "ppiiip"),
     "mopa_img_to_nhwc4": ("i", "piiiiipp"),
+    "mopa_stem_dgrad_image": ("i", "piiiiiippp"),
     "mopa_maxpool3x3s2_fwd": ("i", "piiiiipipp"),
     "mopa_maxpool3x3s2_bwd": ("i", "pipiiiipiip"),
     "mopa_dropout_rows": ("i", "pipiliflp"),

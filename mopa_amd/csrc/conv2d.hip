@@ -1122,3 +1122,57 @@ MOPA_API int mopa_img_to_nhwc4(const float* img, int32_t B, int32_t H, int32_t W
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gradient w.r.t. the input image (only when the caller passes an image with requires_grad: adversarial / saliency style
+// use of the model -- MoPA's training never asks for it, so this is not a hot-path kernel, just the missing edge of the
+// drop-in).  Backward-data of conv1 (7x7, stride 1, padding 3, 3 -> 64; resnet34_unet.py:144) restricted to the H x W window
+// the image occupies inside the /16-padded frame:
+//   dimg[b][c][y][x] = sum_{ky,kx,co} dc1[b][y+3-ky][x+3-kx][co] * w[co][c][ky][kx]        (terms outside the Hp x Wp map dropped)
+// One thread per image pixel (16 x 16 tile per block), the filter in LDS as [tap][co] float4 (c0,c1,c2,0), broadcast reads;
+// fixed summation order (tap-major, then co).
+__global__ __launch_bounds__(256) void k_stem_dgrad_image(const float* __restrict__ dout, int ld, int Hp, int Wp, int H, int W,
+                                                           const float* __restrict__ w, float* __restrict__ dimg) {
+  __shared__ float4 wl[49 * 64];
+  for (int i = threadIdx.x; i < 49 * 64; i += 256) {
+    const int tap = i >> 6, co = i & 63;
+    const float* p = w + (int64_t)co * 147 + tap;   // OIHW: ((co*3 + c)*7 + ky)*7 + kx
+    wl[i] = make_float4(p[0], p[49], p[98], 0.f);
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4), b = blockIdx.z;
+  if (x >= W || y >= H) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int ky = 0; ky < 7; ++ky) {
+    const int py = y + 3 - ky;
+    if ((unsigned)py >= (unsigned)Hp) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      const int px = x + 3 - kx;
+      if ((unsigned)px >= (unsigned)Wp) continue;
+      const float4* d = reinterpret_cast<const float4*>(dout + ((int64_t)(b * Hp + py) * Wp + px) * ld);
+      const float4* wt = wl + (ky * 7 + kx) * 64;
+#pragma unroll 4
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 v = d[c4];
+        const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 ww = wt[c4 * 4 + j];
+          a0 = fmaf(vs[j], ww.x, a0); a1 = fmaf(vs[j], ww.y, a1); a2 = fmaf(vs[j], ww.z, a2);
+        }
+      }
+    }
+  }
+  const int64_t o = ((int64_t)b * 3 * H + y) * W + x;
+  dimg[o] = a0; dimg[o + (int64_t)H * W] = a1; dimg[o + 2 * (int64_t)H * W] = a2;
+}
+// dout: gradient of conv1's output, NHWC [B][Hp][Wp] rows of `ld` floats (64 used); w: conv1.weight OIHW [64][3][7][7];
+// dimg: NCHW (B,3,H,W), overwritten.
+MOPA_API int mopa_stem_dgrad_image(const float* dout, int32_t ld, int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W,
+                                   const float* w, float* dimg, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Hp < H || Wp < W || ld < 64 || (ld & 3) || (((uintptr_t)dout) & 15)) return MOPA_ERR_ARG;
+  dim3 grid((unsigned)((W + 15) / 16), (unsigned)((H + 15) / 16), (unsigned)B);
+  k_stem_dgrad_image<<<grid, 256, 0, (hipStream_t)stream>>>(dout, ld, Hp, Wp, H, W, w, dimg);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

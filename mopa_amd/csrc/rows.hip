@@ -338,6 +338,151 @@ MOPA_API int mopa_bnrelu_rows_bwd(const float* dy, int32_t ld_dy, const float* x
                          dgamma, dbeta, accumulate_param_grads, accumulate_dx, ws, ws_bytes, stream);
 }
 
+// ------------------------------------------------------------------------------------------ synchronised BatchNorm
+// Data-parallel option ("optional SyncBN"): the reference is single-process, its BatchNorm statistics run over the
+// whole batch (2D: B*H*W pixels, 3D: every active row of the batch).  With scans sharded over ranks each rank holds a slice of
+// those rows; the three-stage form below reproduces the single-process statistics:
+//   forward   mopa_bn_sync_moments        rank-local (mean, M2 = sum (x - mean)^2, n) per channel, in double
+//             [host: all_gather of the 2C+1 doubles over the process group -- RCCL / gloo]
+//             mopa_bn_act_fwd_sync        Chan's pairwise combination in rank order (deterministic), running statistics from the
+//                                         GLOBAL moments, then the same apply kernel as the local path
+//   backward  mopa_bn_sync_bwd_sums       rank-local sum dz, sum dz*xhat: added to dbeta / dgamma as they are (the parameter
+//                                         gradients are summed over ranks later, with every other gradient) and exported in double
+//             [host: all_reduce(SUM) of the 2C doubles]
+//             mopa_bn_act_bwd_sync        coef = global sums / global row count, then the same apply kernel
+// Cost: 2 small collectives per BN layer and direction -- an equivalence / small-batch tool, not the throughput configuration
+// (mopa_amd.syncbn; tests/test_gpu_syncbn.py checks 2 ranks x half batch == 1 rank x full batch).
+__global__ __launch_bounds__(256) void k_bn_local_moments(const float* __restrict__ partial, int nblk, const float* __restrict__ x0, int A,
+                                                           int C, double* __restrict__ moments) {
+  const int c = blockIdx.x;
+  double s, ss;
+  bn_block_sum2(partial, nblk, C, c, s, ss);
+  if (threadIdx.x == 0) {
+    const double m = s / A;
+    double m2 = ss - s * m;   // sum (d - m)^2 over the shifted values d = x - x0
+    if (m2 < 0) m2 = 0;
+    moments[c] = (double)x0[c] + m;
+    moments[C + c] = m2;
+    if (c == 0) moments[2 * C] = (double)A;
+  }
+}
+
+__global__ void k_bn_finalize_sync(const double* __restrict__ gathered, int world, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int S = 2 * C + 1;
+  double n = 0.0, mean = 0.0, m2 = 0.0;   // Chan et al.: fold rank r into the running (n, mean, M2)
+  for (int r = 0; r < world; ++r) {
+    const double nr = gathered[(int64_t)r * S + 2 * C], mr = gathered[(int64_t)r * S + c], qr = gathered[(int64_t)r * S + C + c];
+    if (nr <= 0.0) continue;
+    const double nt = n + nr, d = mr - mean;
+    mean += d * (nr / nt);
+    m2 += qr + d * d * (n * nr / nt);
+    n = nt;
+  }
+  const double var = n > 0 ? m2 / n : 0.0;
+  const float meanf = (float)mean, varf = (float)var;
+  const float unbiased = (float)(m2 / (n > 1 ? n - 1 : 1));
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  const float invstd = 1.0f / sqrtf(varf + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+}
+
+// moments: 2C+1 doubles (mean[C], M2[C], n) of this rank's rows.  ws as for mopa_bn_act_fwd.
+MOPA_API int mopa_bn_sync_moments(const float* x, int32_t ldx, int32_t num_rows, int32_t C, double* moments, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || (ldx & 3) || !moments) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_num_blocks(num_rows), RL = 256 / (C >> 2);
+  if (RL < 1) return MOPA_ERR_ARG;
+  float* partial = (float*)ws;
+  k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, bn_rows_per_block(num_rows), partial);
+  k_bn_local_moments<<<C, 256, 0, st>>>(partial, nblk, x, num_rows, C, moments);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// gathered: [world][2C+1] doubles (every rank's mopa_bn_sync_moments output, rank order).  Training mode by definition.
+MOPA_API int mopa_bn_act_fwd_sync(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps, float leak,
+                                  int32_t act, const float* res, int32_t ld_res, const double* gathered, int32_t world, float* stats,
+                                  void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3) || world <= 0 || !gathered)
+    return MOPA_ERR_ARG;
+  if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  k_bn_finalize_sync<<<(C + 255) / 256, 256, 0, st>>>(gathered, world, C, gamma, beta, running_mean, running_var, momentum, eps, stats,
+                                                      stats + C, stats + 2 * C, stats + 3 * C);
+  k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats, stats + C, leak, res, ld_res, act);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_local_sums(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate, double* __restrict__ sums) {
+  const int c = blockIdx.x;
+  double s, ss;
+  bn_block_sum2(partial, nblk, C, c, s, ss);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+    sums[c] = s;
+    sums[C + c] = ss;
+  }
+}
+__global__ void k_bn_bwd_coef_sync(const double* __restrict__ sums, const double* __restrict__ gathered, int world, int C,
+                                   float* __restrict__ coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  double n = 0.0;   // global row count: the n entries of the forward pass's gathered moments (no host round trip)
+  for (int r = 0; r < world; ++r) n += gathered[(int64_t)r * (2 * C + 1) + 2 * C];
+  coef[i] = (float)(sums[i] / n);
+}
+
+// sums: 2C doubles (sum dz, sum dz*xhat over this rank's rows); dgamma / dbeta receive the LOCAL sums.
+MOPA_API int mopa_bn_sync_bwd_sums(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, int32_t num_rows, int32_t C,
+                                   const float* stats, float leak, int32_t act, const float* ymask, int32_t ld_ym, float* dgamma,
+                                   float* dbeta, int32_t accumulate_param_grads, double* sums, void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ((ldx | ld_dy) & 3) || !sums) return MOPA_ERR_ARG;
+  if (ymask && (ld_ym < C || (ld_ym & 3))) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_num_blocks(num_rows), RL = 256 / (C >> 2);
+  float* partial = (float*)ws;
+  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask, ld_ym, act,
+                                                                          bn_rows_per_block(num_rows), partial);
+  k_bn_bwd_local_sums<<<C, 256, 0, st>>>(partial, nblk, C, dgamma, dbeta, accumulate_param_grads, sums);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// sums_global: the all-reduced (SUM) 2C doubles; gathered / world: the forward pass's moments (their n entries give the global row
+// count).  coef_ws: 2C floats of scratch.
+MOPA_API int mopa_bn_act_bwd_sync(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx, int32_t num_rows,
+                                  int32_t C, const float* stats, float leak, int32_t act, const float* ymask, int32_t ld_ym, float* dres,
+                                  int32_t ld_dres, int32_t accumulate_dres, const double* sums_global, const double* gathered,
+                                  int32_t world, int32_t accumulate_dx, float* coef_ws, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3) || world <= 0 ||
+      !sums_global || !gathered || !coef_ws)
+    return MOPA_ERR_ARG;
+  if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  k_bn_bwd_coef_sync<<<(2 * C + 255) / 256, 256, 0, st>>>(sums_global, gathered, world, C, coef_ws);
+  k_bn_bwd_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef_ws, leak, 1,
+                                                             accumulate_dx, ymask, ld_ym, act, dres, ld_dres, accumulate_dres);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ InputLayer mode 4
 // out[row][c] = mean over the row's points (increasing point index) of feats[p][c]; columns [cin, ld) zero-filled.
 __global__ void k_input_layer_fwd(const float* __restrict__ feats, int cin, const int* __restrict__ row_start,

@@ -14,6 +14,7 @@ import os
 import numpy as np
 import torch
 
+from . import syncbn
 from ._lib import GradSink, call, ptr, query, stream, workspace
 from .sparse3d import View
 
@@ -357,6 +358,10 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
 
 
 def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
+    """Returns None, or -- synchronised BatchNorm (mopa_amd.syncbn) in training mode -- the gathered moments for bn_bwd."""
+    if training and syncbn.active():
+        return syncbn.fwd(x, y, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"],
+                          BN_MOMENTUM, BN_EPS, 0.0, act, res, stats)
     wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bn_act_fwd", x.p, x.ld, y.p, y.ld, x.rows, x.C, ptr(P[name + ".weight"]), ptr(P[name + ".bias"]),
@@ -366,7 +371,9 @@ def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
 
 
 def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, acc_dx=False,
-           acc_params=False):
+           acc_params=False, gathered=None):
+    if gathered is not None:   # the forward pass of this layer ran with global statistics
+        return syncbn.bwd(dy, x, dx, stats, 0.0, act, ymask, dres, acc_dres, dgamma, dbeta, acc_params, acc_dx, gathered)
     wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bn_act_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), 0.0, int(act),
@@ -394,10 +401,10 @@ class Net2DFunction(torch.autograd.Function):
         def bn(name, x, act=1, res=None, out=None):
             y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
             stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
-            bn_fwd(x, y, P, name, act, res, training, stats)
+            gathered = bn_fwd(x, y, P, name, act, res, training, stats)
             if training:
                 nbt.append(P[name + ".num_batches_tracked"])
-            tape.append(("bn", name, x, y, stats, act, res))
+            tape.append(("bn", name, x, y, stats, act, res, gathered))
             return y
 
         def conv(name, x, k, s, p, bias=False, out=None):
@@ -499,7 +506,7 @@ class Net2DFunction(torch.autograd.Function):
         # feats.detach(): an alias without grad_fn -- the output object itself on ctx would be a reference cycle through this
         # node, freed only by the cyclic GC (the activations of every step stayed allocated until then)
         ctx.feat, ctx.feats, ctx.point_pix, ctx.dims = feat, feats.detach(), point_pix, (B, H, W, Hp, Wp, N)
-        ctx.drop_seed = drop_seed
+        ctx.drop_seed, ctx.img_dtype = drop_seed, img.dtype
         return feats, l1, l2, pred_all
 
     @staticmethod
@@ -548,6 +555,7 @@ class Net2DFunction(torch.autograd.Function):
                  dfeat.p, dfeat.ld, 1, ptr(pw), ptr(pb), int(head_w_acc or pacc), ptr(ws), ws.numel(), stream())
 
         gmap = {}
+        dimg = None
 
         def key(v):
             return (v.t.data_ptr(), v.col, v.C)
@@ -560,7 +568,7 @@ class Net2DFunction(torch.autograd.Function):
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "bn":
-                _, name, x, y, stats, act, res = rec
+                _, name, x, y, stats, act, res, gathered = rec
                 dy = gmap.pop(key(y))
                 dres = None
                 acc_dres = False
@@ -575,7 +583,7 @@ class Net2DFunction(torch.autograd.Function):
                 gmap[key(x)] = dx
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
                 bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training, dg, db,
-                       acc_params=pacc)
+                       acc_params=pacc, gathered=gathered)
             elif kind == "conv":
                 _, name, op, x, out, V = rec
                 dout = gmap.pop(key(out))
@@ -623,7 +631,10 @@ class Net2DFunction(torch.autograd.Function):
                     dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
                     wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
                     call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
+                if ctx.needs_input_grad[1]:   # gradient w.r.t. the image itself (not asked for by MoPA's training)
+                    dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+                    call("mopa_stem_dgrad_image", dout.p, dout.ld, B, Hp, Wp, H, W, ptr(P[pre + "conv1.weight"]), ptr(dimg), stream())
             elif kind == "block_in":
                 pass
         join_wgrad_stream(feat.t.device)   # the weight gradients are complete for whatever the caller queues next
-        return (None, None, None, None, None, None) + sink.returned()
+        return (None, dimg if dimg is None else dimg.to(ctx.img_dtype), None, None, None, None) + sink.returned()

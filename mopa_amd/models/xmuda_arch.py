@@ -115,8 +115,6 @@ class Net2DSeg(nn.Module):
         img = data_batch["img"].to(dev, non_blocking=True)
         if img.dim() != 4 or img.shape[1] != 3:
             raise RuntimeError(f"img must be (B,3,H,W), got {tuple(img.shape)}")
-        if img.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
         H, W = img.shape[2], img.shape[3]
         pix = data_batch.get("point_pix_2d")
         if pix is None:

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, syncbn
 from ._lib import GradSink, call, ptr, query, stream, workspace
 
 BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
@@ -273,13 +273,19 @@ def spconv_bwd_weight(nbr: torch.Tensor, x: View, dout: View, dw: torch.Tensor, 
 
 
 def bnrelu_fwd(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats: torch.Tensor):
+    """Returns None, or -- synchronised BatchNorm (mopa_amd.syncbn) in training mode -- the gathered moments for bnrelu_bwd."""
+    if training and syncbn.active():
+        return syncbn.fwd(x, y, gamma, beta, rmean, rvar, BN_MOMENTUM, BN_EPS, LEAK, 1, None, stats)
     wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bnrelu_rows_fwd", x.p, x.ld, y.p, y.ld, x.rows, x.C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
          BN_MOMENTUM, BN_EPS, LEAK, int(training), ptr(stats), ptr(ws), ws.numel(), stream())
 
 
-def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool, acc_params: bool = False):
+def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool, acc_params: bool = False,
+               gathered=None):
+    if gathered is not None:   # the forward pass of this layer ran with global statistics
+        return syncbn.bwd(dy, x, dx, stats, LEAK, 1, None, None, False, dgamma, dbeta, acc_params, acc_dx, gathered)
     wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
     call("mopa_bnrelu_rows_bwd", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ptr(stats), LEAK, int(training),
@@ -485,9 +491,11 @@ class SCNNetFunction(torch.autograd.Function):
             if op[0] == "bn":
                 _, name, src, dst = op
                 st = torch.empty(4, src.C, dtype=torch.float32, device=dev)
-                bnrelu_fwd(view(src), view(dst), P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
-                           P[name + ".running_var"], training, st)
+                gathered = bnrelu_fwd(view(src), view(dst), P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                                      P[name + ".running_var"], training, st)
                 stats[name] = st
+                if gathered is not None:
+                    stats[name + "/moments"] = gathered
             elif op[0] == "conv":
                 _, name, kind, l, src, dst = op
                 w = P[name + ".weight"]
@@ -563,7 +571,8 @@ class SCNNetFunction(torch.autograd.Function):
             if step[0] == "bn":
                 _, name, src, dy_ref, dx_ref, acc = step
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-                bnrelu_bwd(gview(dy_ref), views[src.key], gview(dx_ref), ctx.stats[name], ctx.training, dg, db, acc, pacc)
+                bnrelu_bwd(gview(dy_ref), views[src.key], gview(dx_ref), ctx.stats[name], ctx.training, dg, db, acc, pacc,
+                           gathered=ctx.stats.get(name + "/moments"))
             else:
                 _, name, kind, l, src, dout_ref, dx_ref = step
                 dout = gview(dout_ref)

@@ -1,0 +1,161 @@
+"""Worker of tests/test_gpu_syncbn.py (one process per rank, gloo, all ranks on cuda:0).
+
+N ranks x one scan each with mopa_amd.syncbn enabled must compute what ONE process computes on the N-scan batch (the
+reference's single-process semantics): per-point logits, BatchNorm running statistics and -- after the gradient all-reduce --
+every parameter gradient.  Exit code 0 = equal within the tolerances below, anything else = failure (details on stderr).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mopa_amd import syncbn, synth  # noqa: E402
+from mopa_amd.config import default_cfg  # noqa: E402
+from mopa_amd.models.build import build_model_2d, build_model_3d  # noqa: E402
+from oracle.params import det_tensor  # noqa: E402  (test infrastructure: deterministic weights keyed by name)
+
+LOGIT_ATOL, GRAD_REL, STAT_ATOL = 2e-4, 2e-3, 1e-5   # logits / gradient L2 (or 4x the measured noise floor) / running statistics
+
+
+def det_state(model):
+    sd = model.state_dict()
+    return {k: det_tensor(k, tuple(v.shape)) for k, v in sd.items()}
+
+
+def grad_l2(model_a, model_b):
+    """|| g_a - g_b || / || g_b || over all parameter gradients."""
+    num = den = 0.0
+    for (_, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        if pb.grad is None:
+            continue
+        num += float((pa.grad.double() - pb.grad.double()).square().sum())
+        den += float(pb.grad.double().square().sum())
+    return (num / den) ** 0.5
+
+
+def compare(tag, rank, out_s, out_f, rows, model_s, model_f, model_ctrl, failures):
+    """model_f: one process, full batch.  model_s: this rank's shard with synchronised BatchNorm, gradients all-reduced.
+    model_ctrl: one process, full batch with the scans in the opposite order -- the same mathematics summed in another order,
+    i.e. the noise floor of a gradient that has crossed the whole network (a ReLU pre-activation within round-off of zero takes
+    the other branch).  The synchronised run must sit at that floor, not at the 10-50 % a wrong row count or a missing term in
+    the BatchNorm backward would cause."""
+    for k in out_s:
+        a, b = out_s[k].detach().float(), out_f[k].detach().float()[rows]
+        err = float((a - b).abs().max())
+        if not err <= LOGIT_ATOL * max(1.0, float(b.abs().max())):
+            failures.append(f"{tag} rank {rank} output {k}: max abs err {err:.3e}")
+    floor, got = grad_l2(model_ctrl, model_f), grad_l2(model_s, model_f)
+    print(f"[syncbn] {tag} rank {rank}: gradient L2 error sync-vs-full {got:.2e}, reordered-full-vs-full (noise floor) {floor:.2e}",
+          file=sys.stderr, flush=True)
+    if not got <= max(4.0 * floor, GRAD_REL):
+        failures.append(f"{tag} rank {rank} gradients: L2 error {got:.3e} vs noise floor {floor:.3e}")
+    gmax = max(float(p.grad.abs().max()) for p in model_f.parameters() if p.grad is not None)
+    for (n, ps), (_, pf) in zip(model_s.named_parameters(), model_f.named_parameters()):
+        if pf.grad is None:
+            continue
+        scale = float(pf.grad.abs().max())
+        err = float((ps.grad - pf.grad).abs().max())
+        if not err <= 0.1 * scale + 1e-4 * gmax:   # gross errors in a single tensor (conv biases in front of a BN: true gradient 0)
+            failures.append(f"{tag} rank {rank} grad {n}: err {err:.3e} scale {scale:.3e}")
+    sf = model_f.state_dict()
+    for k, v in model_s.state_dict().items():
+        if "running_" in k:
+            err = float((v - sf[k]).abs().max())
+            if not err <= STAT_ATOL * max(1.0, float(sf[k].abs().max())):
+                failures.append(f"{tag} rank {rank} buffer {k}: err {err:.3e}")
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    failures = []
+    cfg = default_cfg(5, True)
+
+    # ------------------------------------------------------------------ 3D: one scan per rank vs the world-scan batch
+    scans = [synth.voxelize(synth.lidar_points(40 + i)) for i in range(world)]
+    npts = [len(c) for c in scans]
+    rng = np.random.Generator(np.random.PCG64(5))
+    gin = [rng.standard_normal((n, 5)).astype(np.float32) for n in npts]
+    full_locs = torch.cat([torch.cat([torch.from_numpy(c), torch.full((len(c), 1), i, dtype=torch.int64)], 1) for i, c in enumerate(scans)])
+    my_locs = torch.cat([torch.from_numpy(scans[rank]), torch.zeros(npts[rank], 1, dtype=torch.int64)], 1)
+    models = []
+    for _ in range(3):
+        m, _ = build_model_3d(cfg)
+        m.load_state_dict(det_state(m))
+        models.append(m.to(dev).train())
+    m_sync, m_full, m_ctrl = models
+    with syncbn.local_statistics():   # the single-process reference: rank-local statistics over the whole batch
+        of = m_full({"x": [full_locs, torch.ones(sum(npts), 1)]})
+        gf = torch.from_numpy(np.concatenate(gin)).to(dev)
+        ((of["seg_logit"] * gf).sum() + (of["seg_logit2"] * gf).sum()).backward()
+        # control: the same batch with the scans in the opposite order
+        rev = list(range(world))[::-1]
+        rev_locs = torch.cat([torch.cat([torch.from_numpy(scans[i]), torch.full((npts[i], 1), j, dtype=torch.int64)], 1) for j, i in enumerate(rev)])
+        oc = m_ctrl({"x": [rev_locs, torch.ones(sum(npts), 1)]})
+        gc_ = torch.from_numpy(np.concatenate([gin[i] for i in rev])).to(dev)
+        ((oc["seg_logit"] * gc_).sum() + (oc["seg_logit2"] * gc_).sum()).backward()
+    syncbn.enable()
+    os_ = m_sync({"x": [my_locs, torch.ones(npts[rank], 1)]})
+    gs = torch.from_numpy(gin[rank]).to(dev)
+    ((os_["seg_logit"] * gs).sum() + (os_["seg_logit2"] * gs).sum()).backward()
+    for p in m_sync.parameters():
+        dist.all_reduce(p.grad)
+    start = sum(npts[:rank])
+    rows = torch.arange(start, start + npts[rank], device=dev)
+    compare("3D", rank, {k: os_[k] for k in ("seg_logit", "seg_logit2")}, of, rows, m_sync, m_full, m_ctrl, failures)
+
+    # ------------------------------------------------------------------ 2D: one image per rank vs the world-image batch
+    H, W, NP = 128, 192, 300
+    imgs = torch.from_numpy(rng.random((world, 3, H, W), dtype=np.float32))
+    idx = [np.stack([rng.integers(0, H, NP), rng.integers(0, W, NP)], 1) for _ in range(world)]
+    gin2 = [rng.standard_normal((NP, 5)).astype(np.float32) for _ in range(world)]
+    models = []
+    for _ in range(3):
+        m, _ = build_model_2d(cfg)
+        m.load_state_dict(det_state(m))
+        m.net_2d.dropout.p = 0.0
+        models.append(m.to(dev).train())
+    m_sync, m_full, m_ctrl = models
+    with syncbn.local_statistics():
+        of = m_full({"img": imgs, "img_indices": idx})
+        gf = torch.from_numpy(np.concatenate(gin2)).to(dev)
+        ((of["seg_logit"] * gf).sum() + (of["seg_logit2"] * gf).sum()).backward()
+        rev = list(range(world))[::-1]
+        oc = m_ctrl({"img": imgs[rev], "img_indices": [idx[i] for i in rev]})
+        gc_ = torch.from_numpy(np.concatenate([gin2[i] for i in rev])).to(dev)
+        ((oc["seg_logit"] * gc_).sum() + (oc["seg_logit2"] * gc_).sum()).backward()
+    os_ = m_sync({"img": imgs[rank:rank + 1], "img_indices": [idx[rank]]})
+    gs = torch.from_numpy(gin2[rank]).to(dev)
+    ((os_["seg_logit"] * gs).sum() + (os_["seg_logit2"] * gs).sum()).backward()
+    for p in m_sync.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad)
+    rows = torch.arange(rank * NP, (rank + 1) * NP, device=dev)
+    compare("2D", rank, {k: os_[k] for k in ("seg_logit", "seg_logit2")}, of, rows, m_sync, m_full, m_ctrl, failures)
+
+    # rank-local statistics must NOT reproduce the full batch (otherwise this test proves nothing)
+    syncbn.disable()
+    m_loc, _ = build_model_2d(cfg)
+    m_loc.load_state_dict(det_state(m_loc))
+    m_loc.net_2d.dropout.p = 0.0
+    ol = m_loc.to(dev).train()({"img": imgs[rank:rank + 1], "img_indices": [idx[rank]]})
+    differs = float((ol["seg_logit"].detach() - of["seg_logit"].detach()[rows]).abs().max()) > 10 * LOGIT_ATOL
+    if not differs:
+        failures.append(f"rank {rank}: rank-local BatchNorm equals the full-batch result -- the check has no power")
+
+    flag = torch.tensor([len(failures)], dtype=torch.int64)
+    dist.all_reduce(flag)
+    for f in failures:
+        print("[syncbn]", f, file=sys.stderr, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()

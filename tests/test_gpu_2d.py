@@ -228,6 +228,60 @@ def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
         model({"img": img, "img_indices": [idx[0], np.array([[H, 0]])]})
 
 
+def test_stem_dgrad_image_kernel_vs_torch():
+    """mopa_stem_dgrad_image alone: backward-data of the 7x7 / stride 1 / padding 3 stem over the image window of the /16-padded
+    frame, against fp64 autograd of F.conv2d on the zero-padded image (resnet34_unet.py:133-144)."""
+    import torch.nn.functional as F
+    from mopa_amd._lib import call, ptr, stream
+    rng = np.random.Generator(np.random.PCG64(22))
+    B, H, W = 2, 37, 50
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    w = torch.from_numpy(rng.standard_normal((64, 3, 7, 7)).astype(np.float32))
+    dout = torch.from_numpy(rng.standard_normal((B, Hp, Wp, 64)).astype(np.float32))   # NHWC rows of 64
+    img = torch.zeros(B, 3, H, W, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.pad(img, [0, Wp - W, 0, Hp - H]), w.double(), padding=3)
+    (y * dout.permute(0, 3, 1, 2).double()).sum().backward()
+    dimg = torch.empty(B, 3, H, W, device="cuda")
+    dd, wd = dout.cuda().contiguous(), w.cuda().contiguous()
+    call("mopa_stem_dgrad_image", ptr(dd), 64, B, Hp, Wp, H, W, ptr(wd), ptr(dimg), stream())
+    _close(dimg, img.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gradient_wrt_input_image_vs_oracle():
+    """The reference's Net2DSeg is an ordinary autograd module: an image with requires_grad gets a gradient
+    (xmuda_arch.py:49-79 through resnet34_unet.py:131-191).  Here that is the backward-data of the 7x7 stem restricted to the
+    image window of the /16-padded frame (mopa_stem_dgrad_image, exact test above) behind the whole backward pass.  Truth: the
+    fp64 oracle's autograd.  Tolerance: like every gradient that has crossed the whole network on a small input it carries the
+    ReLU-mask-flip noise of the ill-conditioned bottleneck (see the parameter-gradient tests: few samples per channel in layer4)
+    -- 3 % in the L2 norm, 5 % of the scale pointwise."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    B, H, W = 2, 72, 104
+    img_np = rng.random((B, 3, H, W), dtype=np.float32)
+    idx = [np.stack([rng.integers(0, H, 400), rng.integers(0, W, 400)], 1) for _ in range(B)]
+    gin = {k: rng.standard_normal(s).astype(np.float32) for k, s in (("seg_logit", (800, 5)), ("seg_logit2", (800, 5)))}
+    model = _build_2d().train()
+    model.net_2d.dropout.p = 0.0
+    img = torch.from_numpy(img_np).cuda().requires_grad_(True)
+    out = model({"img": img, "img_indices": idx})
+    sum((out[k] * torch.from_numpy(v).cuda()).sum() for k, v in gin.items()).backward()
+    assert img.grad is not None and img.grad.shape == img.shape
+    P = {k: (det_tensor(k, v).double() if "num_batches" not in k else det_tensor(k, v)) for k, v in net2d.param_shapes(5, True).items()}
+    img64 = torch.from_numpy(img_np).double().requires_grad_(True)
+    ref = net2d.net2dseg_forward(P, img64, idx, training=True, dropout_p=0.0)
+    sum((ref[k] * torch.from_numpy(v).double()).sum() for k, v in gin.items()).backward()
+    truth = img64.grad.numpy()
+    got = img.grad.double().cpu().numpy()
+    scale = float(np.abs(truth).max())
+    assert scale > 0
+    assert float(np.linalg.norm(got - truth)) <= 3e-2 * float(np.linalg.norm(truth))
+    assert float(np.abs(got - truth).max()) <= 5e-2 * scale, (float(np.abs(got - truth).max()), scale)
+    # a CPU leaf image: the gradient flows back through the upload
+    img_c = torch.from_numpy(img_np).requires_grad_(True)
+    out = model({"img": img_c, "img_indices": idx})
+    out["seg_logit"].sum().backward()
+    assert img_c.grad is not None and img_c.grad.device.type == "cpu" and float(img_c.grad.abs().max()) > 0
+
+
 def test_winograd_f4_network_level(monkeypatch):
     """F(4x4,3x3) at network level.  Default = backward passes only: same logits bit for bit, gradients as close to the fp64
     oracle as the F(2x2) run.  Opt-in forward pass: logits within the stated tolerance of the oracle."""
