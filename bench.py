@@ -146,6 +146,12 @@ class Conv2dTimer:
     summary = ConvTimer.summary
 
 
+def dense2d_streams():
+    """True when the 2D weight gradients run on their own stream in this process (mopa_amd/dense2d.py::wgrad_stream)."""
+    from mopa_amd import dense2d
+    return dense2d.wgrad_stream(torch.cuda.current_device()) is not None
+
+
 def _cpu_passes(one_pass, seconds_budget, max_passes, what):
     """Bounded CPU sample: one warm-up pass, then up to `max_passes` timed passes inside the time
     budget; value = 1 / median pass time (min and count reported in `sample`)."""
@@ -639,7 +645,8 @@ def main():
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
-                    "stream_configuration": "as timed for `value`: 2D main stream + weight-gradient stream + 3D side stream"}
+                    "stream_configuration": "as timed for `value`: 2D main stream + " +
+                                            ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
               "Valid Ground-based Insertion of a 500-pt object per target scan on the device (overlap test, ground cells, "

@@ -190,24 +190,30 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
 
 
 _wgrad_streams = {}
-# MOPA_WGRAD_STREAM: "1" on, "0" off, unset = on in a single-process job and OFF under a torch.distributed process group.
-# Reason for the second half: every extra stream is another hardware queue.  Measured on a 1-GPU box with two ranks sharing
-# the device (the multi-process plumbing test): two streams per rank run at the expected speed, three per rank fall off a cliff
-# (3.4 s per step instead of 0.19).  One rank per GPU plus RCCL's own stream could not be measured here, so data-parallel
-# runs keep the two-stream configuration that was; a caller that has measured it can set MOPA_WGRAD_STREAM=1.
+# MOPA_WGRAD_STREAM: "1" on, "0" off, unset = on -- except under a torch.distributed process group whose backend is not RCCL.
+# Every extra stream is another hardware queue.  Two ranks SHARING one device (only possible over gloo: the multi-process
+# plumbing test on a 1-GPU box) with three streams each fall off a cliff (3.4 s per step instead of 0.19); two per rank behave.
+# RCCL ("nccl") refuses two ranks on one device, so under it a rank owns its GPU: measured with one rank and the real
+# collectives (MOPA_FORCE_COLLECTIVES=1), three compute streams + RCCL's own run the joint step at 242.9
+# scans/s against 227.2 with two -- the third stream stays on there.
 # (The same stream for the sparse-conv weight gradients of 3D-only training was measured too: 1347 -> 1290 scans/s -- that step
 # is host-paced and the stream switches cost more than the overlap returns: not kept.)
-WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may switch it per pass, e.g. bench.py's bracketed steps)
+WGRAD_STREAM = os.environ.get("MOPA_WGRAD_STREAM", "1") != "0"   # (a caller may switch it per pass)
 
 
-def _distributed():
+def _shared_device_group():
+    """True under a process group that may put several ranks on one device (any backend but RCCL)."""
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("MOPA_FORCE_COLLECTIVES") == "1")
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    if dist.get_world_size() == 1 and os.environ.get("MOPA_FORCE_COLLECTIVES") != "1":
+        return False
+    return dist.get_backend() != "nccl"
 
 
 def wgrad_stream(dev):
     """The stream the weight gradients of the 2D convolutions run on (None: the current stream)."""
-    if not WGRAD_STREAM or (os.environ.get("MOPA_WGRAD_STREAM") != "1" and _distributed()):
+    if not WGRAD_STREAM or (os.environ.get("MOPA_WGRAD_STREAM") != "1" and _shared_device_group()):
         return None
     key = (torch.device(dev).index, stream())   # one per (device, consumer stream)
     st = _wgrad_streams.get(key)
