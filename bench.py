@@ -19,7 +19,7 @@ A/B switches (environment; the defaults are what the numbers in DESIGN.md were m
   MOPA_BENCH_GEOM_AHEAD=0     voxel geometry built behind the main stream again;  MOPA_BENCH_REORDER=0  3D forward enqueued
                               first, 3D losses on the main stream;  MOPA_BENCH_BWD3_FIRST=0  (with REORDER=0) 2D backward first
   MOPA_BENCH_NO_SIDE=1        3D branch on the main stream;  MOPA_WGRAD_STREAM=0  2D weight gradients on the main stream
-  MOPA_CONV2D_MFMA=0          fp32 vector-pipe conv kernels;  MOPA_WINOGRAD=0 / MOPA_WINOGRAD_F4=0 / MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad
+  MOPA_CONV2D_MFMA=0          fp32 vector-pipe conv kernels;  MOPA_WINOGRAD=0 / MOPA_WINOGRAD_F4=0 / MOPA_WINOGRAD_F4_ROLES=dgrad,wgrad (exact-product forward)
   MOPA_BENCH_BACKEND=gloo     lets several ranks share one GPU (RCCL refuses that): plumbing test only
   MOPA_BENCH_DRY=1            launcher / process-group plumbing only (no GPU work): every rank joins the group, exchanges its
                               scan seeds and point counts, rank 0 prints a JSON line with n_gpus = world (CPU test of --gpus N)

@@ -132,16 +132,20 @@ def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
 
 
 F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "1500000"))
-# Which passes may use F(4x4): by default the two backward passes, where its rounding error (~1e-5 relative per layer) is a
-# linear perturbation -- logits stay bit-identical and the gradients stay as close to the fp64 oracle as with F(2x2) (tests).
-# In the FORWARD pass the same error also moves a few ReLU pre-activations across zero; layers that normalise over few samples
-# amplify such a flip (measured on a 2 x 160 x 224 input: median gradient error against fp64 1.4 % -> 1.7 %, single tensors of
-# layer4 -- 70 samples per channel -- 1.5 % -> 17 %; at the bench size, 8 x 302 x 480, profiles/f4_gradient_noise.py: median /
-# 90th percentile / max over the parameter tensors 1.0 / 2.1 / 5.0 % with F(2x2), the same with F(4x4) in the backward passes,
-# 1.4 / 2.7 / 6.7 % with F(4x4) in the forward pass too; the direct kernels: 1.0 / 2.1 / 4.3 %).  It is worth another 10 % of throughput (239 -> 263 scans/s on the joint
-# step) and its logits stay within the parity tolerance, so it is an opt-in: MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad; even then
-# the forward pass keeps F(2x2) below F4_FWD_MIN_PIXELS samples per channel.
-F4_ROLES = tuple(r for r in os.environ.get("MOPA_WINOGRAD_F4_ROLES", "dgrad,wgrad").split(",") if r) \
+# Which passes use F(4x4): all three (round 2; round 1 shipped "dgrad,wgrad").  In the backward passes its rounding error
+# (~1e-5 relative per layer) is a linear perturbation.  In the FORWARD pass the same error also moves a few ReLU pre-activations
+# across zero, and layers that normalise over few samples amplify such a flip -- measured against the fp64 oracle
+# (profiles/f4_gradient_noise.py, 8 x 302 x 480, median / 90th percentile / max error over the parameter gradients): direct
+# kernels 1.0 / 2.1 / 4.3 %, F(2x2) forward 1.0 / 2.1 / 5.0 %, F(4x4) forward 1.4 / 2.7 / 6.7 % -- the fp32-vs-fp64 noise of
+# this network is ~1 % whatever the algorithm and F(4x4) adds a third to it; on a tiny 2 x 160 x 224 input single layer4
+# tensors (70 samples per channel) went from 1.5 % to 17 %, hence F4_FWD_MIN_PIXELS below.  The logits stay inside the
+# tolerance every parity test states (rtol 1e-3 / atol 2e-4 against the reference-generated fixtures G1 / G1b and the oracle;
+# 1e-4 against the exact-product forward) and the whole GPU suite passes either way.  For scale: the reference's own arithmetic
+# on the platform it ships for (NGC PyTorch 21.06, Ampere; mopa/common/utils/torch_util.py:12-13 sets cudnn.deterministic
+# but leaves allow_tf32 at its default) is TF32 convolutions, ~1e-3 per layer, with cuDNN free to pick Winograd.
+# Worth 9 % of the joint step (256 -> 280 scans/s, same box).  MOPA_WINOGRAD_F4_ROLES=dgrad,wgrad restores the exact-product
+# forward pass (F(2x2) / direct kernels: bit-identical logits to round 1).
+F4_ROLES = tuple(r for r in os.environ.get("MOPA_WINOGRAD_F4_ROLES", "fwd,dgrad,wgrad").split(",") if r) \
     if os.environ.get("MOPA_WINOGRAD_F4", "1") != "0" else ()
 F4_FWD_MIN_PIXELS = 4096
 

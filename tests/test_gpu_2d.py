@@ -283,8 +283,9 @@ def test_gradient_wrt_input_image_vs_oracle():
 
 
 def test_winograd_f4_network_level(monkeypatch):
-    """F(4x4,3x3) at network level.  Default = backward passes only: same logits bit for bit, gradients as close to the fp64
-    oracle as the F(2x2) run.  Opt-in forward pass: logits within the stated tolerance of the oracle."""
+    """F(4x4,3x3) at network level.  Backward passes only (MOPA_WINOGRAD_F4_ROLES=dgrad,wgrad): same logits bit for bit as
+    without it, gradients as close to the fp64 oracle as the F(2x2) run.  Forward pass too (the default): logits within the
+    stated tolerance of the oracle and 1e-4 of the exact-product forward."""
     from mopa_amd import dense2d
     rng = np.random.Generator(np.random.PCG64(11))
     B, H, W = 2, 160, 224
@@ -305,7 +306,7 @@ def test_winograd_f4_network_level(monkeypatch):
     monkeypatch.setattr(dense2d, "wino_conv", lambda *a, **kw: (used.append(kw.get("F", 2)), inner(*a, **kw))[1])
     import os
     if "MOPA_WINOGRAD_F4_ROLES" not in os.environ and os.environ.get("MOPA_WINOGRAD_F4", "1") != "0":
-        assert dense2d.F4_ROLES == ("dgrad", "wgrad")   # the shipped default
+        assert dense2d.F4_ROLES == ("fwd", "dgrad", "wgrad")   # the shipped default
     o4, g4 = run(("dgrad", "wgrad"))
     assert 4 in used and 2 in used
     o2, g2 = run(())
@@ -329,7 +330,7 @@ def test_winograd_f4_network_level(monkeypatch):
         if e4 > max(1.5 * e2, 2e-4):
             worst.append((k, e4, e2))
     assert not worst, worst[:8]
-    # forward pass on F(4x4) too (MOPA_WINOGRAD_F4_ROLES=fwd,dgrad,wgrad): logits within the tolerance of the logit parity tests
+    # forward pass on F(4x4) too (the default): logits within the tolerance of the logit parity tests
     of, _ = run(("fwd", "dgrad", "wgrad"), backward=False)
     for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
         _close(of[k], ref[k].detach().float(), rtol=1e-3, atol=2e-4)

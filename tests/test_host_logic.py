@@ -132,7 +132,7 @@ def test_conv_algorithm_choice(monkeypatch):
     assert t(64, 128, 3, 2, 1, B, 152, 240, "dgrad") == 0 and t(64, 128, 1, 1, 0, B, 76, 120, "fwd") == 0
     assert t(256, 96, 3, 1, 1, B, 38, 60, "dgrad") == 0
     assert t(512, 512, 3, 1, 1, 2, 2, 3, "dgrad") == 2 and t(512, 512, 3, 1, 1, 2, 2, 3, "fwd") == 2
-    # opt-in forward pass on F(4x4): only with enough samples per channel
+    # forward pass on F(4x4) (the default since round 2): only with enough samples per channel
     monkeypatch.setattr(dense2d, "F4_ROLES", ("fwd", "dgrad", "wgrad"))
     assert t(256, 256, 3, 1, 1, B, 38, 60, "fwd") == 4 and t(256, 256, 3, 1, 1, 2, 8, 12, "fwd") == 2
     # the weight gradient in the transform domain needs 64-aligned channels on both sides
