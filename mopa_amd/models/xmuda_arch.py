@@ -48,8 +48,11 @@ def _teacher_scope_exit(entered):
 class _FlatCache:
     """`[tensor for name in spec.order]` of a module, resolved once: walking named_parameters() / named_buffers() costs ~0.3 ms per
     forward (25,000 generator steps for the 2D network), which matters for the host-paced 3D step.  Parameters and buffers keep
-    their identity under load_state_dict / optimizer updates; `Module._apply` (.cuda(), .to(), .float()) replaces buffer objects,
-    so the owning module drops the cache there."""
+    their identity under load_state_dict / optimizer updates; `Module._apply` (.cuda(), .to(), .float()) replaces buffer objects
+    and assigning a sub-module or parameter to the network (`model.linear = nn.Linear(64, 11)` for another label set) replaces
+    parameter objects: the owning module drops the cache in both cases (`_CachedParams`).  Anything that swaps tensor OBJECTS
+    deeper inside (`load_state_dict(..., assign=True)`, `model.net_2d.layer4 = ...`) must be followed by
+    `model.refresh_parameters()`."""
 
     def __init__(self):
         self.order, self.flat = None, None
@@ -63,6 +66,23 @@ class _FlatCache:
         return self.order, self.flat
 
 
+class _CachedParams:
+    """Mixin of the two networks: owns `_cache` and drops it whenever the set of tensor objects may have changed."""
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_cache"] = _FlatCache()
+        return super()._apply(fn, *a, **k)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)) and "_cache" in self.__dict__:
+            self.__dict__["_cache"] = _FlatCache()
+        super().__setattr__(name, value)
+
+    def refresh_parameters(self):
+        """Re-resolve the parameter / buffer objects on the next forward (after replacing tensors inside a sub-module)."""
+        self.__dict__["_cache"] = _FlatCache()
+
+
 def _require_cuda(module: nn.Module):
     dev = next(module.parameters()).device
     if dev.type != "cuda":
@@ -70,7 +90,7 @@ def _require_cuda(module: nn.Module):
     return dev
 
 
-class Net2DSeg(nn.Module):
+class Net2DSeg(_CachedParams, nn.Module):
     """2D branch (xmuda_arch.py:22-79): UNetResNet34, full-image head, integer point gather, point head(s)."""
 
     def __init__(self, num_classes, dual_head, backbone_2d, backbone_2d_kwargs, output_all=False):
@@ -87,10 +107,6 @@ class Net2DSeg(nn.Module):
             self.linear2 = nn.Linear(feat_channels, num_classes)
         self._cache = _FlatCache()
         self._calls = 0
-
-    def _apply(self, fn, *a, **k):
-        self._cache = _FlatCache()
-        return super()._apply(fn, *a, **k)
 
     @staticmethod
     def pack_indices(img_indices, H, W, device):
@@ -139,7 +155,7 @@ class Net2DSeg(nn.Module):
         return preds
 
 
-class Net3DSeg(nn.Module):
+class Net3DSeg(_CachedParams, nn.Module):
     """3D branch (xmuda_arch.py:82-126): SCN UNet + linear head(s) on per-point features."""
 
     def __init__(self, num_classes, dual_head, backbone_3d, backbone_3d_kwargs, da_method=None, pretrained=False):
@@ -158,10 +174,6 @@ class Net3DSeg(nn.Module):
         if da_method == "MCD":   # a third head that the reference creates but never uses in forward (xmuda_arch.py:110-126)
             self.linear3 = nn.Linear(m, num_classes)
         self._cache = _FlatCache()
-
-    def _apply(self, fn, *a, **k):
-        self._cache = _FlatCache()
-        return super()._apply(fn, *a, **k)
 
     def _spec(self):
         order, _ = self._cache.get(self)

@@ -111,7 +111,16 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0, closure=None):
-        loss = closure() if closure is not None else None
+        """``step()`` / ``step(grad_scale)`` / ``step(closure)``: torch's convention puts the closure first, so a callable in
+        the first position is taken as the closure.  ``grad_scale`` multiplies the gradient inside the update kernel
+        (``1 / world_size`` after a sum all-reduce, times the rank's loss weight)."""
+        if callable(grad_scale):
+            closure, grad_scale = grad_scale, 1.0
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        else:
+            loss = None
         if not getattr(self, "_checked", False):
             self._check_grads()
         self._checked = False

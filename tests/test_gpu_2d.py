@@ -368,6 +368,20 @@ def test_cached_weight_layouts_follow_every_kind_of_weight_update():
     with ema.average_parameters():                         # shadow = the initial weights
         assert torch.allclose(logits(), y0, rtol=1e-5, atol=1e-6)
     assert torch.equal(logits(), y2)
+    # torch's convention: step(closure) re-evaluates the model and returns the loss (the closure runs with grad enabled)
+    m.train()
+    calls = []
+
+    def closure():
+        opt.zero_grad()
+        loss = m(b)["seg_logit"].square().mean()
+        loss.backward()
+        calls.append(float(loss))
+        return loss
+
+    t0 = opt.t
+    ret = opt.step(closure)
+    assert len(calls) == 1 and float(ret) == calls[0] and opt.t == t0 + 1
 
 
 def test_net2dseg_well_conditioned_fixture_bounds_every_gradient_at_one_percent(golden_dir):

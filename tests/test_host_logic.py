@@ -140,3 +140,25 @@ def test_conv_algorithm_choice(monkeypatch):
     assert dense2d.wino_wgrad_eligible(64, 64, 3, 1, 1, B, 152, 240) and not dense2d.wino_wgrad_eligible(16, 64, 3, 1, 1, B, 152, 240)
     monkeypatch.setenv("MOPA_WINOGRAD", "0")
     assert t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 0
+
+
+def test_parameter_list_cache_follows_module_surgery():
+    """The per-forward parameter list is cached (mopa_amd/models/xmuda_arch.py::_FlatCache); replacing a head (another label
+    set), moving the module or asking for a refresh must drop it -- the reference's modules are plain nn.Modules where such
+    surgery just works."""
+    import torch.nn as nn
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d, build_model_3d
+    for build in (build_model_2d, build_model_3d):
+        m, _ = build(default_cfg(5, True))
+        order, flat = m._cache.get(m)
+        i = order.index("linear.weight")
+        assert flat[i] is m.linear.weight
+        m.linear = nn.Linear(m.linear.in_features, 11)
+        order2, flat2 = m._cache.get(m)
+        assert flat2[order2.index("linear.weight")] is m.linear.weight and flat2[order2.index("linear.weight")].shape[0] == 11
+        m.double()
+        assert m._cache.flat is None
+        m._cache.get(m)
+        m.refresh_parameters()
+        assert m._cache.flat is None
