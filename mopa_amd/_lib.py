@@ -90,6 +90,8 @@ SIGNATURES = {
     "mopa_wino_wgrad_workspace_bytes": ("z", "iii"),
     "mopa_wino_bwd_weight": ("i", "ppiiipipzp"),
     "mopa_wino4_weight": ("i", "piiipp"),
+    "mopa_wino4_weight_t": ("i", "piiipp"),
+    "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),
     "mopa_wino4_output": ("i", "piiiippiip"),
     "mopa_wino4_dout": ("i", "piiiiipp"),

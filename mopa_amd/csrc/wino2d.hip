@@ -269,7 +269,7 @@ __device__ __forceinline__ void w4_gt(const float u[6], float g[3]) {   // g = G
 }
 
 // U[p][r][c] (p = 6*i + j) = (G g G^T)[p]; dgrad as in k_wino_w
-__global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U) {
+__global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U, int transpose) {
   const int R = dgrad ? O : I, C = dgrad ? I : O;
   const int n = R * C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -291,7 +291,7 @@ __global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, 
       float u[6];
       w4_g(t[a], u);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * n + i] = u[b];
+      for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * n + (transpose ? c * R + r : i)] = u[b];   // transpose: U^T[p][c][r]
     }
   }
 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_wino4_dout(const float* __restrict__ dy
 // T = B * ceil(H/4) * ceil(W/4) tiles.
 MOPA_API int mopa_wino4_weight(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* U, void* stream) {
   if (O <= 0 || I <= 0) return MOPA_ERR_ARG;
-  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, U);
+  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, U, 0);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -438,6 +438,257 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   k_wino4_dout<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(dy, ld, B, H, W, C, th, tw, dM);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ================================================================================================================
+// F(4x4): the 36 GEMMs with the OUTPUT TRANSFORM IN THE EPILOGUE -- M (2.25x the activations) is never written or read.
+// Why: at 64-128 channels the batched GEMM is bound by V in + M out (4.2 TB/s at 67 TFLOP/s for 64 -> 64 at 152x240) and the
+// output transform re-reads M; together 129 us of that layer's 200 (profiles/by_layer_2d.py).
+// How: a block owns 64 tiles x 32 output channels and walks the 36 transform points one after the other with an LDS-staged K
+// loop per point (A = V[p] rows, B = U^T[p] rows, both k-contiguous).  The output transform is linear,
+// Y = A^T M A = sum_i AT[.][i] (sum_j m[i][j] AT[.][j]): after point (i, j) the wave folds its 8 (tile, channel) results into a
+// 4-value row sum, after the 6th j the row sum goes into the 16 output values of the pair -- 128 + 32 registers per lane
+// instead of 36 x 8 accumulators.
+// Waves: 2 (tiles) x 2 (channels), each 32 x 16 = two v_mfma_f32_16x16x4_f32 tiles; k is permuted consistently for both
+// operands (MFMA step (g, s) takes k = 16 g + 4 q + s from lane group q) so one b128 LDS read feeds 4 MFMAs.
+// Blocks are numbered so that the channel groups of one tile range run on the same XCD back to back (they share V through L2).
+// Measured (profiles/bench_wino_fused.py, B = 8, whole conv incl. the input transform, batched GEMM + output transform -> fused):
+//   64 -> 128 at 152x240  311 -> 241 us     128 -> 64 at 304x480  1087 -> 950 us     64 -> 128 at 304x480  1150 -> 808 us
+//   64 -> 64 at 152x240   181 -> 185        128 -> 64 at 152x240   287 -> 350        128^2 at 76x120 106 -> 140, deeper: worse
+// A lone block needs ~1.4 us per unit (point x 64-channel chunk) of which 0.47 us are its 32 MFMAs per wave (one wave per SIMD
+// issues them at the full rate: profiles/micro/mfma_rate.hip); DMA latency (~2 us, two units ahead) and the barrier-to-first-MFMA
+// chain fill the rest, and with 72 KB of LDS only two blocks share a CU.  So the kernel wins where there are at least two full
+// rounds of blocks (>= 1024: the 304x480 layers and the 128-output-channel layers at 152x240) and loses to the batched GEMM on
+// grids of ~570 blocks (one round plus a 58-block tail) and on the short deep levels: dense2d.wino4_fused picks by block count.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+// A^T of F(4x4,3x3), transposed: c_w4_at[j][c] = AT[c][j]
+__constant__ float c_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+#define W4G_BM 64
+#define W4G_BN 32
+#define W4G_KB 64
+#define W4G_NST 3   // LDS ring: the unit being multiplied + two in flight (LDS-DMA, no staging registers)
+
+// Staging = global_load_lds_dwordx4 (LDS-DMA): one wave instruction moves 4 rows x 256 B into 1 KiB of LDS, lane-linear.  Rows are
+// 256 B, so unpadded b128 fragment reads of 16 rows would hit one bank group 16 times: the 16-byte chunk c of row R lives in slot
+// c ^ (R & 15) -- applied on the SOURCE address when staging (the LDS image of a DMA cannot be scattered) and on the read address.
+// A unit = (transform point, 64-channel K chunk).  Per unit and wave: wait until its own DMA of this unit has landed (counted
+// vmcnt: the next unit's 6 stay in flight), barrier (everyone's has; everyone is done reading the slot that is overwritten next),
+// issue the DMA of unit u + 2, multiply unit u.  At 64 input channels a unit is only 32 MFMAs per wave (0.4 us): one unit of
+// prefetch left the kernel waiting on HBM latency for most of every step (170 us at 64 -> 64, 152x240; round-2 first version).
+__global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restrict__ V, const float* __restrict__ Ut,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int ld_out,
+                                                            int B, int H, int W, int th, int tw, int Cin, int Cout, int accumulate,
+                                                            int mtiles, int ntn, int64_t a_ps, int ldv) {
+  __shared__ __attribute__((aligned(1024))) float As[W4G_NST][W4G_BM][W4G_KB];
+  __shared__ __attribute__((aligned(1024))) float Bs[W4G_NST][W4G_BN][W4G_KB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int bid = blockIdx.x;
+  const int grp = bid / (8 * ntn), within = bid - grp * 8 * ntn;
+  const int n_idx = within >> 3, m_idx = grp * 8 + (within & 7);
+  if (m_idx >= mtiles) return;
+  const int T = B * th * tw;
+  const int m0 = m_idx * W4G_BM, n0 = n_idx * W4G_BN;
+  const int wm0 = (wv & 1) * 32, wn0 = (wv >> 1) * 16;
+  const int nkc = Cin / W4G_KB;
+  const int NU = 36 * nkc;
+  // DMA assignment: wave wv, instruction j moves rows 4 (4 j + wv) .. + 3; lane = (row in group: lane >> 4, slot: lane & 15).
+  // Byte offsets inside one transform point stay below 2^32 (launcher).
+  unsigned a_off[4], b_off[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 4 * (4 * j + wv) + (lane >> 4);
+    a_off[j] = (unsigned)(((int64_t)min(m0 + row, T - 1) * ldv + (((lane & 15) ^ (row & 15)) << 2)) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 4 * (4 * j + wv) + (lane >> 4);
+    b_off[j] = (unsigned)(((int64_t)(n0 + row) * Cin + (((lane & 15) ^ (row & 15)) << 2)) * 4);
+  }
+  const int64_t b_ps = (int64_t)Cout * Cin;
+#define W4G_DMA(U_)                                                                                                  \
+  {                                                                                                                  \
+    const int p_ = (U_) / nkc, kc_ = (U_) - p_ * nkc, st_ = (U_) % W4G_NST;                                          \
+    const char* ap_ = reinterpret_cast<const char*>(V + (int64_t)p_ * a_ps + kc_ * W4G_KB);                         \
+    const char* bp_ = reinterpret_cast<const char*>(Ut + (int64_t)p_ * b_ps + kc_ * W4G_KB);                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                 \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap_ + a_off[j_]),             \
+                                       (__attribute__((address_space(3))) void*)(&As[st_][4 * (4 * j_ + wv)][0]), 16, 0, 0); \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                 \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp_ + b_off[j_]),             \
+                                       (__attribute__((address_space(3))) void*)(&Bs[st_][4 * (4 * j_ + wv)][0]), 16, 0, 0); \
+  }
+  float o[8][16];
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[pr][e] = 0.f;
+
+  W4G_DMA(0);
+  W4G_DMA(1);
+  int u = 0;
+  // Fragment reads are inline asm: the compiler cannot tell that the slot a DMA is filling is not the slot being read and would
+  // put `s_waitcnt vmcnt(0)` in front of every compiler-visible LDS read (draining the ring).  LDS byte addresses: stage base +
+  // row * 256 + 16 * ((4 g + q) ^ r); the second row tile is the first + 4096 (offset field).
+  const unsigned lds_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&As[0][0][0];
+  const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
+  const unsigned ar = lds_a + (unsigned)(wm0 + r) * 256u, br = lds_b + (unsigned)(wn0 + r) * 256u;
+  unsigned sl[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sl[g] = (unsigned)(((4 * g + q) ^ r) << 4);
+#define W4G_RD(XA0, XA1, XB, G)                                                                  \
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %4" \
+               : "=&v"(XA0), "=&v"(XA1), "=&v"(XB)                                                \
+               : "v"(sa + sl[G]), "v"(sb + sl[G]))
+#define W4G_WAIT(N, XA0, XA1, XB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(XA0), "+v"(XA1), "+v"(XB))
+#define W4G_MM(XA0, XA1, XB)                                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA0[s2], XB[s2], acc0, 0, 0, 0);    \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA1[s2], XB[s2], acc1, 0, 0, 0);    \
+  }
+  // The point loop over pi is NOT unrolled (36 copies of the unit body were 60 KB of code: instruction-cache misses on every unit);
+  // the transform coefficients are wave-uniform values from a constant table.  The epilogue of point p -- fold its 8 results into
+  // the row sums, and after the 6th point of a row the row sums into the outputs -- is DEFERRED into the first unit of point p + 1,
+  // between that unit's MFMA groups: ~70 (every 6th point ~200) VALU instructions that otherwise sit between the last MFMA of a
+  // point and the barrier of the next, where nothing overlaps them (a unit is only 32 MFMAs per wave at 64 input channels).
+  f32x4w pm0 = {0.f, 0.f, 0.f, 0.f}, pm1 = {0.f, 0.f, 0.f, 0.f};   // results of the previous point (zero before the first)
+  float srow_sum[8][4];
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) srow_sum[pr][c] = 0.f;
+#define W4G_UNIT_HEAD()                                                                                   \
+  if (u + 1 < NU) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6): this unit has landed, the next one's 6 DMAs may be in flight */ \
+  else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  if (u + 2 < NU) W4G_DMA(u + 2);                                                      \
+  const unsigned st = (unsigned)(u % W4G_NST);                                                            \
+  const unsigned sa = ar + st * (W4G_BM * W4G_KB * 4), sb = br + st * (W4G_BN * W4G_KB * 4);              \
+  f32x4w xa0, xa1, xb, ya0, ya1, yb;
+#define W4G_ROWSUM(PJ_)                                                                                   \
+  {                                                                                                       \
+    const float t0 = c_w4_at[PJ_][0], t1 = c_w4_at[PJ_][1], t2 = c_w4_at[PJ_][2], t3 = c_w4_at[PJ_][3];   \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                                    \
+      srow_sum[j4][0] = fmaf(t0, pm0[j4], srow_sum[j4][0]);                                               \
+      srow_sum[j4][1] = fmaf(t1, pm0[j4], srow_sum[j4][1]);                                               \
+      srow_sum[j4][2] = fmaf(t2, pm0[j4], srow_sum[j4][2]);                                               \
+      srow_sum[j4][3] = fmaf(t3, pm0[j4], srow_sum[j4][3]);                                               \
+      srow_sum[4 + j4][0] = fmaf(t0, pm1[j4], srow_sum[4 + j4][0]);                                       \
+      srow_sum[4 + j4][1] = fmaf(t1, pm1[j4], srow_sum[4 + j4][1]);                                       \
+      srow_sum[4 + j4][2] = fmaf(t2, pm1[j4], srow_sum[4 + j4][2]);                                       \
+      srow_sum[4 + j4][3] = fmaf(t3, pm1[j4], srow_sum[4 + j4][3]);                                       \
+    }                                                                                                     \
+  }
+#define W4G_COLSUM(PI_)                                                                                   \
+  {                                                                                                       \
+    const float w0 = c_w4_at[PI_][0], w1 = c_w4_at[PI_][1], w2 = c_w4_at[PI_][2], w3 = c_w4_at[PI_][3];   \
+    _Pragma("unroll") for (int pr = 0; pr < 8; ++pr)                                                      \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                     \
+        o[pr][0 + c] = fmaf(w0, srow_sum[pr][c], o[pr][0 + c]);                                           \
+        o[pr][4 + c] = fmaf(w1, srow_sum[pr][c], o[pr][4 + c]);                                           \
+        o[pr][8 + c] = fmaf(w2, srow_sum[pr][c], o[pr][8 + c]);                                           \
+        o[pr][12 + c] = fmaf(w3, srow_sum[pr][c], o[pr][12 + c]);                                         \
+        srow_sum[pr][c] = 0.f;                                                                            \
+      }                                                                                                   \
+  }
+#pragma unroll 1
+  for (int pi = 0; pi < 6; ++pi) {
+#pragma unroll
+    for (int pj = 0; pj < 6; ++pj) {
+      f32x4w acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      {   // first unit of the point, with the previous point's epilogue between its MFMA groups
+        W4G_UNIT_HEAD();
+        W4G_RD(xa0, xa1, xb, 0);
+        W4G_RD(ya0, ya1, yb, 1);
+        W4G_WAIT(3, xa0, xa1, xb);
+        W4G_MM(xa0, xa1, xb);
+        W4G_ROWSUM((pj + 5) % 6);              // previous point = (pi, pj - 1), or (pi - 1, 5)
+        W4G_RD(xa0, xa1, xb, 2);
+        W4G_WAIT(3, ya0, ya1, yb);
+        W4G_MM(ya0, ya1, yb);
+        if (pj == 0) W4G_COLSUM((pi + 5) % 6);  // the previous row of points is complete (all zeros before the first)
+        W4G_RD(ya0, ya1, yb, 3);
+        W4G_WAIT(3, xa0, xa1, xb);
+        W4G_MM(xa0, xa1, xb);
+        W4G_WAIT(0, ya0, ya1, yb);
+        W4G_MM(ya0, ya1, yb);
+        ++u;
+      }
+#pragma unroll 1
+      for (int kc = 1; kc < nkc; ++kc, ++u) {
+        W4G_UNIT_HEAD();
+        W4G_RD(xa0, xa1, xb, 0);
+        W4G_RD(ya0, ya1, yb, 1);
+        W4G_WAIT(3, xa0, xa1, xb);
+        W4G_MM(xa0, xa1, xb);
+        W4G_RD(xa0, xa1, xb, 2);
+        W4G_WAIT(3, ya0, ya1, yb);
+        W4G_MM(ya0, ya1, yb);
+        W4G_RD(ya0, ya1, yb, 3);
+        W4G_WAIT(3, xa0, xa1, xb);
+        W4G_MM(xa0, xa1, xb);
+        W4G_WAIT(0, ya0, ya1, yb);
+        W4G_MM(ya0, ya1, yb);
+      }
+      pm0 = acc0;
+      pm1 = acc1;
+    }
+  }
+  W4G_ROWSUM(5);
+  W4G_COLSUM(5);
+#undef W4G_UNIT_HEAD
+#undef W4G_ROWSUM
+#undef W4G_COLSUM
+#undef W4G_DMA
+#undef W4G_RD
+#undef W4G_WAIT
+#undef W4G_MM
+  const int co = n0 + wn0 + r;
+  const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr) {
+    const int tile = m0 + wm0 + 16 * (pr >> 2) + 4 * q + (pr & 3);
+    if (tile >= T) continue;
+    const int b = tile / (th * tw), rt = tile - b * th * tw;
+    const int ty = rt / tw, tx = rt - ty * tw;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = 4 * ty + a;
+      if (y >= H) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int x = 4 * tx + c;
+        if (x >= W) continue;
+        float* pp = out + ((int64_t)(b * H + y) * W + x) * ld_out + co;
+        float v = o[pr][a * 4 + c] + bv;
+        if (accumulate) v += *pp;
+        *pp = v;
+      }
+    }
+  }
+}
+
+// U^T[36][C][R] (k-contiguous rows for the fused kernel) from the OIHW weight; dgrad as in mopa_wino4_weight.
+MOPA_API int mopa_wino4_weight_t(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* Ut, void* stream) {
+  if (O <= 0 || I <= 0) return MOPA_ERR_ARG;
+  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, Ut, 1);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// out (NHWC, row stride ld_out) = A^T (V[p] U[p]) A (+ bias) (+= if accumulate): mopa_conv2d_igemm_batched + mopa_wino4_output in
+// one kernel.  V: [36][T][Cin] from mopa_wino4_input, Ut: [36][Cout][Cin] from mopa_wino4_weight_t.  Cin % 64 == 0, Cout % 32 == 0.
+MOPA_API int mopa_wino4_gemm_output(const float* V, const float* Ut, const float* bias, float* out, int32_t ld_out, int32_t B, int32_t H,
+                                    int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % W4G_KB || Cout % W4G_BN || ld_out < Cout) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const int64_t T = (int64_t)B * th * tw;
+  if (T * Cin * 4 >= (1ll << 32) || (int64_t)Cout * Cin * 4 >= (1ll << 32) || T >= (1 << 30)) return MOPA_ERR_ARG;
+  const int mtiles = (int)cdiv64(T, W4G_BM), ntn = Cout / W4G_BN;
+  const int64_t nblk = cdiv64(mtiles, 8) * 8 * ntn;
+  k_wino4_gemm_out<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(V, Ut, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
+                                                                    mtiles, ntn, T * Cin, Cin);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

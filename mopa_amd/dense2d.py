@@ -105,15 +105,31 @@ def relayout_cached(w, shape, O, I, KH, KW, mode):
     return _cached_weight_form(w, ("relayout", mode), build)
 
 
-def wino_weight_cached(w, dgrad: bool, F: int = 2):
-    """U[(F+2)^2][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version."""
+def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: bool = False):
+    """U[(F+2)^2][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version.
+    transposed (F = 4 only): U^T[36][C][R], the k-contiguous operand of the fused GEMM + output-transform kernel."""
     O, I = w.shape[0], w.shape[1]
 
     def build():
-        u = torch.empty((F + 2) ** 2, (O if dgrad else I), (I if dgrad else O), dtype=torch.float32, device=w.device)
-        call("mopa_wino_weight" if F == 2 else "mopa_wino4_weight", ptr(w), O, I, int(dgrad), ptr(u), stream())
+        R, C = (O if dgrad else I), (I if dgrad else O)
+        u = torch.empty((F + 2) ** 2, (C if transposed else R), (R if transposed else C), dtype=torch.float32, device=w.device)
+        name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight_t" if transposed else "mopa_wino4_weight")
+        call(name, ptr(w), O, I, int(dgrad), ptr(u), stream())
         return u
-    return _cached_weight_form(w, ("wino", F, int(dgrad)), build)
+    assert not (transposed and F != 4)
+    return _cached_weight_form(w, ("wino", F, int(dgrad), int(transposed)), build)
+
+
+# F(4x4) layers whose 36 GEMMs and output transform run as ONE kernel (mopa_wino4_gemm_output: M is never materialised): needs
+# 64-aligned input channels and at least two full rounds of its 64-tile x 32-channel blocks (2 per CU): the 304x480 layers and
+# the 128-output-channel layers at 152x240 (measured in csrc/wino2d.hip; -0.55 ms per 8-image forward + backward).  Smaller
+# grids stay on the batched GEMM + output transform.  MOPA_WINO4_FUSED=0 switches it off.
+WINO4_FUSED_MIN_BLOCKS = int(os.environ.get("MOPA_WINO4_FUSED_MIN_BLOCKS", "1024")) if os.environ.get("MOPA_WINO4_FUSED", "1") != "0" else 1 << 62
+
+
+def wino4_fused(cin, cout, B, H, W):
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    return cin % 64 == 0 and cout % 32 == 0 and ((T + 63) // 64) * (cout // 32) >= WINO4_FUSED_MIN_BLOCKS
 
 
 def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
@@ -155,12 +171,20 @@ def wino_eligible(cin, cout, k, s, p, B, H, W):
 
 
 def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2):
-    """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform."""
+    """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform.
+    U: wino_weight_cached(w, dgrad, F, transposed=(F == 4 and wino4_fused(cin, cout, B, H, W)))."""
     dev = U.device
     th, tw = (H + F - 1) // F, (W + F - 1) // F
     T, NP = B * th * tw, (F + 2) ** 2
     sfx = "" if F == 2 else "4"
     V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
+    if F == 4 and wino4_fused(cin, cout, B, H, W):
+        if tuple(U.shape) != (36, cout, cin):
+            raise RuntimeError("wino_conv: the fused F(4x4) path takes the transposed weight transform")
+        call("mopa_wino4_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
+        call("mopa_wino4_gemm_output", ptr(V), ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
+             int(accumulate), stream())
+        return V
     M = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
     call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
@@ -276,7 +300,8 @@ class ConvOp:
         """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
         F = wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "fwd")
         if F:
-            V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O, wino_weight_cached(self.w, False, F), self.b, out.p, out.ld, F=F)
+            V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O,
+                          wino_weight_cached(self.w, False, F, F == 4 and wino4_fused(self.I, self.O, x.B, x.H, x.W)), self.b, out.p, out.ld, F=F)
             same = F == wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad")   # V serves the weight gradient
             return V if keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
@@ -302,7 +327,8 @@ class ConvOp:
             return
         F = wino_tile(self.O, self.I, k, s, p, x.B, x.H, x.W, "dgrad")   # backward-data of a stride-1 3x3 conv is one, too
         if F:
-            wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I, wino_weight_cached(self.w, True, F), None, dx.p, dx.ld, acc_dx, F=F)
+            wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I,
+                      wino_weight_cached(self.w, True, F, F == 4 and wino4_fused(self.O, self.I, x.B, x.H, x.W)), None, dx.p, dx.ld, acc_dx, F=F)
             return
         wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:

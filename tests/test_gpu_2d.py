@@ -228,6 +228,37 @@ def test_net2dseg_vs_oracle_odd_size_and_dropout_semantics():
         model({"img": img, "img_indices": [idx[0], np.array([[H, 0]])]})
 
 
+@pytest.mark.parametrize("cin,cout,H,W,acc", [(64, 64, 37, 51, False), (128, 64, 21, 30, True), (64, 128, 16, 24, False)])
+def test_wino4_fused_gemm_output_vs_fp64_conv(cin, cout, H, W, acc, monkeypatch):
+    """mopa_wino4_gemm_output (the 36 GEMMs + output transform of F(4x4) in one kernel, LDS-DMA staged) through dense2d.wino_conv,
+    forced on for small shapes: against an fp64 conv3x3 (padding 1) and against the batched-GEMM + output-transform path; odd
+    sizes (ragged tiles, a last row block beyond T), bias, and accumulation into an existing output."""
+    import torch.nn.functional as F
+    from mopa_amd import dense2d
+    from mopa_amd._lib import call, ptr, stream
+    rng = np.random.Generator(np.random.PCG64(400 + cin + W))
+    B = 2
+    x = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+    prev = torch.from_numpy(rng.standard_normal((B * H * W, cout)).astype(np.float32)).cuda()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), None if acc else bias.double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    if acc:
+        ref = ref + prev.double().cpu()
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(dense2d, "WINO4_FUSED_MIN_BLOCKS", 0 if fused else 1 << 62)
+        assert dense2d.wino4_fused(cin, cout, B, H, W) == fused
+        U = torch.empty(36, cout, cin, device="cuda") if fused else torch.empty(36, cin, cout, device="cuda")
+        call("mopa_wino4_weight_t" if fused else "mopa_wino4_weight", ptr(w), cout, cin, 0, ptr(U), stream())
+        out = prev.clone() if acc else torch.full((B * H * W, cout), float("nan"), device="cuda")
+        dense2d.wino_conv(ptr(x), cin, B, H, W, cin, cout, U, None if acc else bias, ptr(out), cout, accumulate=acc, F=4)
+        _close(out, ref.float().numpy(), rtol=1e-4, atol=3e-5)
+        outs.append(out)
+    _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
+
+
 def test_stem_dgrad_image_kernel_vs_torch():
     """mopa_stem_dgrad_image alone: backward-data of the 7x7 / stride 1 / padding 3 stem over the image window of the /16-padded
     frame, against fp64 autograd of F.conv2d on the zero-padded image (resnet34_unet.py:133-144)."""
