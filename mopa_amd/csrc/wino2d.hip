@@ -9,6 +9,7 @@
 // layers stay on the direct kernel: there the V / M traffic (4x the activations, written and read) costs more than the
 // saved FMAs.  Replaces cuDNN's choice of algorithm behind mopa/models/resnet34_unet.py:97-110; oracle: oracle/net2d.py.
 #include "common.h"
+#include <stdio.h>
 
 // U[p][r][c], p = 4*i + j.  dgrad = 0: r = input channel, c = output channel, g = w[c][r][.][.] (OIHW);
 //                           dgrad = 1: r = output channel, c = input channel, g = w[r][c] rotated by 180 degrees.
@@ -455,13 +456,15 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
 // operands (MFMA step (g, s) takes k = 16 g + 4 q + s from lane group q) so one b128 LDS read feeds 4 MFMAs.
 // Blocks are numbered so that the channel groups of one tile range run on the same XCD back to back (they share V through L2).
 // Measured (profiles/bench_wino_fused.py, B = 8, whole conv incl. the input transform, batched GEMM + output transform -> fused):
-//   64 -> 128 at 152x240  311 -> 241 us     128 -> 64 at 304x480  1087 -> 950 us     64 -> 128 at 304x480  1150 -> 808 us
-//   64 -> 64 at 152x240   181 -> 185        128 -> 64 at 152x240   287 -> 350        128^2 at 76x120 106 -> 140, deeper: worse
-// A lone block needs ~1.4 us per unit (point x 64-channel chunk) of which 0.47 us are its 32 MFMAs per wave (one wave per SIMD
-// issues them at the full rate: profiles/micro/mfma_rate.hip); DMA latency (~2 us, two units ahead) and the barrier-to-first-MFMA
-// chain fill the rest, and with 72 KB of LDS only two blocks share a CU.  So the kernel wins where there are at least two full
-// rounds of blocks (>= 1024: the 304x480 layers and the 128-output-channel layers at 152x240) and loses to the batched GEMM on
-// grids of ~570 blocks (one round plus a 58-block tail) and on the short deep levels: dense2d.wino4_fused picks by block count.
+//   64 -> 128 at 304x480  1175 -> 781 us    128 -> 64 at 304x480  1111 -> 927     64 -> 128 at 152x240  316 -> 234
+//   64 -> 64 at 152x240    189 -> 175       128 -> 64 at 152x240   291 -> 328     128^2 at 76x120  109 -> 134, deeper: worse
+// In-kernel cycle counters (-DW4G_PROFILE) per unit (point x 64-channel chunk) of a lone block: the 32 MFMAs per wave ~600-680,
+// fragment-read waits + epilogue + drain ~750-900, DMA issue 340-830 (six LDS-DMA instructions per wave; it grows with the load on
+// the memory pipeline), barrier + vmcnt < 200: the DMA's latency (~2 us) is hidden by the two units of lookahead, what is left is
+// issue-side.  One wave per SIMD issues v_mfma_f32_16x16x4_f32 at the full rate (profiles/micro/mfma_rate.hip: 144-155 TFLOP/s),
+// so the remaining headroom is in overlapping those segments, and with 72 KB of LDS only two blocks share a CU.  The kernel wins
+// on grids of at least two full rounds of blocks (>= 1024) and, at 64 input channels, from one round on; it loses to the batched
+// GEMM on ~570-block grids with more K per point (a 58-block tail round) and on the short deep levels: dense2d.wino4_fused.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 // A^T of F(4x4,3x3), transposed: c_w4_at[j][c] = AT[c][j]
 __constant__ float c_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
@@ -480,10 +483,15 @@ __constant__ float c_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, 
 __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restrict__ V, const float* __restrict__ Ut,
                                                             const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                             int B, int H, int W, int th, int tw, int Cin, int Cout, int accumulate,
-                                                            int mtiles, int ntn, int64_t a_ps, int ldv) {
+                                                            int mtiles, int ntn, int64_t a_ps, int ldv
+#ifdef W4G_PROFILE
+                                                            , long long* prof
+#endif
+                                                            ) {
   __shared__ __attribute__((aligned(1024))) float As[W4G_NST][W4G_BM][W4G_KB];
   __shared__ __attribute__((aligned(1024))) float Bs[W4G_NST][W4G_BN][W4G_KB];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the DMA's LDS targets (M0) become scalar arithmetic
   const int bid = blockIdx.x;
   const int grp = bid / (8 * ntn), within = bid - grp * 8 * ntn;
   const int n_idx = within >> 3, m_idx = grp * 8 + (within & 7);
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
   const int nkc = Cin / W4G_KB;
   const int NU = 36 * nkc;
   // DMA assignment: wave wv, instruction j moves rows 4 (4 j + wv) .. + 3; lane = (row in group: lane >> 4, slot: lane & 15).
-  // Byte offsets inside one transform point stay below 2^32 (launcher).
+  // Byte offsets inside one transform point stay below 2^32 (launcher): uniform 64-bit base + 32-bit lane offset.
   unsigned a_off[4], b_off[2];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -506,18 +514,29 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
     const int row = 4 * (4 * j + wv) + (lane >> 4);
     b_off[j] = (unsigned)(((int64_t)(n0 + row) * Cin + (((lane & 15) ^ (row & 15)) << 2)) * 4);
   }
-  const int64_t b_ps = (int64_t)Cout * Cin;
-#define W4G_DMA(U_)                                                                                                  \
-  {                                                                                                                  \
-    const int p_ = (U_) / nkc, kc_ = (U_) - p_ * nkc, st_ = (U_) % W4G_NST;                                          \
-    const char* ap_ = reinterpret_cast<const char*>(V + (int64_t)p_ * a_ps + kc_ * W4G_KB);                         \
-    const char* bp_ = reinterpret_cast<const char*>(Ut + (int64_t)p_ * b_ps + kc_ * W4G_KB);                        \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                 \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap_ + a_off[j_]),             \
-                                       (__attribute__((address_space(3))) void*)(&As[st_][4 * (4 * j_ + wv)][0]), 16, 0, 0); \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                 \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp_ + b_off[j_]),             \
-                                       (__attribute__((address_space(3))) void*)(&Bs[st_][4 * (4 * j_ + wv)][0]), 16, 0, 0); \
+  // the unit the next DMA fetches: running pointers (no division per unit), its ring slot, and how many are left
+  typedef const __attribute__((address_space(1))) char* gptr_t;
+  gptr_t dma_a = (gptr_t)V, dma_b = (gptr_t)Ut;
+  const int64_t a_step = (int64_t)W4G_KB * 4, a_wrap = (a_ps - (int64_t)(nkc - 1) * W4G_KB) * 4;
+  const int64_t b_wrap = ((int64_t)Cout * Cin - (int64_t)(nkc - 1) * W4G_KB) * 4;
+  int dma_kc = 0, dma_left = NU;
+  unsigned dma_st = 0;
+  const unsigned lds_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&As[0][0][0];
+  const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
+  const unsigned dma_la = lds_a + (unsigned)wv * 1024u, dma_lb = lds_b + (unsigned)wv * 1024u;   // + j * 4096 + slot * stage bytes
+#define W4G_DMA()                                                                                                     \
+  if (dma_left > 0) {                                                                                                 \
+    const unsigned la_ = dma_la + dma_st * (W4G_BM * W4G_KB * 4), lb_ = dma_lb + dma_st * (W4G_BN * W4G_KB * 4);      \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_a + a_off[j_]),            \
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)(la_ + j_ * 4096u), 16, 0, 0); \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                  \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_b + b_off[j_]),            \
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)(lb_ + j_ * 4096u), 16, 0, 0); \
+    --dma_left;                                                                                                       \
+    dma_st = dma_st == W4G_NST - 1 ? 0u : dma_st + 1u;                                                                \
+    if (++dma_kc == nkc) { dma_kc = 0; dma_a += a_wrap; dma_b += b_wrap; }                                            \
+    else { dma_a += a_step; dma_b += a_step; }                                                                        \
   }
   float o[8][16];
 #pragma unroll
@@ -525,14 +544,13 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[pr][e] = 0.f;
 
-  W4G_DMA(0);
-  W4G_DMA(1);
+  W4G_DMA();
+  W4G_DMA();
   int u = 0;
+  unsigned st = 0;   // ring slot of unit u
   // Fragment reads are inline asm: the compiler cannot tell that the slot a DMA is filling is not the slot being read and would
   // put `s_waitcnt vmcnt(0)` in front of every compiler-visible LDS read (draining the ring).  LDS byte addresses: stage base +
   // row * 256 + 16 * ((4 g + q) ^ r); the second row tile is the first + 4096 (offset field).
-  const unsigned lds_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&As[0][0][0];
-  const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
   const unsigned ar = lds_a + (unsigned)(wm0 + r) * 256u, br = lds_b + (unsigned)(wn0 + r) * 256u;
   unsigned sl[4];
 #pragma unroll
@@ -542,42 +560,54 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
                : "=&v"(XA0), "=&v"(XA1), "=&v"(XB)                                                \
                : "v"(sa + sl[G]), "v"(sb + sl[G]))
 #define W4G_WAIT(N, XA0, XA1, XB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(XA0), "+v"(XA1), "+v"(XB))
-#define W4G_MM(XA0, XA1, XB)                                                        \
-  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA0[s2], XB[s2], acc0, 0, 0, 0);    \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA1[s2], XB[s2], acc1, 0, 0, 0);    \
+#define W4G_MM(C0, C1, XA0, XA1, XB)                                            \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                            \
+    C0 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA0[s2], XB[s2], C0, 0, 0, 0);    \
+    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA1[s2], XB[s2], C1, 0, 0, 0);    \
   }
   // The point loop over pi is NOT unrolled (36 copies of the unit body were 60 KB of code: instruction-cache misses on every unit);
-  // the transform coefficients are wave-uniform values from a constant table.  The epilogue of point p -- fold its 8 results into
-  // the row sums, and after the 6th point of a row the row sums into the outputs -- is DEFERRED into the first unit of point p + 1,
-  // between that unit's MFMA groups: ~70 (every 6th point ~200) VALU instructions that otherwise sit between the last MFMA of a
-  // point and the barrier of the next, where nothing overlaps them (a unit is only 32 MFMAs per wave at 64 input channels).
-  f32x4w pm0 = {0.f, 0.f, 0.f, 0.f}, pm1 = {0.f, 0.f, 0.f, 0.f};   // results of the previous point (zero before the first)
+  // the transform coefficients are wave-uniform values from a constant table.  Two accumulator sets alternate between points:
+  // while point p's MFMAs still drain, the wave is already through the wait / barrier / DMA issue / fragment reads of the next
+  // unit, and the epilogue of point p -- fold its 8 results into the row sums, after the 6th point of a row the row sums into the
+  // outputs -- runs between the MFMA groups of point p + 1's first unit, out of the OTHER set (no copy, no drain).  In-kernel
+  // cycle counters of the first version, per unit of 32 MFMAs (~660): issue of the 6 DMAs ~500-800 (per-unit division, 64-bit
+  // VALU address adds, readfirstlane for M0: now running pointers and scalar LDS targets), drain + epilogue ~800-1000.
+  f32x4w eA0 = {0.f, 0.f, 0.f, 0.f}, eA1 = eA0, eB0 = eA0, eB1 = eA0;
   float srow_sum[8][4];
 #pragma unroll
   for (int pr = 0; pr < 8; ++pr)
 #pragma unroll
     for (int c = 0; c < 4; ++c) srow_sum[pr][c] = 0.f;
+#ifdef W4G_PROFILE
+  long long pt[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define W4G_T(K_) { const long long n_ = __builtin_readcyclecounter(); pt[K_] += n_ - tprev; tprev = n_; }
+#else
+#define W4G_T(K_)
+#endif
 #define W4G_UNIT_HEAD()                                                                                   \
+  W4G_T(0) /* loop tail since the last MFMA issue */                                                      \
   if (u + 1 < NU) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6): this unit has landed, the next one's 6 DMAs may be in flight */ \
   else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                \
+  W4G_T(1)                                                                                                \
   __builtin_amdgcn_s_barrier();                                                                           \
-  if (u + 2 < NU) W4G_DMA(u + 2);                                                      \
-  const unsigned st = (unsigned)(u % W4G_NST);                                                            \
+  W4G_T(2)                                                                                                \
+  W4G_DMA();                                                                                              \
+  W4G_T(3)                                                                                                \
   const unsigned sa = ar + st * (W4G_BM * W4G_KB * 4), sb = br + st * (W4G_BN * W4G_KB * 4);              \
+  st = st == W4G_NST - 1 ? 0u : st + 1u;                                                                  \
   f32x4w xa0, xa1, xb, ya0, ya1, yb;
-#define W4G_ROWSUM(PJ_)                                                                                   \
+#define W4G_ROWSUM(PJ_, P0, P1)                                                                           \
   {                                                                                                       \
     const float t0 = c_w4_at[PJ_][0], t1 = c_w4_at[PJ_][1], t2 = c_w4_at[PJ_][2], t3 = c_w4_at[PJ_][3];   \
     _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                                    \
-      srow_sum[j4][0] = fmaf(t0, pm0[j4], srow_sum[j4][0]);                                               \
-      srow_sum[j4][1] = fmaf(t1, pm0[j4], srow_sum[j4][1]);                                               \
-      srow_sum[j4][2] = fmaf(t2, pm0[j4], srow_sum[j4][2]);                                               \
-      srow_sum[j4][3] = fmaf(t3, pm0[j4], srow_sum[j4][3]);                                               \
-      srow_sum[4 + j4][0] = fmaf(t0, pm1[j4], srow_sum[4 + j4][0]);                                       \
-      srow_sum[4 + j4][1] = fmaf(t1, pm1[j4], srow_sum[4 + j4][1]);                                       \
-      srow_sum[4 + j4][2] = fmaf(t2, pm1[j4], srow_sum[4 + j4][2]);                                       \
-      srow_sum[4 + j4][3] = fmaf(t3, pm1[j4], srow_sum[4 + j4][3]);                                       \
+      srow_sum[j4][0] = fmaf(t0, P0[j4], srow_sum[j4][0]);                                                \
+      srow_sum[j4][1] = fmaf(t1, P0[j4], srow_sum[j4][1]);                                                \
+      srow_sum[j4][2] = fmaf(t2, P0[j4], srow_sum[j4][2]);                                                \
+      srow_sum[j4][3] = fmaf(t3, P0[j4], srow_sum[j4][3]);                                                \
+      srow_sum[4 + j4][0] = fmaf(t0, P1[j4], srow_sum[4 + j4][0]);                                        \
+      srow_sum[4 + j4][1] = fmaf(t1, P1[j4], srow_sum[4 + j4][1]);                                        \
+      srow_sum[4 + j4][2] = fmaf(t2, P1[j4], srow_sum[4 + j4][2]);                                        \
+      srow_sum[4 + j4][3] = fmaf(t3, P1[j4], srow_sum[4 + j4][3]);                                        \
     }                                                                                                     \
   }
 #define W4G_COLSUM(PI_)                                                                                   \
@@ -592,54 +622,65 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
         srow_sum[pr][c] = 0.f;                                                                            \
       }                                                                                                   \
   }
+// one transform point into the set (C0, C1); (P0, P1) = the other set = the previous point's results
+#define W4G_POINT(C0, C1, P0, P1)                                                                         \
+  {                                                                                                       \
+    {   /* first unit of the point, with the previous point's epilogue between its MFMA groups */        \
+      W4G_UNIT_HEAD();                                                                                    \
+      W4G_RD(xa0, xa1, xb, 0);                                                                            \
+      W4G_RD(ya0, ya1, yb, 1);                                                                            \
+      W4G_ROWSUM((pj + 5) % 6, P0, P1);        /* previous point = (pi, pj - 1), or (pi - 1, 5) */        \
+      C0 = (f32x4w){0.f, 0.f, 0.f, 0.f};                                                                  \
+      C1 = (f32x4w){0.f, 0.f, 0.f, 0.f};                                                                  \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_T(4)                                                                                            \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_RD(xa0, xa1, xb, 2);                                                                            \
+      W4G_WAIT(3, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+      if (pj == 0) W4G_COLSUM((pi + 5) % 6);   /* the previous row of points is complete (zeros before the first) */ \
+      W4G_RD(ya0, ya1, yb, 3);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_WAIT(0, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+      W4G_T(5)                                                                                            \
+      ++u;                                                                                                \
+    }                                                                                                     \
+    _Pragma("unroll 1") for (int kc = 1; kc < nkc; ++kc, ++u) {                                           \
+      W4G_UNIT_HEAD();                                                                                    \
+      W4G_RD(xa0, xa1, xb, 0);                                                                            \
+      W4G_RD(ya0, ya1, yb, 1);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_RD(xa0, xa1, xb, 2);                                                                            \
+      W4G_WAIT(3, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+      W4G_RD(ya0, ya1, yb, 3);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_WAIT(0, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+    }                                                                                                     \
+  }
 #pragma unroll 1
   for (int pi = 0; pi < 6; ++pi) {
 #pragma unroll
     for (int pj = 0; pj < 6; ++pj) {
-      f32x4w acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      {   // first unit of the point, with the previous point's epilogue between its MFMA groups
-        W4G_UNIT_HEAD();
-        W4G_RD(xa0, xa1, xb, 0);
-        W4G_RD(ya0, ya1, yb, 1);
-        W4G_WAIT(3, xa0, xa1, xb);
-        W4G_MM(xa0, xa1, xb);
-        W4G_ROWSUM((pj + 5) % 6);              // previous point = (pi, pj - 1), or (pi - 1, 5)
-        W4G_RD(xa0, xa1, xb, 2);
-        W4G_WAIT(3, ya0, ya1, yb);
-        W4G_MM(ya0, ya1, yb);
-        if (pj == 0) W4G_COLSUM((pi + 5) % 6);  // the previous row of points is complete (all zeros before the first)
-        W4G_RD(ya0, ya1, yb, 3);
-        W4G_WAIT(3, xa0, xa1, xb);
-        W4G_MM(xa0, xa1, xb);
-        W4G_WAIT(0, ya0, ya1, yb);
-        W4G_MM(ya0, ya1, yb);
-        ++u;
-      }
-#pragma unroll 1
-      for (int kc = 1; kc < nkc; ++kc, ++u) {
-        W4G_UNIT_HEAD();
-        W4G_RD(xa0, xa1, xb, 0);
-        W4G_RD(ya0, ya1, yb, 1);
-        W4G_WAIT(3, xa0, xa1, xb);
-        W4G_MM(xa0, xa1, xb);
-        W4G_RD(xa0, xa1, xb, 2);
-        W4G_WAIT(3, ya0, ya1, yb);
-        W4G_MM(ya0, ya1, yb);
-        W4G_RD(ya0, ya1, yb, 3);
-        W4G_WAIT(3, xa0, xa1, xb);
-        W4G_MM(xa0, xa1, xb);
-        W4G_WAIT(0, ya0, ya1, yb);
-        W4G_MM(ya0, ya1, yb);
-      }
-      pm0 = acc0;
-      pm1 = acc1;
+      if (pj % 2 == 0) W4G_POINT(eA0, eA1, eB0, eB1)
+      else W4G_POINT(eB0, eB1, eA0, eA1)
     }
   }
-  W4G_ROWSUM(5);
+  W4G_ROWSUM(5, eB0, eB1);   // point (5, 5) went into set B
   W4G_COLSUM(5);
 #undef W4G_UNIT_HEAD
+#ifdef W4G_PROFILE
+  if (blockIdx.x == 0 && tid == 0)
+    for (int k = 0; k < 6; ++k) prof[k] = pt[k];
+#endif
 #undef W4G_ROWSUM
 #undef W4G_COLSUM
+#undef W4G_POINT
 #undef W4G_DMA
 #undef W4G_RD
 #undef W4G_WAIT
@@ -687,8 +728,18 @@ MOPA_API int mopa_wino4_gemm_output(const float* V, const float* Ut, const float
   if (T * Cin * 4 >= (1ll << 32) || (int64_t)Cout * Cin * 4 >= (1ll << 32) || T >= (1 << 30)) return MOPA_ERR_ARG;
   const int mtiles = (int)cdiv64(T, W4G_BM), ntn = Cout / W4G_BN;
   const int64_t nblk = cdiv64(mtiles, 8) * 8 * ntn;
+#ifdef W4G_PROFILE
+  static long long* prof = nullptr;
+  if (!prof) hipMallocManaged(&prof, 64);
+  k_wino4_gemm_out<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(V, Ut, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
+                                                                    mtiles, ntn, T * Cin, Cin, prof);
+  hipStreamSynchronize((hipStream_t)stream);
+  printf("[w4g profile] block 0 wave 0, cycles per unit: tail %.0f | vmcnt %.0f | barrier %.0f | dma issue %.0f | lds first wait %.0f | mfma groups %.0f  (units %d)\n",
+         prof[0] / (36.0 * Cin / 64), prof[1] / (36.0 * Cin / 64), prof[2] / (36.0 * Cin / 64), prof[3] / (36.0 * Cin / 64), prof[4] / (36.0 * Cin / 64), prof[5] / (36.0 * Cin / 64), 36 * Cin / 64);
+#else
   k_wino4_gemm_out<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(V, Ut, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
                                                                     mtiles, ntn, T * Cin, Cin);
+#endif
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

@@ -141,7 +141,8 @@ def test_conv_algorithm_choice(monkeypatch):
     # the fused GEMM + output-transform kernel: 64-aligned input channels and >= 1024 of its 64-tile x 32-channel blocks
     monkeypatch.setattr(dense2d, "WINO4_FUSED_MIN_BLOCKS", 1024)
     assert dense2d.wino4_fused(128, 64, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 152, 240)
-    assert not dense2d.wino4_fused(64, 64, B, 152, 240) and not dense2d.wino4_fused(512, 512, B, 19, 30) and not dense2d.wino4_fused(48, 128, B, 304, 480)
+    assert dense2d.wino4_fused(64, 64, B, 152, 240) and not dense2d.wino4_fused(128, 64, B, 152, 240)   # one K chunk per point: one round suffices
+    assert not dense2d.wino4_fused(64, 64, B, 76, 120) and not dense2d.wino4_fused(512, 512, B, 19, 30) and not dense2d.wino4_fused(48, 128, B, 304, 480)
     monkeypatch.setenv("MOPA_WINOGRAD", "0")
     assert t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 0
 
