@@ -467,7 +467,6 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
 // GEMM on ~570-block grids with more K per point (a 58-block tail round) and on the short deep levels: dense2d.wino4_fused.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 // A^T of F(4x4,3x3), transposed: c_w4_at[j][c] = AT[c][j]
-static constexpr float k_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
 __constant__ float c_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
 #define W4G_BM 64
 #define W4G_BN 32
@@ -574,6 +573,11 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
   // cycle counters of the first version, per unit of 32 MFMAs (~660): issue of the 6 DMAs ~500-800 (per-unit division, 64-bit
   // VALU address adds, readfirstlane for M0: now running pointers and scalar LDS targets), drain + epilogue ~800-1000.
   f32x4w eA0 = {0.f, 0.f, 0.f, 0.f}, eA1 = eA0, eB0 = eA0, eB1 = eA0;
+  float srow_sum[8][4];
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) srow_sum[pr][c] = 0.f;
 #ifdef W4G_PROFILE
   long long pt[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define W4G_T(K_) { const long long n_ = __builtin_readcyclecounter(); pt[K_] += n_ - tprev; tprev = n_; }
@@ -591,62 +595,72 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
   W4G_T(3)                                                                                                \
   const unsigned sa = ar + st * (W4G_BM * W4G_KB * 4), sb = br + st * (W4G_BN * W4G_KB * 4);              \
   st = st == W4G_NST - 1 ? 0u : st + 1u;                                                                  \
-  f32x4w xa0, xa1, xb, ya0, ya1, yb, za0, za1, zb;
-// fold the results (P0, P1) of point (PI_, PJ_) into the outputs: o[pair][a][c] += AT[a][PI_] * AT[c][PJ_] * m   (PJ_ is a
-// compile-time constant: its zero coefficients drop out; PI_ is wave-uniform)
-#define W4G_FOLD(PI_, PJ_, P0, P1)                                                                        \
+  f32x4w xa0, xa1, xb, ya0, ya1, yb;
+#define W4G_ROWSUM(PJ_, P0, P1)                                                                           \
   {                                                                                                       \
-    const float w0 = c_w4_at[PI_][0], w1 = c_w4_at[PI_][1], w2 = c_w4_at[PI_][2], w3 = c_w4_at[PI_][3];   \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                       \
-      const float tc = k_w4_at[PJ_][c];                                                                   \
-      if (tc != 0.f) {                                                                                    \
-        const float f0 = w0 * tc, f1 = w1 * tc, f2 = w2 * tc, f3 = w3 * tc;                               \
-        _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                                \
-          o[j4][0 + c] = fmaf(f0, P0[j4], o[j4][0 + c]);                                                  \
-          o[j4][4 + c] = fmaf(f1, P0[j4], o[j4][4 + c]);                                                  \
-          o[j4][8 + c] = fmaf(f2, P0[j4], o[j4][8 + c]);                                                  \
-          o[j4][12 + c] = fmaf(f3, P0[j4], o[j4][12 + c]);                                                \
-          o[4 + j4][0 + c] = fmaf(f0, P1[j4], o[4 + j4][0 + c]);                                          \
-          o[4 + j4][4 + c] = fmaf(f1, P1[j4], o[4 + j4][4 + c]);                                          \
-          o[4 + j4][8 + c] = fmaf(f2, P1[j4], o[4 + j4][8 + c]);                                          \
-          o[4 + j4][12 + c] = fmaf(f3, P1[j4], o[4 + j4][12 + c]);                                        \
-        }                                                                                                 \
-      }                                                                                                   \
+    const float t0 = c_w4_at[PJ_][0], t1 = c_w4_at[PJ_][1], t2 = c_w4_at[PJ_][2], t3 = c_w4_at[PJ_][3];   \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                                    \
+      srow_sum[j4][0] = fmaf(t0, P0[j4], srow_sum[j4][0]);                                                \
+      srow_sum[j4][1] = fmaf(t1, P0[j4], srow_sum[j4][1]);                                                \
+      srow_sum[j4][2] = fmaf(t2, P0[j4], srow_sum[j4][2]);                                                \
+      srow_sum[j4][3] = fmaf(t3, P0[j4], srow_sum[j4][3]);                                                \
+      srow_sum[4 + j4][0] = fmaf(t0, P1[j4], srow_sum[4 + j4][0]);                                        \
+      srow_sum[4 + j4][1] = fmaf(t1, P1[j4], srow_sum[4 + j4][1]);                                        \
+      srow_sum[4 + j4][2] = fmaf(t2, P1[j4], srow_sum[4 + j4][2]);                                        \
+      srow_sum[4 + j4][3] = fmaf(t3, P1[j4], srow_sum[4 + j4][3]);                                        \
     }                                                                                                     \
   }
+#define W4G_COLSUM(PI_)                                                                                   \
+  {                                                                                                       \
+    const float w0 = c_w4_at[PI_][0], w1 = c_w4_at[PI_][1], w2 = c_w4_at[PI_][2], w3 = c_w4_at[PI_][3];   \
+    _Pragma("unroll") for (int pr = 0; pr < 8; ++pr)                                                      \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                     \
+        o[pr][0 + c] = fmaf(w0, srow_sum[pr][c], o[pr][0 + c]);                                           \
+        o[pr][4 + c] = fmaf(w1, srow_sum[pr][c], o[pr][4 + c]);                                           \
+        o[pr][8 + c] = fmaf(w2, srow_sum[pr][c], o[pr][8 + c]);                                           \
+        o[pr][12 + c] = fmaf(w3, srow_sum[pr][c], o[pr][12 + c]);                                         \
+        srow_sum[pr][c] = 0.f;                                                                            \
+      }                                                                                                   \
+  }
 // one transform point into the set (C0, C1); (P0, P1) = the other set = the previous point's results
-#define W4G_UNIT_BODY(C0, C1)                                                                             \
-  W4G_RD(xa0, xa1, xb, 0);                                                                                \
-  W4G_RD(ya0, ya1, yb, 1);                                                                                \
-  W4G_RD(za0, za1, zb, 2);
-#define W4G_UNIT_MMS(C0, C1, MID_)                                                                        \
-  W4G_WAIT(6, xa0, xa1, xb);                                                                              \
-  W4G_T(4)                                                                                                \
-  W4G_MM(C0, C1, xa0, xa1, xb);                                                                           \
-  W4G_RD(xa0, xa1, xb, 3);                                                                                \
-  MID_                                                                                                    \
-  W4G_WAIT(6, ya0, ya1, yb);                                                                              \
-  W4G_MM(C0, C1, ya0, ya1, yb);                                                                           \
-  W4G_WAIT(3, za0, za1, zb);                                                                              \
-  W4G_MM(C0, C1, za0, za1, zb);                                                                           \
-  W4G_WAIT(0, xa0, xa1, xb);                                                                              \
-  W4G_MM(C0, C1, xa0, xa1, xb);
 #define W4G_POINT(C0, C1, P0, P1)                                                                         \
   {                                                                                                       \
-    {   /* first unit of the point, with the previous point's fold between its MFMA groups */           \
-      const int pip_ = pj == 0 ? (pi == 0 ? 5 : pi - 1) : pi;   /* previous point = (pi, pj - 1), or (pi - 1, 5) */ \
+    {   /* first unit of the point, with the previous point's epilogue between its MFMA groups */        \
       W4G_UNIT_HEAD();                                                                                    \
-      W4G_UNIT_BODY(C0, C1)                                                                               \
+      W4G_RD(xa0, xa1, xb, 0);                                                                            \
+      W4G_RD(ya0, ya1, yb, 1);                                                                            \
+      W4G_ROWSUM((pj + 5) % 6, P0, P1);        /* previous point = (pi, pj - 1), or (pi - 1, 5) */        \
       C0 = (f32x4w){0.f, 0.f, 0.f, 0.f};                                                                  \
       C1 = (f32x4w){0.f, 0.f, 0.f, 0.f};                                                                  \
-      W4G_UNIT_MMS(C0, C1, W4G_FOLD(pip_, (pj + 5) % 6, P0, P1))                                          \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_T(4)                                                                                            \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_RD(xa0, xa1, xb, 2);                                                                            \
+      W4G_WAIT(3, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+      if (pj == 0) W4G_COLSUM((pi + 5) % 6);   /* the previous row of points is complete (zeros before the first) */ \
+      W4G_RD(ya0, ya1, yb, 3);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_WAIT(0, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
       W4G_T(5)                                                                                            \
       ++u;                                                                                                \
     }                                                                                                     \
     _Pragma("unroll 1") for (int kc = 1; kc < nkc; ++kc, ++u) {                                           \
       W4G_UNIT_HEAD();                                                                                    \
-      W4G_UNIT_BODY(C0, C1)                                                                               \
-      W4G_UNIT_MMS(C0, C1, )                                                                              \
+      W4G_RD(xa0, xa1, xb, 0);                                                                            \
+      W4G_RD(ya0, ya1, yb, 1);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_RD(xa0, xa1, xb, 2);                                                                            \
+      W4G_WAIT(3, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
+      W4G_RD(ya0, ya1, yb, 3);                                                                            \
+      W4G_WAIT(3, xa0, xa1, xb);                                                                          \
+      W4G_MM(C0, C1, xa0, xa1, xb);                                                                       \
+      W4G_WAIT(0, ya0, ya1, yb);                                                                          \
+      W4G_MM(C0, C1, ya0, ya1, yb);                                                                       \
     }                                                                                                     \
   }
 #pragma unroll 1
@@ -657,16 +671,16 @@ __global__ __launch_bounds__(256, 2) void k_wino4_gemm_out(const float* __restri
       else W4G_POINT(eB0, eB1, eA0, eA1)
     }
   }
-  W4G_FOLD(5, 5, eB0, eB1);   // point (5, 5) went into set B
+  W4G_ROWSUM(5, eB0, eB1);   // point (5, 5) went into set B
+  W4G_COLSUM(5);
 #undef W4G_UNIT_HEAD
 #ifdef W4G_PROFILE
   if (blockIdx.x == 0 && tid == 0)
     for (int k = 0; k < 6; ++k) prof[k] = pt[k];
 #endif
-#undef W4G_FOLD
+#undef W4G_ROWSUM
+#undef W4G_COLSUM
 #undef W4G_POINT
-#undef W4G_UNIT_BODY
-#undef W4G_UNIT_MMS
 #undef W4G_DMA
 #undef W4G_RD
 #undef W4G_WAIT
