@@ -142,6 +142,21 @@ class Conv2dTimer:
             timer.records.append((s, e, 4 * nbatch * (M * cin + M * cout + cin * cout), 2 * nbatch * M * cout * cin))
 
         dense2d.igemm_batched = wrapped_b
+        inner_call = dense2d.call
+
+        def wrapped_call(name, *a):   # the fused F(4x4) GEMM + output-transform kernel belongs to the same family
+            if not timer.enabled or name != "mopa_wino4_gemm_output":
+                return inner_call(name, *a)
+            B, H, W, cin, cout = a[5], a[6], a[7], a[8], a[9]
+            T = B * ((H + 3) // 4) * ((W + 3) // 4)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = inner_call(name, *a)
+            e.record()
+            timer.records.append((s, e, 4 * (36 * T * cin + B * H * W * cout + 36 * cin * cout), 2 * 36 * T * cin * cout))
+            return r
+
+        dense2d.call = wrapped_call
 
     summary = ConvTimer.summary
 
@@ -636,12 +651,15 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r2_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if joint and os.path.exists(tpath):                                  # of this same command (profiles/traffic.py)
-            traffic = json.load(open(tpath)).get("k_conv2d_igemm_mfma", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out") if k in tj]
+            if fam:
+                traffic = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r2_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm_mfma (f32-operand MFMA, exact fp32; conv fwd + bwd-data + convT + the Winograd layers' batched GEMMs)",
+                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
