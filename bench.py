@@ -456,8 +456,20 @@ def main():
         elif mopa:
             l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
+        if reorder and mopa and not supervised:
+            # MoPA target half: the VGI inside loss_3d() reads a few numbers back per scan (cell counts for numpy's RNG draws) --
+            # each read waits for the side stream.  The 2D backward is enqueued FIRST (the losses are independent graphs), so the
+            # main stream has ~12 ms of work while the host sits in those round trips; the side stream is ordered behind the 2D
+            # losses only (event), not behind that backward.
+            ready = torch.cuda.Event()
+            ready.record()
+            l2.backward()
+            with dual.on_side(o2["seg_logit"], after=ready):
+                l3 = loss_3d()
+            l3.backward()
+            return l2.detach(), l3.detach()
         if reorder:
-            # the 3D losses (and the VGI pass) on the side stream: their backward -- the whole 3D backward -- is then queued there
+            # the 3D losses on the side stream: their backward -- the whole 3D backward -- is then queued there
             # and runs beside the 2D backward without the host having to enqueue it first while the main stream waits
             with dual.on_side(o2["seg_logit"]):
                 l3 = loss_3d()

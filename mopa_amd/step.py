@@ -55,12 +55,18 @@ class DualStream:
         self.side = torch.cuda.Stream(device=self.device, priority=prio)
         self.order_2d_first = order_2d_first
 
-    def on_side(self, *tensors_from_main):
+    def on_side(self, *tensors_from_main, after=None):
         """Context: run what follows (e.g. the 3D losses, so that their backward -- and with it the whole 3D backward -- is queued
         on the side stream and does not wait behind the 2D backward) on the side stream, ordered after everything queued on the
-        current stream so far; `tensors_from_main` are recorded as used by the side stream."""
+        current stream so far -- or, with ``after`` (an event recorded on the current stream), only after that point: work
+        enqueued on the current stream behind the event (e.g. the 2D backward) then runs beside the block instead of in front of
+        it, which matters when the block holds host round trips (the VGI of the MoPA iteration).  `tensors_from_main` are
+        recorded as used by the side stream."""
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(main)
         for t in tensors_from_main:
             if torch.is_tensor(t):
                 t.record_stream(self.side)

@@ -188,8 +188,10 @@ def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, ob
         cat_label = torch.cat([lab, torch.from_numpy(np.concatenate(new_lab, 0)).to(dev).to(lab.dtype)], 0)
         mask = torch.zeros(cat_pc.shape[0], dtype=torch.bool, device=dev)
         mask[n0:] = True
+        mask.n_obj = cat_pc.shape[0] - n0     # known on the host: post_process need not read it back from the device
         return cat_pc, cat_label, mask, mask.clone()
     none = torch.zeros(n0, dtype=torch.bool, device=dev)
+    none.n_obj = 0
     return m.pts[:, :3].double().contiguous(), lab, none, none.clone()
 
 
@@ -232,13 +234,17 @@ def post_process(cat_pc_ls, cat_pslabel_ls, obj_mask_ls, scale, full_scale, augm
     -> ``[{'x': [locs (sumN',4) int64, feats (sumN',1)]}, cat_ps_label, obj_mask, None]`` on the device."""
     if "SCN" not in backbone:
         raise IndexError("The specified backbone is not supported: {}".format(backbone))
-    locs, labels, masks = [], [], []
+    # Host round trips: the reference works on numpy arrays, here every `.item()` / boolean-mask index waits for the whole
+    # stream.  Per scan nothing is read back (the object count rides on the mask tensor, `point_mixmatch` knows it; the NaN test
+    # stays a device flag); ONE `nonzero` over the concatenated keep mask compacts the batch, the flags are read behind it.
+    coords_ls, keep_ls, labels, masks, nan_flags = [], [], [], [], []
     for i, (pc, lab, om) in enumerate(zip(cat_pc_ls, cat_pslabel_ls, obj_mask_ls)):
         pc = pc.contiguous()
-        if bool(torch.isnan(pc).any()):
-            raise AssertionError("Found Nan object points: {}".format(scan_pth_ls[i] if scan_pth_ls else i))
+        nan_flags.append(torch.isnan(pc).any())
         n = pc.shape[0]
-        n_obj = int(om.sum().item())
+        n_obj = getattr(om, "n_obj", None)
+        if n_obj is None:
+            n_obj = int(om.sum().item())
         valid = range_keep(pc, n - n_obj, fov_up, fov_down, proj_W, proj_H) if (use_proj and n_obj > 0) else None
         rot = _rot_matrix(augment_3d["noisy_rot"], augment_3d.get("flip_x", 0.0), augment_3d.get("flip_y", 0.0), augment_3d["rot_z"])
         u = np.random.rand(3) if augment_3d["transl"] else None
@@ -250,9 +256,15 @@ def post_process(cat_pc_ls, cat_pslabel_ls, obj_mask_ls, scale, full_scale, augm
         vk = None if valid is None else valid.to(torch.uint8)
         call("mopa_voxelize_f64", ptr(pc), n, ptr(vk), None if rot_c is None else rot_c.ctypes.data, float(scale), int(full_scale),
              None if u_c is None else u_c.ctypes.data, int(u is not None), i, ptr(coords), ptr(keep), ptr(ws), ws.numel(), stream())
-        k = keep.bool()
-        locs.append(coords[k])
-        labels.append(torch.as_tensor(lab).to(pc.device)[k])
-        masks.append(om[k])
-    locs = torch.cat(locs, 0)
-    return [{"x": [locs, torch.ones(locs.shape[0], 1, device=locs.device)]}, torch.cat(labels, 0), torch.cat(masks, 0), None]
+        coords_ls.append(coords)
+        keep_ls.append(keep)
+        labels.append(torch.as_tensor(lab).to(pc.device))
+        masks.append(om)
+    sel = torch.nonzero(torch.cat(keep_ls, 0)).squeeze(1)       # the one synchronisation of the batch
+    bad = torch.stack(nan_flags).cpu()
+    if bool(bad.any()):
+        i = int(torch.nonzero(bad)[0])
+        raise AssertionError("Found Nan object points: {}".format(scan_pth_ls[i] if scan_pth_ls else i))
+    locs = torch.cat(coords_ls, 0).index_select(0, sel)
+    return [{"x": [locs, torch.ones(locs.shape[0], 1, device=locs.device)]}, torch.cat(labels, 0).index_select(0, sel),
+            torch.cat(masks, 0).index_select(0, sel), None]
