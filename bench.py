@@ -93,12 +93,13 @@ class ConvTimer:
     def summary(self):
         if not self.records:
             return None
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
         nbytes = sum(r[2] for r in self.records)
         flops = sum(r[3] for r in self.records)
+        direct = sum(r[4] if len(r) > 4 else r[3] for r in self.records)   # flops of the direct convolutions the launches stand for
         n = len(self.records)
         return dict(launches=n, avg_us=1e3 * ms / n, bytes_per_launch=nbytes / n, gbs=nbytes / (ms * 1e-3) / 1e9,
-                    tflops=flops / (ms * 1e-3) / 1e12)
+                    tflops=flops / (ms * 1e-3) / 1e12, tflops_direct=direct / (ms * 1e-3) / 1e12)
 
 
 class Conv2dTimer:
@@ -125,7 +126,7 @@ class Conv2dTimer:
             M = g[0] * g[3] * g[4]  # B * OHl * OWl
             taps, cin, cout = g[15] * g[16], g[21], g[22]
             # bytes: activations read once + outputs written once + weights once (ideal reuse)
-            timer.records.append((s, e, 4 * (M * cin + M * cout + taps * cin * cout), 2 * M * cout * taps * cin))
+            timer.records.append((s, e, 4 * (M * cin + M * cout + taps * cin * cout), 2 * M * cout * taps * cin, 2 * M * cout * taps * cin))
 
         dense2d.igemm = wrapped
         inner_b = dense2d.igemm_batched
@@ -139,7 +140,9 @@ class Conv2dTimer:
             e.record()
             g = list(geom)
             M, cin, cout = g[0] * g[3] * g[4], g[21], g[22]
-            timer.records.append((s, e, 4 * nbatch * (M * cin + M * cout + cin * cout), 2 * nbatch * M * cout * cin))
+            # (the direct 3x3 convolution these GEMMs replace: 16 or 36 points stand for 4 or 16 output pixels x 9 taps)
+            timer.records.append((s, e, 4 * nbatch * (M * cin + M * cout + cin * cout), 2 * nbatch * M * cout * cin,
+                                  2 * M * cout * cin * 9 * (4 if nbatch == 16 else 16 if nbatch == 36 else nbatch / 9)))
 
         dense2d.igemm_batched = wrapped_b
         inner_call = dense2d.call
@@ -153,7 +156,7 @@ class Conv2dTimer:
             s.record()
             r = inner_call(name, *a)
             e.record()
-            timer.records.append((s, e, 4 * (36 * T * cin + B * H * W * cout + 36 * cin * cout), 2 * 36 * T * cin * cout))
+            timer.records.append((s, e, 4 * (36 * T * cin + B * H * W * cout + 36 * cin * cout), 2 * 36 * T * cin * cout, 2 * 16 * T * cin * cout * 9))
             return r
 
         dense2d.call = wrapped_call
@@ -675,6 +678,7 @@ def main():
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
+                    "direct_conv_equivalent_tflops": round(k2["tflops_direct"], 1),   # NOT the roofline figure: what a direct 3x3 conv would have to sustain for the same launch times (Winograd executes 2.25x / 4x fewer flops)
                     "stream_configuration": "as timed for `value`: 2D main stream + " +
                                             ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
