@@ -330,3 +330,23 @@ def test_config3_mopa_iteration_4_plus_4_full_size_properties():
     # the teacher now differs from the student: its pseudo labels are still valid class ids or ignore
     _, _, q2, _ = teacher_labels()
     assert set(torch.unique(q2).tolist()) <= {-100, 0, 1, 2, 3, 4}
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` end to end on the GPU box: the parent starts two ranks itself (torch.distributed.run), both
+    run the joint step on cuda:0 over gloo (RCCL refuses two ranks per device; the code path is the data-parallel one: per-rank
+    scans, flat gradient all-reduce per network, loss weights, barrier + max-over-ranks timing), rank 0 prints ONE JSON line
+    with n_gpus = 2.  A plumbing test of SURVEY 8e on hardware, not a performance number."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOPA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
