@@ -43,6 +43,7 @@ SIGNATURES = {
     "mopa_spconv_transpose_weight": ("i", "piiipp"),
     "mopa_spconv_grouped_wants_packed": ("i", "iiii"),
     "mopa_spconv_pack_weight": ("i", "piiiiipp"),
+    "mopa_spconv_pack_weights_batched": ("i", "pip"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
     # ---- VGI (vgi.hip)

@@ -410,6 +410,66 @@ MOPA_API int mopa_spconv_pack_weight(const float* w, int32_t K, int32_t cin, int
   return MOPA_OK;
 }
 
+// Every packed / transposed weight form of a network in ONE launch (the 3D step re-lays out ~50 conv weights per optimizer step:
+// 50 launches at the ~5 us floor each, on a host-paced step).  desc_host [n][6] int64: source, destination, K, cin, cout (of the
+// layer weight [K][cin][cout]), flags: bit 0 = the convolution to run is the per-offset transpose (backward-data), bits 8-15 =
+// ntw (column groups of ntw 16-column tiles, as mopa_spconv_pack_weight) or 0 = plain per-offset transpose
+// (mopa_spconv_transpose_weight).  n <= 64 per call; the array travels as a kernel argument.
+#define PW_MAX 64
+struct PackDescs { int64_t src[PW_MAX], dst[PW_MAX]; int32_t K[PW_MAX], cin[PW_MAX], cout[PW_MAX], flags[PW_MAX]; };
+__global__ void k_pack_w_batched(const PackDescs d) {
+  const int e = blockIdx.y;
+  const float* __restrict__ w = reinterpret_cast<const float*>(d.src[e]);
+  float* __restrict__ wp = reinterpret_cast<float*>(d.dst[e]);
+  const int K = d.K[e], cin_w = d.cin[e], cout_w = d.cout[e], transpose = d.flags[e] & 1, ntw = (d.flags[e] >> 8) & 0xff;
+  const int n = K * cin_w * cout_w;
+  if (ntw == 0) {   // wt[o][co][ci] = w[o][ci][co]
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int ci = i % cin_w, t = i / cin_w;
+      const int co = t % cout_w, o = t / cout_w;
+      wp[i] = w[((int64_t)o * cin_w + ci) * cout_w + co];
+    }
+    return;
+  }
+  const int cin_c = transpose ? cout_w : cin_w;
+  const int nkc = cin_c >> 4, cp = ntw * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {   // same map as k_pack_w
+    int rem = i;
+    const int t = rem % ntw; rem /= ntw;
+    const int s2 = rem & 3; rem >>= 2;
+    const int lane = rem & 63; rem >>= 6;
+    const int kc = rem % nkc; rem /= nkc;
+    const int o = rem % K;
+    const int cg = rem / K;
+    const int k = kc * 16 + (lane >> 4) * 4 + s2, c = cg * cp + (lane & 15) * ntw + t;
+    wp[i] = transpose ? w[((int64_t)o * cin_w + c) * cout_w + k] : w[((int64_t)o * cin_w + k) * cout_w + c];
+  }
+}
+MOPA_API int mopa_spconv_pack_weights_batched(const int64_t* desc_host, int32_t n, void* stream) {
+  if (!desc_host || n <= 0 || n > PW_MAX) return MOPA_ERR_ARG;
+  PackDescs d;
+  memset(&d, 0, sizeof(d));
+  int64_t nmax = 0;
+  for (int e = 0; e < n; ++e) {
+    const int64_t* r = desc_host + (int64_t)e * 6;
+    const int K = (int)r[2], cin = (int)r[3], cout = (int)r[4], flags = (int)r[5];
+    const int transpose = flags & 1, ntw = (flags >> 8) & 0xff;
+    const int cin_c = transpose ? cout : cin, cout_c = transpose ? cin : cout;
+    if (!r[0] || !r[1] || K <= 0 || cin <= 0 || cout <= 0 || (int64_t)K * cin * cout >= (1ll << 31)) return MOPA_ERR_ARG;
+    if (ntw && (cin_c % 16 || cout_c % 16 || ntw > 4 || (cout_c / 16) % ntw)) return MOPA_ERR_ARG;
+    if (!ntw && !transpose) return MOPA_ERR_ARG;
+    d.src[e] = r[0]; d.dst[e] = r[1]; d.K[e] = K; d.cin[e] = cin; d.cout[e] = cout; d.flags[e] = flags;
+    const int64_t ne = (int64_t)K * cin * cout;
+    if (ne > nmax) nmax = ne;
+  }
+  int bx = (int)cdiv64(nmax, 256 * 4);
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  k_pack_w_batched<<<dim3(bx, n), 256, 0, (hipStream_t)stream>>>(d);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
 // ----------------------------------------------------------------------------------------------
 // Block kernel on the grouped rulebook: 4 waves = 4 consecutive 64-row tiles walk the filter offsets in lockstep;
 // the block stages the column slice W[o][:, c0:c0+16*NTW] of each offset ONCE in LDS (double-buffered, next offset's

@@ -24,6 +24,7 @@ from ._lib import GradSink, call, ptr, query, stream, workspace
 BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
 BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
 LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
+BATCHED_REPACK = os.environ.get("MOPA_BATCHED_REPACK", "1") != "0"   # A/B switch: one launch for all stale weight forms
 
 
 def _ws(nbytes, device):
@@ -212,6 +213,37 @@ def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: b
 
 
 _weight_cache = {}
+_refreshed = {}   # stream -> WEIGHTS_EPOCH of the last batched refresh
+
+
+def _refresh_stale_forms(st):
+    """Re-lay out EVERY cached form whose weight changed since it was built -- all layers of all networks on this stream -- in one
+    launch (mopa_spconv_pack_weights_batched) instead of one tiny kernel per layer and form as each is first used: a step of
+    the 3D network re-packs ~50 forms (forward + backward-data of 25 convolutions) right after the optimizer step.  The cached
+    destination buffers are re-used (same sizes; the launches that read them are ahead of this one on the same stream).  A form
+    that was never built before (new network, another geometry-dependent plan) still takes the single-kernel path."""
+    import numpy as np
+    epoch = _lib.WEIGHTS_EPOCH[0]
+    rows, hits = [], []
+    for key, (tag, t, wref) in list(_weight_cache.items()):
+        if key[2] != st:
+            continue
+        w = wref()
+        if w is None:
+            del _weight_cache[key]
+            continue
+        new_tag = (epoch, w._version, w.data_ptr())
+        if tag == new_tag:
+            continue
+        form = key[1]
+        flags = (form[1] | (form[2] << 8)) if form[0] == "pack" else 1
+        rows.append((w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1], w.shape[2], flags))
+        hits.append((key, new_tag, t, wref))
+    for i in range(0, len(rows), 64):
+        desc = np.asarray(rows[i:i + 64], dtype=np.int64)
+        call("mopa_spconv_pack_weights_batched", desc.ctypes.data, len(desc), st)
+    for key, new_tag, t, wref in hits:
+        _weight_cache[key] = (new_tag, t, wref)
 
 
 def _weight_form(w: torch.Tensor, form: tuple) -> torch.Tensor:
@@ -219,11 +251,18 @@ def _weight_form(w: torch.Tensor, form: tuple) -> torch.Tensor:
     iteration share the weights).  Same validity rules as dense2d.relayout_cached: one live tensor object, one weight
     version (autograd counter + _lib.WEIGHTS_EPOCH), one stream."""
     import weakref
-    key = (id(w), form, stream())
+    st = stream()
+    key = (id(w), form, st)
     tag = (_lib.WEIGHTS_EPOCH[0], w._version, w.data_ptr())
     hit = _weight_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
+    if hit is not None and hit[2]() is w and _refreshed.get(st) != tag[0] and BATCHED_REPACK:
+        _refreshed[st] = tag[0]      # once per epoch and stream: everything stale goes in one launch
+        _refresh_stale_forms(st)
+        hit = _weight_cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
     K = w.shape[0]
     if form[0] == "pack":
         t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)

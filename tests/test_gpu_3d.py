@@ -324,3 +324,46 @@ def test_device_rotation_stage_replays_the_reference_augmentation(golden_dir):
         assert got.shape == want.shape and np.abs(got - want).max() <= 1   # a last-ulp difference can move a point across a voxel face
         assert (got == want).all(1).mean() >= 0.99
         assert rot is None or rot.dtype == np.float32
+
+
+def test_cached_weight_forms_3d_follow_weight_updates_batched_and_single(monkeypatch):
+    """The packed / transposed forms of the sparse-conv weights are cached per weight version and, after an update, ALL stale
+    forms are rebuilt in one launch (mopa_spconv_pack_weights_batched).  Optimizer steps, a tracked in-place update and an EMA
+    swap must all be seen, and the batched refresh must give the bits of the one-kernel-per-form path."""
+    from mopa_amd import sparse3d, synth
+    from mopa_amd.optim import FlatAdam
+    from mopa_amd.pseudo import FlatEMA
+    b = synth.make_batch(2, H=16, W=16)
+    locs, feats = b["x"][0].cuda(), b["x"][1].cuda()
+
+    def run(batched):
+        monkeypatch.setattr(sparse3d, "BATCHED_REPACK", batched)
+        sparse3d._weight_cache.clear()
+        sparse3d._refreshed.clear()
+        torch.manual_seed(0)
+        m = _build_3d(7).train()
+        opt = FlatAdam(m.parameters(), lr=1e-2)
+        ema = FlatEMA(opt, decay=0.5)
+        outs = []
+        for it in range(3):
+            opt.zero_grad()
+            o = m({"x": [locs, feats]})
+            (o["seg_logit"].square().mean() + o["seg_logit2"].square().mean()).backward()
+            opt.step()
+            ema.update()
+            outs.append(o["seg_logit"].detach().clone())
+        with torch.no_grad():
+            first = m.net_3d.sparseModel_weights()[0] if hasattr(m.net_3d, "sparseModel_weights") else next(p for n, p in m.named_parameters() if p.dim() == 3)
+            first.mul_(1.25)                                   # tracked in-place update of one cached layer
+        m.eval()
+        with torch.no_grad():
+            outs.append(m({"x": [locs, feats]})["seg_logit"].clone())
+            with ema.average_parameters():
+                outs.append(m({"x": [locs, feats]})["seg_logit"].clone())
+            outs.append(m({"x": [locs, feats]})["seg_logit"].clone())
+        return outs
+
+    a, s = run(True), run(False)
+    for x, y in zip(a, s):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[3], a[4]) and torch.equal(a[3], a[5])
