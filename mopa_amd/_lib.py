@@ -92,6 +92,7 @@ SIGNATURES = {
     "mopa_wino_bwd_weight": ("i", "ppiiipipzp"),
     "mopa_wino4_weight": ("i", "piiipp"),
     "mopa_wino4_weight_t": ("i", "piiipp"),
+    "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),
     "mopa_wino4_output": ("i", "piiiippiip"),

@@ -16,6 +16,7 @@
 //   (oy*IS + IY0 + ty*IDY, ox*IS + IX0 + tx*IDX), zero outside [IH][IW]; its weight slice is
 //   w[(KH0 + ty*KS) * KWF + (KW0 + tx*KS)] of shape [Cin][Cout].
 #include "common.h"
+#include "weight_forms.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1049,6 +1050,10 @@ MOPA_API int mopa_wino4_bwd_weight(const float* V, const float* dM, int32_t T, i
 // (modes 0 and 2 only).
 __global__ void k_relayout_w(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int KH, int KW, int mode,
                              int inverse, int accumulate) {
+  if (!inverse) {   // (shared with the batched refresh: weight_forms.h)
+    wf_relayout_body(src, dst, O, I, KH, KW, mode, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+    return;
+  }
   const int64_t n = (int64_t)O * I * KH * KW;
   const int R = (mode == 0 || mode == 2) ? I : O, C = (mode == 0 || mode == 2) ? O : I;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1061,8 +1066,7 @@ __global__ void k_relayout_w(const float* __restrict__ src, float* __restrict__ 
     const int o = (mode == 0 || mode == 2) ? c : r, ii = (mode == 0 || mode == 2) ? r : c;
     const int64_t p = (mode < 2) ? (((int64_t)o * I + ii) * KH + kh) * KW + kw   // OIHW
                                  : (((int64_t)ii * O + o) * KH + kh) * KW + kw;  // IOHW
-    if (!inverse) dst[i] = src[p];
-    else dst[p] = (accumulate ? dst[p] : 0.f) + src[i];
+    dst[p] = (accumulate ? dst[p] : 0.f) + src[i];
   }
 }
 

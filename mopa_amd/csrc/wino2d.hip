@@ -9,39 +9,14 @@
 // layers stay on the direct kernel: there the V / M traffic (4x the activations, written and read) costs more than the
 // saved FMAs.  Replaces cuDNN's choice of algorithm behind mopa/models/resnet34_unet.py:97-110; oracle: oracle/net2d.py.
 #include "common.h"
+#include "weight_forms.h"
+#include <string.h>
 #include <stdio.h>
 
 // U[p][r][c], p = 4*i + j.  dgrad = 0: r = input channel, c = output channel, g = w[c][r][.][.] (OIHW);
 //                           dgrad = 1: r = output channel, c = input channel, g = w[r][c] rotated by 180 degrees.
 __global__ void k_wino_w(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U) {
-  const int R = dgrad ? O : I, C = dgrad ? I : O;
-  const int n = R * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int r = i / C, c = i - r * C;
-    const int o = dgrad ? r : c, ci = dgrad ? c : r;
-    const float* g9 = w + ((int64_t)o * I + ci) * 9;
-    float g[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = dgrad ? g9[(2 - a) * 3 + (2 - b)] : g9[a * 3 + b];
-    float t[4][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      t[0][b] = g[0][b];
-      t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-      t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-      t[3][b] = g[2][b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
-      U[(int64_t)(a * 4 + 0) * n + i] = u0;
-      U[(int64_t)(a * 4 + 1) * n + i] = u1;
-      U[(int64_t)(a * 4 + 2) * n + i] = u2;
-      U[(int64_t)(a * 4 + 3) * n + i] = u3;
-    }
-  }
+  wf_wino2_body(w, O, I, dgrad, U, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // thread = (tile, channel quad)
@@ -255,14 +230,6 @@ __device__ __forceinline__ void w4_a(const float d[4], float r[6]) {    // r = A
   r[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
   r[5] = d[3];
 }
-__device__ __forceinline__ void w4_g(const float g[3], float t[6]) {    // t = G g
-  t[0] = 0.25f * g[0];
-  t[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
-  t[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
-  t[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
-  t[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
-  t[5] = g[2];
-}
 __device__ __forceinline__ void w4_gt(const float u[6], float g[3]) {   // g = G^T u
   g[0] = 0.25f * u[0] - (1.f / 6.f) * (u[1] + u[2]) + (1.f / 24.f) * (u[3] + u[4]);
   g[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
@@ -271,30 +238,7 @@ __device__ __forceinline__ void w4_gt(const float u[6], float g[3]) {   // g = G
 
 // U[p][r][c] (p = 6*i + j) = (G g G^T)[p]; dgrad as in k_wino_w
 __global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U, int transpose) {
-  const int R = dgrad ? O : I, C = dgrad ? I : O;
-  const int n = R * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int r = i / C, c = i - r * C;
-    const int o = dgrad ? r : c, ci = dgrad ? c : r;
-    const float* g9 = w + ((int64_t)o * I + ci) * 9;
-    float t[6][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float col[3], tc[6];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) col[a] = dgrad ? g9[(2 - a) * 3 + (2 - b)] : g9[a * 3 + b];
-      w4_g(col, tc);
-#pragma unroll
-      for (int a = 0; a < 6; ++a) t[a][b] = tc[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      float u[6];
-      w4_g(t[a], u);
-#pragma unroll
-      for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * n + (transpose ? c * R + r : i)] = u[b];   // transpose: U^T[p][c][r]
-    }
-  }
+  wf_wino4_body(w, O, I, dgrad, U, transpose, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, int ld_in, int B, int H, int W, int C, int th, int tw,
@@ -439,6 +383,44 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   k_wino4_dout<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(dy, ld, B, H, W, C, th, tw, dM);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// ================================================================================================================
+// Every stale weight form of the 2D network in ONE launch: after an optimizer step the first use of each conv re-laid out
+// its weight with a tiny kernel of its own (igemm layouts, Winograd transforms: ~95 launches of 8-10 us per joint step, serialised
+// on the main stream between the convolutions).  desc_host [n][8] int64: source, destination, O, I, KH, KW, kind (0 = igemm
+// layout, 1 = F(2x2) transform, 2 = F(4x4) transform), arg (kind 0: mode 0-3; kinds 1, 2: bit 0 = dgrad, bit 1 = transposed).
+#define WF_MAX 48
+struct WeightFormDescs { int64_t src[WF_MAX], dst[WF_MAX]; int32_t O[WF_MAX], I[WF_MAX], KH[WF_MAX], KW[WF_MAX], kind[WF_MAX], arg[WF_MAX]; };
+__global__ void k_weight_forms_batched(const WeightFormDescs d) {
+  const int e = blockIdx.y;
+  const float* src = reinterpret_cast<const float*>(d.src[e]);
+  float* dst = reinterpret_cast<float*>(d.dst[e]);
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, istep = gridDim.x * blockDim.x;
+  if (d.kind[e] == 0) wf_relayout_body(src, dst, d.O[e], d.I[e], d.KH[e], d.KW[e], d.arg[e], i0, istep);
+  else if (d.kind[e] == 1) wf_wino2_body(src, d.O[e], d.I[e], d.arg[e] & 1, dst, i0, istep);
+  else wf_wino4_body(src, d.O[e], d.I[e], d.arg[e] & 1, dst, (d.arg[e] >> 1) & 1, i0, istep);
+}
+MOPA_API int mopa_conv2d_weight_forms_batched(const int64_t* desc_host, int32_t n, void* stream) {
+  if (!desc_host || n <= 0 || n > WF_MAX) return MOPA_ERR_ARG;
+  WeightFormDescs d;
+  memset(&d, 0, sizeof(d));
+  int64_t nmax = 0;
+  for (int e = 0; e < n; ++e) {
+    const int64_t* r = desc_host + (int64_t)e * 8;
+    const int64_t O = r[2], I = r[3], KH = r[4], KW = r[5], kind = r[6], arg = r[7];
+    if (!r[0] || !r[1] || O <= 0 || I <= 0 || kind < 0 || kind > 2) return MOPA_ERR_ARG;
+    if (kind == 0 && (KH <= 0 || KW <= 0 || arg < 0 || arg > 3 || O * I * KH * KW >= (1ll << 31))) return MOPA_ERR_ARG;
+    if (kind != 0 && (KH != 3 || KW != 3 || arg < 0 || arg > 3 || (kind == 1 && (arg & 2)))) return MOPA_ERR_ARG;
+    d.src[e] = r[0]; d.dst[e] = r[1]; d.O[e] = (int)O; d.I[e] = (int)I; d.KH[e] = (int)KH; d.KW[e] = (int)KW; d.kind[e] = (int)kind; d.arg[e] = (int)arg;
+    const int64_t ne = kind == 0 ? O * I * KH * KW : O * I;
+    if (ne > nmax) nmax = ne;
+  }
+  int bx = (int)cdiv64(nmax, 256);
+  if (bx > 256) bx = 256;
+  k_weight_forms_batched<<<dim3(bx, n), 256, 0, (hipStream_t)stream>>>(d);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

@@ -74,25 +74,64 @@ def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
 
 
 _relayout_cache = {}
+_refreshed = {}   # stream -> WEIGHTS_EPOCH of the last batched refresh
+BATCHED_REFRESH = os.environ.get("MOPA_BATCHED_REFRESH", "1") != "0"   # A/B switch: one launch for all stale weight forms
 
 
-def _cached_weight_form(w, form, build):
+def _refresh_stale_forms(st):
+    """Rebuild EVERY cached weight form of this stream whose weight changed since it was built in one launch
+    (mopa_conv2d_weight_forms_batched) -- igemm layouts and Winograd transforms of all convolutions, ~95 forms per joint
+    step, each of which used to be an 8-10 us kernel serialised on the main stream at the layer's first use after the
+    optimizer step.  The cached destination tensors are re-used (same sizes; their readers are ahead on the same stream).
+    A form that was never built on this stream still takes the single-kernel path."""
+    from ._lib import WEIGHTS_EPOCH
+    epoch = WEIGHTS_EPOCH[0]
+    rows, hits = [], []
+    for key, ent in list(_relayout_cache.items()):
+        if key[2] != st or len(ent) < 4 or ent[3] is None:
+            continue
+        tag, t, wref, meta = ent
+        w = wref()
+        if w is None:
+            del _relayout_cache[key]
+            continue
+        new_tag = (epoch, w._version, w.data_ptr())
+        if tag == new_tag:
+            continue
+        rows.append((w.data_ptr(), t.data_ptr()) + meta)
+        hits.append((key, new_tag, t, wref, meta))
+    for i in range(0, len(rows), 48):
+        desc = np.asarray(rows[i:i + 48], dtype=np.int64)
+        call("mopa_conv2d_weight_forms_batched", desc.ctypes.data, len(desc), st)
+    for key, new_tag, t, wref, meta in hits:
+        _relayout_cache[key] = (new_tag, t, wref, meta)
+
+
+def _cached_weight_form(w, form, build, meta=None):
     """A derived layout of a conv weight, re-used until the weight changes (an iteration runs the network on the source and
     on the target batch with the same weights).  An entry belongs to ONE live tensor object (weak reference: the allocator
     hands a freed weight's address to the next tensor), one weight version (autograd's counter + the epoch that FlatAdam /
     FlatEMA bump for their raw in-place updates) and one stream (the copy is only ordered with work of the stream that
-    made it)."""
+    made it).  `meta` = (O, I, KH, KW, kind, arg) of mopa_conv2d_weight_forms_batched lets a later refresh rebuild the form
+    together with all other stale ones."""
     import weakref
     from ._lib import WEIGHTS_EPOCH
-    key = (id(w), form, stream())
+    st = stream()
+    key = (id(w), form, st)
     tag = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
     hit = _relayout_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
+    if hit is not None and hit[2]() is w and BATCHED_REFRESH and _refreshed.get(st) != tag[0]:
+        _refreshed[st] = tag[0]      # once per epoch and stream
+        _refresh_stale_forms(st)
+        hit = _relayout_cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
     t = build()
     if len(_relayout_cache) > 4096:   # temporaries (tests, one-off calls) must not pile up
         _relayout_cache.clear()
-    _relayout_cache[key] = (tag, t, weakref.ref(w))
+    _relayout_cache[key] = (tag, t, weakref.ref(w), meta)
     return t
 
 
@@ -102,7 +141,7 @@ def relayout_cached(w, shape, O, I, KH, KW, mode):
         t = torch.empty(*shape, dtype=torch.float32, device=w.device)
         relayout(w, t, O, I, KH, KW, mode)
         return t
-    return _cached_weight_form(w, ("relayout", mode), build)
+    return _cached_weight_form(w, ("relayout", mode), build, (O, I, KH, KW, 0, mode))
 
 
 def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: bool = False):
@@ -117,7 +156,8 @@ def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: bool = False):
         call(name, ptr(w), O, I, int(dgrad), ptr(u), stream())
         return u
     assert not (transposed and F != 4)
-    return _cached_weight_form(w, ("wino", F, int(dgrad), int(transposed)), build)
+    return _cached_weight_form(w, ("wino", F, int(dgrad), int(transposed)), build,
+                               (O, I, 3, 3, 1 if F == 2 else 2, int(dgrad) | (int(transposed) << 1)))
 
 
 # F(4x4) layers whose 36 GEMMs and output transform run as ONE kernel (mopa_wino4_gemm_output: M is never materialised): needs

@@ -418,6 +418,39 @@ def test_cached_weight_layouts_follow_every_kind_of_weight_update():
     assert len(calls) == 1 and float(ret) == calls[0] and opt.t == t0 + 1
 
 
+def test_batched_weight_form_refresh_gives_the_bits_of_the_single_kernels(monkeypatch):
+    """After a weight update every stale igemm layout / Winograd transform of the network is rebuilt in ONE launch
+    (mopa_conv2d_weight_forms_batched, shared device code with the one-form kernels): training steps with the batched refresh
+    on and off must give identical logits."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    from mopa_amd.optim import FlatAdam
+    b = synth.make_batch(2, H=64, W=96)
+
+    def run(batched):
+        monkeypatch.setattr(dense2d, "BATCHED_REFRESH", batched)
+        dense2d._relayout_cache.clear()
+        dense2d._refreshed.clear()
+        torch.manual_seed(0)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        m.net_2d.dropout.p = 0.0
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        outs = []
+        for _ in range(3):
+            opt.zero_grad()
+            o = m(b)
+            (o["seg_logit"].square().mean() + o["seg_logit2"].square().mean()).backward()
+            opt.step()
+            outs.append(o["seg_logit"].detach().clone())
+        return outs
+
+    a, s = run(True), run(False)
+    for x, y in zip(a, s):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[0], a[1])
+
+
 def test_net2dseg_well_conditioned_fixture_bounds_every_gradient_at_one_percent(golden_dir):
     """Fixture G1b (reference Net2DSeg, train mode, 2 x 64 x 96: layer4 sees 48 samples per channel).  Outputs against the
     reference's fp32 values; EVERY parameter gradient against the fp64 oracle within 1 % of its norm -- including the
