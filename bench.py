@@ -14,6 +14,7 @@ before the timed region.  value = scans/s over all ranks (weak scaling: per-GPU 
 A/B switches (environment; the defaults are what the numbers in DESIGN.md were measured with):
   MOPA_BENCH_EVENT_STRIDE=5   HIP-event brackets (roofline figures) on every n-th timed step; 0 = none, 1 = every step
   MOPA_BENCH_STEP_TIMES=1     per-step host clock + caching-allocator counters + cyclic-GC passes of the timed region on stderr
+  MOPA_BENCH_TIMELINE=1       HIP-event marks on the streams (ends of the forwards / losses / backwards of both halves), mean offsets on stderr
   MOPA_BENCH_GC_FREEZE=0      skip mopa_amd.step.freeze_host_heap() after the warm-up (then one 70-100 ms full GC pass lands in
                               the timed region: -20 % on the launch-bound 3D-only workload, nothing on the joint one)
   MOPA_BENCH_GEOM_AHEAD=0     voxel geometry built behind the main stream again;  MOPA_BENCH_REORDER=0  3D forward enqueued
@@ -424,10 +425,22 @@ def main():
     if os.environ.get("MOPA_BENCH_NO_SIDE") == "1":   # A/B only: the 3D branch on the main stream
         dual.side = torch.cuda.current_stream(dev)
 
+    tl = None
+    if os.environ.get("MOPA_BENCH_TIMELINE") == "1" and joint:   # diagnostics: HIP-event marks on the streams, printed on stderr
+        from mopa_amd.step import Timeline
+        tl = dual.timeline = Timeline()
     resident = torch.cuda.Event()
     resident.record()           # the synthetic batches are in HBM from here on
     geom_ahead = os.environ.get("MOPA_BENCH_GEOM_AHEAD", "1") != "0"
     bwd3_first = os.environ.get("MOPA_BENCH_BWD3_FIRST", "1") != "0"
+
+    # The 3D network's optimizer lives on the side stream with the rest of the 3D branch (its gradient clear, all-reduce and Adam
+    # update are ordered behind the 3D backward there), so the main stream never waits for the 3D backward: measured with
+    # MOPA_BENCH_TIMELINE=1 the 3D backward of the target half ended 3.8 ms after the 2D backward -- it is enqueued behind it and
+    # shares the chip with it -- and `dual.join()` in front of the optimizer steps left the main stream idle for that long every
+    # step.  The next 3D forward follows on the same stream, the cross-modal losses order the streams as before.
+    # MOPA_BENCH_DECOUPLE_3D_OPT=0: the joined form (both updates on the main stream behind dual.join()).
+    decoupled = joint and os.environ.get("MOPA_BENCH_DECOUPLE_3D_OPT", "1") != "0"
 
     def half(b, lam_xm, supervised, ready=None):
         """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
@@ -453,6 +466,8 @@ def main():
                 l3 = l3 + seg_ce(ov["seg_logit"], cat_ps)
             return l3
 
+        if tl is not None:
+            tl.mark("fwd_joined")
         l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
         if supervised:
             l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
@@ -469,15 +484,28 @@ def main():
             l2.backward()
             with dual.on_side(o2["seg_logit"], after=ready):
                 l3 = loss_3d()
-            l3.backward()
+                l3.backward()   # called ON the side stream: see below
             return l2.detach(), l3.detach()
         if reorder:
             # the 3D losses on the side stream: their backward -- the whole 3D backward -- is then queued there
             # and runs beside the 2D backward without the host having to enqueue it first while the main stream waits
             with dual.on_side(o2["seg_logit"]):
                 l3 = loss_3d()
+            if tl is not None:
+                tl.mark("losses_done")
             l2.backward()
-            l3.backward()
+            if tl is not None:
+                tl.mark("bwd2d_end")
+            # backward() ends by making the stream that is CURRENT AT THE CALL wait for every stream the backward pass ran on
+            # (autograd's stream semantics): called from the main stream, `l3.backward()` was a hidden join -- the main stream
+            # sat idle until the 3D backward had finished, 3.8 ms in each half (MOPA_BENCH_TIMELINE=1).  Called with the side
+            # stream current, nothing waits; the optimizer of the 3D network is on that stream too (step()).
+            if decoupled:
+                dual.backward_on_side(l3)
+            else:
+                l3.backward()
+            if tl is not None:
+                tl.mark("bwd3d_end", dual.side)
             return l2.detach(), l3.detach()
         l3 = loss_3d()
         if bwd3_first:   # the 3D backward (side stream) starts as soon as its loss gradient exists, beside the 2D backward
@@ -521,9 +549,21 @@ def main():
             t.record_stream(dual.side)
         return d, ev
 
+    host_delay = float(os.environ.get("MOPA_BENCH_HOST_DELAY_MS", "0")) * 1e-3   # diagnostics: is the step host-paced?
+
     def step(i, host_fed=False):
-        for o in opts:
-            o.zero_grad()
+        if host_delay:
+            time.sleep(host_delay)
+        if tl is not None:
+            tl.begin()
+            tl.mark("step_start")
+        if decoupled:
+            with torch.cuda.stream(dual.side):
+                opts[0].zero_grad()
+            opts[1].zero_grad()
+        else:
+            for o in opts:
+                o.zero_grad()
         work3 = None
         if joint and host_fed:
             d0, e0 = stage(host_batches[0])
@@ -546,6 +586,18 @@ def main():
             out = model3d({"x": [b["locs"], b["feats"]], "geometry_3d": geom})
             loss = seg_ce(out["seg_logit"], b["label"], cw) + seg_ce(out["seg_logit2"], b["label"], cw)
             loss.backward()
+        if decoupled:
+            with torch.cuda.stream(dual.side):   # 3D: reduce + update behind its own backward
+                if work3 is not None:
+                    work3.wait()                 # the side stream waits for the collective; the host does not block
+                else:
+                    opts[0].all_reduce()
+                opts[0].step(rank_weight / world)
+            opts[1].all_reduce()                 # 2D: on the main stream behind the 2D backward
+            opts[1].step(rank_weight / world)
+            if tl is not None:
+                tl.mark("step_end")
+            return parts                         # (l2, l3) x 2 halves, summed after the final synchronisation
         if joint:
             dual.join()  # 3D backward done before its gradients are reduced / applied
             for t in parts:   # the 3D parts live in the side stream's pool
@@ -559,6 +611,8 @@ def main():
             work3.wait()   # the current stream waits for the collective; the host does not block
         for o in opts:
             o.step(rank_weight / world)
+        if tl is not None:
+            tl.mark("step_end")
         return loss
 
     scans_per_step = 2 * B if joint else B
@@ -613,6 +667,11 @@ def main():
               [(g, round(at, 3), round(1e3 * d, 1)) for g, at, d in gc_log if d > 1e-3], file=sys.stderr, flush=True)
         print("[bench] cumulative step times:", " ".join(f"{t:.3f}" for t in per_step), file=sys.stderr, flush=True)
     t_enqueued = time.perf_counter() - t0   # host time to enqueue the steps (stderr only): ~= elapsed means launch-bound
+    if tl is not None:
+        torch.cuda.synchronize()
+        tl.steps = tl.steps[args.warmup:]
+        print("[bench] timeline (mean ms from step start): " + ", ".join(f"{n} {t:.2f}" for n, t in tl.report()), file=sys.stderr, flush=True)
+        tl = dual.timeline = None
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -623,6 +682,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if isinstance(loss, tuple):   # decoupled streams: the four loss parts, read after the synchronisation above
+        loss = sum(t.float() for t in loss)
     assert torch.isfinite(loss).item(), "loss is not finite"
     host_value = None
     if host_batches is not None:   # same step, inputs handed over as host tensors (not part of `value`)
