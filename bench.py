@@ -405,6 +405,14 @@ def main():
             bt["vgi_proj"] = np.array([[1266.0, 800.0, 0, 0], [0, 450.0, -1266.0, 0], [0, 1, 0, 0]], np.float64)
         batches.append(bt)
 
+    # what an empty event bracket reads on this box (median of 100, idle stream): context for the launch times below
+    torch.cuda.synchronize()
+    _ev = []
+    for _ in range(100):
+        _s, _e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _s.record(); _e.record(); _ev.append((_s, _e))
+    torch.cuda.synchronize()
+    bracket_overhead_us = round(sorted(a.elapsed_time(b) * 1e3 for a, b in _ev)[50], 2)
     timer = ConvTimer()
     timer.install()
     timer2d = Conv2dTimer()
@@ -739,6 +747,11 @@ def main():
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
+                    "event_bracket_overhead_us": bracket_overhead_us,   # an EMPTY HIP-event bracket on the idle stream, measured at start-up
+                    "note": ("HIP-event brackets measure from the retirement of the stream's previous packet to the end of the kernel: under "
+                             "the three-stream overlap they include the launch gap in front of the kernel (command-processor arbitration, "
+                             "waiting for free CUs), which rocprofv3's kernel durations of the same command do not "
+                             "(profiles/r2_final_joint_kernel_stats.md: ~10 % shorter)"),
                     "direct_conv_equivalent_tflops": round(k2["tflops_direct"], 1),   # NOT the roofline figure: what a direct 3x3 conv would have to sustain for the same launch times (Winograd executes 2.25x / 4x fewer flops)
                     "stream_configuration": "as timed for `value`: 2D main stream + " +
                                             ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
