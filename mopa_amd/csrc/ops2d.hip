@@ -316,15 +316,19 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     partial[(int64_t)blockIdx.x * C + c] = t;
   }
 }
+// one block of 256 per column (like k_bn_finalize): <= 8 independent partial loads per thread, wave sums in double, the four wave
+// sums added in order.  (16 blocks of one wave per column walked the partials 32 deep: 28 us of latency per call.)
 __global__ __launch_bounds__(256) void k_colsum_reduce(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
                                                         int accumulate) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = blockIdx.x * 4 + wv; c < C; c += gridDim.x * 4) {
-    double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += (double)partial[(int64_t)b * C + c];
-    s = wave_sum_d(s);
-    if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
-  }
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+#pragma unroll 8
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(int64_t)b * C + c];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)(((red[0] + red[1]) + red[2]) + red[3]);
 }
 static inline int colsum_rows(int64_t num_rows) {
   int64_t r = cdiv64(num_rows, 2048);
@@ -344,7 +348,7 @@ MOPA_API int mopa_colsum(const float* x, int32_t ld, int64_t num_rows, int32_t C
   const int nblk = (int)cdiv64(num_rows, rpb);
   const int RL = 256 / (C >> 2);
   k_colsum_partial<<<nblk, 256, (size_t)RL * C * sizeof(float), st>>>(x, ld, (int)num_rows, C, rpb, (float*)ws);
-  k_colsum_reduce<<<16, 256, 0, st>>>((const float*)ws, nblk, C, out, accumulate);
+  k_colsum_reduce<<<C, 256, 0, st>>>((const float*)ws, nblk, C, out, accumulate);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
