@@ -219,11 +219,14 @@ def test_dual_stream_is_bit_identical_to_sequential():
             else:
                 p2, p3 = dual.forward(m2, m3, b, b, inputs_ready=ready if ahead else None)
             l2 = seg_ce(p2["seg_logit"], lab) + xm_kl(p2["seg_logit2"], p3["seg_logit"])
-            if ahead == "side_loss":   # 3D losses on the side stream: the whole 3D backward is queued there, 2D backward first
+            if ahead in ("side_loss", "side_backward"):   # 3D losses on the side stream: the whole 3D backward is queued there
                 with dual.on_side(p2["seg_logit"]):
                     l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
                 l2.backward()
-                l3.backward()
+                if ahead == "side_backward":   # bench.py's order: backward() called with the side stream current (no hidden join)
+                    dual.backward_on_side(l3)
+                else:
+                    l3.backward()
             else:
                 l3 = seg_ce(p3["seg_logit"], lab) + xm_kl(p3["seg_logit2"], p2["seg_logit"])
                 if ahead:   # 3D backward first: it runs on the side stream beside the 2D backward
@@ -251,6 +254,11 @@ def test_dual_stream_is_bit_identical_to_sequential():
     g_side, e = run(DualStream("cuda", order_2d_first=True), ahead="side_loss")
     assert a == e
     assert all(torch.equal(x, y) for x, y in zip(g_seq, g_side))
+    # ... and the 3D loss's backward called with the side stream current (DualStream.backward_on_side): the main stream is never
+    # made to wait for the 3D backward inside the iteration (the final join above is the only one)
+    g_sb, f = run(DualStream("cuda", order_2d_first=True), ahead="side_backward")
+    assert a == f
+    assert all(torch.equal(x, y) for x, y in zip(g_seq, g_sb))
 
 
 def test_geometry_built_ahead_on_the_side_stream_gives_the_same_results():
