@@ -44,6 +44,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (dense)
 CLASS_WEIGHTS = [2.68678412, 4.36182969, 5.47896839, 3.89026883, 1.0]  # configs/nuscenes/usa_singapore yaml:54
+CLASS_WEIGHTS_KITTI = [1.89090012, 2.0585112, 3.1970535, 3.1111633, 1., 2.93751704, 1.92053733,
+                       1.47886874, 1.04654198, 1.78266561]              # configs/a2d2_semantic_kitti/xmuda.yaml:42-43
 
 
 def parse():
@@ -51,9 +53,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="joint", choices=["joint", "3d", "mopa"],
-                    help="joint = BASELINE configs[2] (default), 3d = configs[1], mopa = configs[3] per-GPU step")
-    ap.add_argument("--batch", type=int, default=None, help="scans per domain per GPU (default 8; 4 for mopa)")
+    ap.add_argument("--workload", default="joint", choices=["joint", "3d", "mopa", "kitti"],
+                    help="joint = BASELINE configs[2] (default), 3d = configs[1], mopa = configs[3] per-GPU step, "
+                         "kitti = configs[4] per-GPU step (A2D2->SemanticKITTI shape: 120,000-pt scans, 10 classes, joint 2D+3D)")
+    ap.add_argument("--batch", type=int, default=None, help="scans per domain per GPU (default 8; 4 for mopa; 2 for kitti)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -165,6 +168,11 @@ class Conv2dTimer:
     summary = ConvTimer.summary
 
 
+def f4_roles():
+    from mopa_amd import dense2d
+    return tuple(dense2d.F4_ROLES)
+
+
 def dense2d_streams():
     """True when the 2D weight gradients run on their own stream in this process (mopa_amd/dense2d.py::wgrad_stream)."""
     from mopa_amd import dense2d
@@ -186,7 +194,7 @@ def _cpu_passes(one_pass, seconds_budget, max_passes, what):
                        f"median {med:.2f} s, min {min(times):.2f} s per scan")
 
 
-def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
+def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0, shape=None):
     """CPU restatement (oracle, kind 'port') of one scan of the joint step: 2D + 3D forward/backward + CE/KL losses."""
     from mopa_amd import synth
     from oracle import losses as ol
@@ -196,7 +204,8 @@ def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(ncpu, 32)))
-    s = synth.make_scan(4242)
+    shape = shape or synth.NUSCENES
+    s = synth.make_scan(4242, shape=shape)
     coords = np.concatenate([s["coords"], np.zeros((len(s["coords"]), 1), np.int64)], 1)
     P2 = {k: v.detach().cpu().clone() for k, v in model2d.state_dict().items()}
     P3 = {k: v.detach().cpu().float().clone() for k, v in scn3d.fold_state_dict(model3d.state_dict()).items()}
@@ -219,7 +228,7 @@ def cpu_baseline_joint(model2d, model3d, seconds_budget=25.0):
         return time.time() - t0
 
     return _cpu_passes(one_pass, seconds_budget, 10,
-                       "1 synthetic scan: 302x480 image + 34,880 pts, Net2DSeg+Net3DSeg fwd+bwd+CE+KL, torch-CPU fp32 oracle")
+                       f"1 synthetic scan: 302x480 image + {len(coords):,} pts, Net2DSeg+Net3DSeg fwd+bwd+CE+KL, torch-CPU fp32 oracle")
 
 
 def cpu_baseline_3d(model, seconds_budget=25.0):
@@ -255,6 +264,14 @@ def launch_ranks(args) -> int:
     Nothing in this process has touched the GPU (no HIP call is made by importing torch), so the children own the devices."""
     import socket
     import subprocess
+    # preflight (device_count() does not initialise the GPU): RCCL wants one device per rank, and a launcher that starts more ranks
+    # than there are devices fails late and obscurely inside init_process_group
+    if os.environ.get("MOPA_BENCH_DRY") != "1" and os.environ.get("MOPA_BENCH_BACKEND", "nccl") == "nccl":
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"[bench] --gpus {args.gpus} needs {args.gpus} visible devices, this node has {ndev} "
+                  "(set MOPA_BENCH_BACKEND=gloo to run several ranks on one device as a plumbing test)", file=sys.stderr, flush=True)
+            return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -335,12 +352,16 @@ def main():
     from mopa_amd.optim import FlatAdam
     from mopa_amd.sparse3d import Geometry3D
 
-    joint = args.workload in ("joint", "mopa")
+    joint = args.workload in ("joint", "mopa", "kitti")
     mopa = args.workload == "mopa"
+    kitti = args.workload == "kitti"
     if args.batch is None:
-        args.batch = 4 if mopa else 8
+        args.batch = 4 if mopa else 2 if kitti else 8
+    shape = synth.KITTI if kitti else synth.NUSCENES     # 64 beams x 1875 azimuths = 120,000 pts vs 32 x 1090 = 34,880
+    NC = shape["classes"]
+    lam_src, lam_trg = (0.1, 0.01) if kitti else (1.0, 0.1)   # lambda_xm_src / _trg: a2d2_semantic_kitti yaml :54-55, nuscenes :56-57
     torch.manual_seed(1 + rank)
-    cfg = default_cfg(num_classes=5, dual_head=True)
+    cfg = default_cfg(num_classes=NC, dual_head=True)
     model3d, _ = build_model_3d(cfg)
     model3d = model3d.to(dev).train()
     models = [model3d]
@@ -353,7 +374,7 @@ def main():
             for p in m.parameters():
                 dist.broadcast(p.data, 0)
     opts = [FlatAdam(m.parameters(), lr=1e-3) for m in models]
-    cw = torch.tensor(CLASS_WEIGHTS, device=dev)
+    cw = torch.tensor(CLASS_WEIGHTS_KITTI if kitti else CLASS_WEIGHTS, device=dev)
     H, W = 302, 480
 
     # ---- synthetic batches, resident in HBM before timing.  joint: [source, target] of one xMUDA iteration;
@@ -364,9 +385,9 @@ def main():
         scans = []
         for i in range(B):
             seed = 1000 * rank + j * B + i
-            pts = synth.lidar_points(seed)
+            pts = synth.lidar_points(seed, shape)
             rng = np.random.Generator(np.random.PCG64(99 + seed))
-            lab = rng.integers(0, 5, len(pts)).astype(np.int64)
+            lab = rng.integers(0, NC, len(pts)).astype(np.int64)
             lab[rng.random(len(pts)) < 0.1] = -100
             scans.append((synth.voxelize(pts), lab, rng))
         locs = torch.cat([torch.cat([torch.from_numpy(c), torch.full((len(c), 1), i, dtype=torch.int64)], 1)
@@ -559,7 +580,10 @@ def main():
 
     host_delay = float(os.environ.get("MOPA_BENCH_HOST_DELAY_MS", "0")) * 1e-3   # diagnostics: is the step host-paced?
 
+    steps_run = [0]
+
     def step(i, host_fed=False):
+        steps_run[0] += 1
         if host_delay:
             time.sleep(host_delay)
         if tl is not None:
@@ -577,11 +601,11 @@ def main():
             d0, e0 = stage(host_batches[0])
             d1, e1 = stage(host_batches[1])   # in flight while the source half computes
             torch.cuda.current_stream(dev).wait_event(e0)
-            pa = half(d0, 1.0, True, ready=e0)
+            pa = half(d0, lam_src, True, ready=e0)
             torch.cuda.current_stream(dev).wait_event(e1)
-            parts = pa + half(d1, 0.1, False, ready=e1)
+            parts = pa + half(d1, lam_trg, False, ready=e1)
         elif joint:
-            parts = half(batches[0], 1.0, True) + half(batches[1], 0.1, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
+            parts = half(batches[0], lam_src, True) + half(batches[1], lam_trg, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
             if multi and overlap_3d and not host_fed:
                 # the 3D network's gradients are complete when the side stream drains: reduce them there, under the tail of the
                 # 2D backward on the main stream (RCCL orders its own stream behind the stream current at the call)
@@ -759,6 +783,9 @@ def main():
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
               "Valid Ground-based Insertion of a 500-pt object per target scan on the device (overlap test, ground cells, "
               "range-image culling, re-voxelisation) + third 3D pass on that batch, backward, Adam") if mopa else (
+              "A2D2->SemanticKITTI-shape joint step per GPU (BASELINE configs[4]): "
+              f"{B} source + {B} target scans/GPU per step, 120,000 pts/scan (64 beams x 1875 azimuths, scale 20), 10 classes, "
+              "Net2DSeg(UNetResNet34, 302x480) + Net3DSeg(SCN UNet), CE + cross-modal KL, backward, Adam") if kitti else (
               "Full xMUDA 2D+3D joint step + xModalKL (BASELINE configs[2]): "
               f"{B} source + {B} target scans/GPU per step, Net2DSeg(UNetResNet34, 302x480) + Net3DSeg(SCN UNet, 34,880 pts), "
               "CE + cross-modal KL, backward, Adam") if joint else (
@@ -770,9 +797,16 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "scans_per_step_per_gpu": scans_per_step, "global_batch": scans_per_step * world,
-                       "points_per_scan": 34880, "image": "302x480", "parallelism": f"dp{world}",
+                       "points_per_scan": shape["beams"] * shape["azimuths"], "num_classes": NC, "image": "302x480",
+                       "parallelism": f"dp{world}",
                        "collective": "one flat fp32 gradient all-reduce per network per step (RCCL), 3D one overlapped with the 2D backward"
-                       if world > 1 else "none (1 rank)"},
+                       if world > 1 else ("one-rank process group, same collectives (MOPA_FORCE_COLLECTIVES=1)" if multi else "none (1 rank)"),
+                       # what actually ran: backend of the process group, all-reduces issued per timed + warm-up step (FlatAdam counts
+                       # them), and which passes of the stride-1 3x3 convolutions use Winograd F(4x4) (fp32, ~1e-5 relative per
+                       # layer; "dgrad,wgrad" = exact-product forward pass)
+                       "backend": (dist.get_backend() if multi else None),
+                       "allreduces_per_step": round(sum(o.n_collectives for o in opts) / max(1, steps_run[0]), 2),
+                       "winograd_f4_roles": ",".join(f4_roles()) if joint else None},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "value_with_host_inputs": None if host_value is None else round(host_value[0], 3),
             "host_inputs_note": None if host_value is None else (
@@ -784,7 +818,7 @@ def main():
         print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s (host enqueue {t_enqueued:.3f}s)", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only
             t_cpu = time.perf_counter()
-            line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d) if joint else cpu_baseline_3d(model3d)
+            line["cpu_baseline"] = cpu_baseline_joint(model2d, model3d, shape=shape) if joint else cpu_baseline_3d(model3d)
             print(f"[bench] cpu baseline took {time.perf_counter() - t_cpu:.1f}s", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if multi:

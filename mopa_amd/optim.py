@@ -57,6 +57,8 @@ class FlatAdam(torch.optim.Optimizer):
                 off += sz
         self._attach_grads()
         self.t = 0
+        self.n_collectives = 0        # all-reduces issued so far, and the backend of the last one (bench.py / tests report them)
+        self.collective_backend = None
         self._ckpt_shapes = list(checkpoint_shapes) if checkpoint_shapes is not None else [None] * len(params)
         if len(self._ckpt_shapes) != len(params):
             raise ValueError("checkpoint_shapes must have one entry per trainable parameter")
@@ -82,17 +84,20 @@ class FlatAdam(torch.optim.Optimizer):
     def _check_grads(self):
         """Every ``p.grad`` must still be the view of the flat gradient buffer the HIP kernels accumulate into.
         ``model.zero_grad()`` (torch's default sets grads to None) or a hook that replaces ``.grad`` would otherwise make
-        ``step`` and ``all_reduce`` read a stale flat buffer without any error: a detached gradient is folded back in and
-        the view is re-attached."""
+        ``step`` and ``all_reduce`` read a stale flat buffer without any error.  A detached slice is STALE -- whoever dropped
+        the view meant "zero", and nothing has accumulated into the slice since -- so the parameter's own ``.grad`` is the
+        truth: its value replaces the slice (``None`` = no gradient this iteration = zeros), and the view is re-attached."""
         for i, (p, gv) in enumerate(zip(self.params, self._gviews)):
             g = p.grad
             if g is gv:      # autograd accumulates in place: the tensor object we attached is still the gradient (~0.1 us per check)
                 continue
             view = self._gviews[i] = self._grad_view(i)
-            if g is not None:   # autograd attached a fresh tensor after the view was dropped: keep what it accumulated
+            if g is None:
+                view.zero_()
+            else:               # autograd attached a fresh tensor after the view was dropped: it holds everything accumulated since
                 if g.shape != p.shape:
                     raise RuntimeError("FlatAdam: a parameter's .grad was replaced by a tensor of another shape")
-                view.add_(g.to(view.dtype))
+                view.copy_(g)
             p.grad = view
 
     def zero_grad(self, set_to_none: bool = False):
@@ -106,6 +111,8 @@ class FlatAdam(torch.optim.Optimizer):
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
             self._check_grads()
             self._checked = True   # once per iteration (~0.1 ms of host time for 200 parameters)
+            self.n_collectives += 1
+            self.collective_backend = dist.get_backend()
             return dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=async_op)
         return None
 

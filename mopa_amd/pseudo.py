@@ -68,8 +68,13 @@ class FlatEMA:
 
     def state_dict(self):
         """Same keys as ``torch_ema.ExponentialMovingAverage.state_dict()`` (per-parameter shadow tensors), so EMA
-        checkpoints written by the reference's ``CheckpointerV2(..., ema=...)`` style code load here and vice versa."""
-        shadow = [self.shadow[off:off + n].view(p.shape).clone() for (off, n), p in zip(self.opt._slices, self.opt.params)]
+        checkpoints written by the reference's ``CheckpointerV2(..., ema=...)`` style code load here and vice versa.  The
+        shadow tensors take the optimizer's checkpoint shapes (SparseConvNet's 4-D conv-weight layout when ``FlatAdam`` was built
+        with ``checkpoint_shapes``), i.e. the shapes ``model.state_dict()`` saves -- a reference-side ``copy_to`` then pairs every
+        shadow tensor with a parameter of its own shape."""
+        shapes = getattr(self.opt, "_ckpt_shapes", [None] * len(self.opt.params))
+        shadow = [self.shadow[off:off + n].view(shp or p.shape).clone()
+                  for (off, n), p, shp in zip(self.opt._slices, self.opt.params, shapes)]
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": shadow, "collected_params": None}
 
     def load_state_dict(self, sd):

@@ -98,7 +98,7 @@ class Geometry3D:
         # grouped rulebooks (MFMA-ready 16-rule groups per 64-row tile) for ALL tables at once: tiles and groups are numbered
         # globally -- one count launch, one scan, ONE more host sync for the group total, one fill launch.  Built once per
         # geometry, used by every layer's fwd and bwd-data; a table's rulebook = its slice of the scan + the shared arrays.
-        self._rb = {}
+        self._rb, self._rb_cs = {}, {}
         tables = list(self.nbr27) + list(self.ch) + list(self.up)
         tile0, desc = [0], []
         for t in tables:
@@ -140,6 +140,15 @@ class Geometry3D:
     def rulebook(self, table: torch.Tensor):
         return self._rb.get(table.data_ptr())
 
+    def rulebook_cs(self, table: torch.Tensor, tile_rows: int):
+        """Grouped rulebook of `table` over 128- or 256-row tiles for the column-slice kernel (mopa_spconv_fwd_cs); built on first
+        use, arrays sized from mopa_rulebook_cs_group_bound (no host round trip)."""
+        key = (table.data_ptr(), tile_rows)
+        hit = self._rb_cs.get(key)
+        if hit is None:
+            hit = self._rb_cs[key] = build_rulebook_cs([table], tile_rows)[0]
+        return hit
+
     def tensors(self):
         """Every device tensor this geometry owns."""
         out = [self.point_row, self.row_start, self.row_points]
@@ -161,6 +170,33 @@ class Geometry3D:
     @property
     def num_rules(self):
         return [int((n >= 0).sum().item()) for n in self.nbr27]
+
+
+def build_rulebook_cs(tables, tile_rows: int):
+    """[(grp_start, grp_o, grp_in, grp_out)] per table: MFMA-ready 16-rule groups per `tile_rows`-row tile, ordered by filter
+    offset, every group tagged with the groups left in its (tile, offset) run.  All tables in one count / scan / fill chain."""
+    dev = tables[0].device
+    i32 = dict(dtype=torch.int32, device=dev)
+    st = stream()
+    tile0, desc, bound = [0], [], 0
+    for t in tables:
+        K, Ao = t.shape
+        desc += [t.data_ptr(), K, Ao, tile0[-1]]
+        tile0.append(tile0[-1] + (Ao + tile_rows - 1) // tile_rows)
+        bound += query("mopa_rulebook_cs_group_bound", K, Ao, tile_rows)
+    ntile = tile0[-1]
+    desc_h = torch.tensor(desc, dtype=torch.int64)
+    tg = torch.empty(ntile, **i32)
+    gs = torch.empty(ntile + 1, **i32)
+    call("mopa_rulebook_cs_count", desc_h.data_ptr(), len(tables), ntile, tile_rows, ptr(tg), st)
+    ws = _ws(query("mopa_scan_workspace_bytes", ntile), dev)
+    call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
+    bound = max(bound, 1)
+    go = torch.empty(bound, **i32)
+    gi = torch.empty(bound * 16, **i32)
+    gout = torch.empty(bound * 16, **i32)
+    call("mopa_rulebook_cs_fill", desc_h.data_ptr(), len(tables), ntile, tile_rows, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
+    return [(gs[tile0[i]:tile0[i + 1] + 1], go, gi, gout) for i in range(len(tables))]
 
 
 # --------------------------------------------------------------------------------------- kernels (thin wrappers)

@@ -65,10 +65,15 @@ def fwd(x, y, gamma, beta, rmean, rvar, momentum, eps, leak, act, res, stats):
     C = x.C
     group = _STATE["group"]
     world = dist.get_world_size(group)
+    gathered = torch.empty(world * (2 * C + 1), dtype=torch.float64, device=dev)   # [world][2C+1], flat for gloo's all_gather
+    if x.rows == 0:
+        # a rank without rows at this layer still takes part in the collective (moments with n = 0 are skipped by the Chan
+        # combination); raising here would leave the other ranks blocked in all_gather for ever
+        dist.all_gather_into_tensor(gathered, torch.zeros(2 * C + 1, dtype=torch.float64, device=dev), group=group)
+        return gathered
     ws = _ws(query("mopa_bnrelu_rows_workspace_bytes", x.rows, C), dev)
     mine = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
     call("mopa_bn_sync_moments", x.p, x.ld, x.rows, C, ptr(mine), ptr(ws), ws.numel(), stream())
-    gathered = torch.empty(world * (2 * C + 1), dtype=torch.float64, device=dev)   # [world][2C+1], flat for gloo's all_gather
     dist.all_gather_into_tensor(gathered, mine, group=group)
     call("mopa_bn_act_fwd_sync", x.p, x.ld, y.p, y.ld, x.rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
          leak, int(act), res.p if res is not None else None, res.ld if res is not None else 0, ptr(gathered), world, ptr(stats),
@@ -80,6 +85,12 @@ def bwd(dy, x, dx, stats, leak, act, ymask, dres, acc_dres, dgamma, dbeta, acc_p
     dev = x.t.device
     C = x.C
     group = _STATE["group"]
+    if x.rows == 0:   # no rows here: contribute zeros to the sums, nothing to apply (see fwd)
+        dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=dev), op=dist.ReduceOp.SUM, group=group)
+        if not acc_params:
+            dgamma.zero_()
+            dbeta.zero_()
+        return
     ws = _ws(query("mopa_bnrelu_rows_workspace_bytes", x.rows, C), dev)
     sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
     call("mopa_bn_sync_bwd_sums", dy.p, dy.ld, x.p, x.ld, x.rows, C, ptr(stats), leak, int(act),

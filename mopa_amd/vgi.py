@@ -157,13 +157,18 @@ def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, ob
     n0 = m.pts.shape[0]
     lab = torch.as_tensor(ori_label).to(dev)
     ext = np.array([np.linalg.norm(np.max(o, axis=0)[0:2] - np.min(o, axis=0)[0:2]) for o in obj_pc_ls])
-    for obj_idx in np.argsort(ext)[::-1]:
+    # ignore_idx_ls as the reference writes it (mixmatch_ss.py:123-196): a failed anchor attempt records its POSITION in the
+    # extent order; Step 4 skips the object whose LIST index equals a recorded position.  The random draws still cover every object.
+    ignore = []
+    for idx_i, obj_idx in enumerate(np.argsort(ext)[::-1]):
         obj = np.asarray(obj_pc_ls[obj_idx])
         fc = m.free_cells(obj[:, :3])
         if fc["free"] is None:
+            ignore.append(idx_i)
             continue
         cells, n_free, n_kept = m.ground_cells(fc, obj, proj_matrix, image_size)
         if n_free == 0 or n_kept == 0 or cells.shape[0] == 0:
+            ignore.append(idx_i)
             continue
         pick = np.random.choice(cells.shape[0], len(obj_pc_ls))          # mixmatch_ss.py:409
         new_pc, new_lab = [], []
@@ -177,6 +182,8 @@ def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, ob
             disc = np.array([d_r * np.cos(occ[1]), d_r * np.sin(occ[1]), 0])
             rot = np.array([[np.cos(d_theta), -np.sin(d_theta), 0, 0], [np.sin(d_theta), np.cos(d_theta), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
             disc[2] = m.road_height(cell) - np.min(o3[:, 2], axis=0) + np.random.rand() * 0.1   # :444-446
+            if i in ignore:
+                continue
             t = np.eye(4)
             t[:3, 3] = disc
             tr = rot @ t

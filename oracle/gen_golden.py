@@ -344,7 +344,11 @@ def vgi_case(k: int):
     ori_pc = np.concatenate([pts, rng.random((len(pts), 1), dtype=np.float32)], 1)   # (N, 4): xyz + intensity
     g_mask = pts[:, 2] < -1.7
     objs, labs = [], []
-    for j, (size, c) in enumerate((((4.2, 1.8, 1.5), (6.0, 9.0, -1.0)), ((0.8, 0.8, 1.7), (-3.0, 5.0, -0.9)))):
+    shapes = (((4.2, 1.8, 1.5), (6.0, 9.0, -1.0)), ((0.8, 0.8, 1.7), (-3.0, 5.0, -0.9)))
+    if k == 2:   # the object with the LARGEST extent (list index 1) fits nowhere: the first anchor attempt fails and the reference's
+        # ignore_idx_ls bookkeeping (positions in extent order used as list indices, mixmatch_ss.py:123-196) decides what is inserted
+        shapes = (shapes[0], ((22.0, 20.0, 1.5), (1.0, 14.0, -1.0)), shapes[1])
+    for j, (size, c) in enumerate(shapes):
         n = 400 + 150 * j
         o = (rng.random((n, 3)) - 0.5) * np.array(size) + np.array(c)
         if front == "x":
@@ -383,7 +387,7 @@ def gen_g8():
     from mopa.data.utils.augmentation_3d import range_projection  # reference
 
     save = {}
-    for k in range(2):
+    for k in range(3):
         c = vgi_case(k)
         # (a) candidate centres of the larger object
         vc = ref.check_overlap(c["ori_pc"], c["objs"][0][:, :3], voxel_size=0.5, search_range=[25.0, 25.0], z_min=-2.0,

@@ -99,6 +99,19 @@ def test_flat_adam_keeps_working_when_grads_are_set_to_none():
     opt._check_grads()
     assert torch.equal(opt.grad[:12], torch.full((12,), 2.0)) and torch.equal(opt.grad[12:17], torch.full((5,), 3.0))
     assert all(p.grad.data_ptr() == opt.grad.data_ptr() + 4 * opt._slices[i][0] for i, p in enumerate(ps))
+    # second iteration, again cleared through the model only (the stale slice must not be added to the new gradient)
+    for p in ps:
+        p.grad = None
+    (ps[0].sum() * 5).backward()      # ps[1] gets no gradient at all this time
+    opt._check_grads()
+    assert torch.equal(opt.grad[:12], torch.full((12,), 5.0)) and torch.equal(opt.grad[12:17], torch.zeros(5))
+    # two backward passes into a detached gradient accumulate in the fresh tensor; the slice takes their sum once
+    for p in ps:
+        p.grad = None
+    (ps[0].sum() * 1).backward()
+    (ps[0].sum() * 2 + ps[1].sum()).backward()
+    opt._check_grads()
+    assert torch.equal(opt.grad[:12], torch.full((12,), 3.0)) and torch.equal(opt.grad[12:17], torch.ones(5))
 
 
 def test_2d_state_dict_is_plain_torch_layout():
@@ -120,3 +133,11 @@ def test_flat_ema_state_dict_has_torch_ema_keys():
     ema2 = FlatEMA(FlatAdam([torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5))]), 0.5)
     ema2.load_state_dict(sd)
     assert ema2.num_updates == 7 and ema2.decay == 0.99 and torch.equal(ema2.shadow, ema.shadow)
+    # with checkpoint shapes (SparseConvNet's 4-D conv weights) the shadow tensors are saved in those shapes and load back
+    opt3 = FlatAdam([torch.nn.Parameter(torch.randn(27, 4, 3)), torch.nn.Parameter(torch.randn(5))], checkpoint_shapes=[(27, 1, 4, 3), None])
+    ema3 = FlatEMA(opt3, 0.9)
+    sd3 = _save_load(ema3.state_dict())
+    assert [tuple(t.shape) for t in sd3["shadow_params"]] == [(27, 1, 4, 3), (5,)]
+    ema3.shadow.zero_()
+    ema3.load_state_dict(sd3)
+    assert torch.equal(ema3.shadow, opt3.flat)

@@ -261,6 +261,56 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training, 
                 np.testing.assert_allclose(sd[k].cpu().numpy(), P[k].float().numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_net3dseg_equals_dense_network():
+    """The HIP path against the SECOND, independent oracle (oracle/dense3d.py): the whole 7-level Net3DSeg executed as dense
+    conv3d / conv_transpose3d / masked batch-norm on a 64^3 grid, driven by the reference's recorded layer graph (fixture G6) --
+    no hashes, no row orders, no rule tables in the checker.  Logits, parameter gradients and running statistics; the yardstick is
+    the same dense network in fp32 against itself in fp64."""
+    from oracle import dense3d
+    c, feats64 = dense3d.dense_case()
+    feats = feats64.float()
+    model = _build_3d(7).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
+    rng = np.random.Generator(np.random.PCG64(5))
+    f_dev = feats.cuda()
+    out = model({"x": [torch.from_numpy(c), f_dev]})
+    gouts = {k: torch.from_numpy(rng.standard_normal(tuple(out[k].shape), dtype=np.float32)) for k in ("seg_logit", "seg_logit2")}
+    sum((out[k] * gouts[k].cuda()).sum() for k in gouts).backward()
+
+    def dense(dtype):
+        P = {k: v.to(dtype).clone() for k, v in sd0.items()}
+        for k in P:
+            if "running" not in k:
+                P[k].requires_grad_(True)
+        stats = {}
+        o = dense3d.net3dseg_dense(P, c, feats.to(dtype), 64, stats=stats)
+        sum((o[k] * gouts[k].to(dtype)).sum() for k in gouts).backward()
+        return P, o, stats
+
+    P, ref, stats = dense(torch.float64)
+    P32, ref32, _ = dense(torch.float32)
+
+    def close(got, truth, yard, what):
+        scale = max(1e-6, float(np.abs(truth).max()))
+        err, yerr = float(np.abs(got - truth).max()), float(np.abs(yard - truth).max())
+        assert err <= max(4.0 * yerr, 2e-4 * scale), (what, err, yerr, scale)
+        assert err <= 1e-2 * scale, (what, err, scale)
+
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        close(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), ref32[k].detach().double().numpy(), k)
+    named = dict(model.named_parameters())
+    for k, p in P.items():
+        if p.requires_grad:
+            g = named[k].grad.cpu().numpy().reshape(p.shape)
+            close(g, p.grad.numpy(), P32[k].grad.double().numpy(), k)
+    sd = scn3d.fold_state_dict(model.state_dict())
+    for name, (mean, var, n) in stats.items():   # running = 0.9 * old + 0.1 * (batch mean, unbiased batch variance)
+        np.testing.assert_allclose(sd[name + ".running_mean"].cpu().numpy(), (0.9 * sd0[name + ".running_mean"].double() + 0.1 * mean).numpy(),
+                                   rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sd[name + ".running_var"].cpu().numpy(),
+                                   (0.9 * sd0[name + ".running_var"].double() + 0.1 * var * n / max(n - 1, 1)).numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_net3dseg_duplicate_points_and_extra_feature_rows():
     # nuScenes quirk (Appendix B.8): more feature rows than coords; and every point duplicated once.
     c = _cloud(9, n=800, size=24)

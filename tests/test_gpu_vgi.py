@@ -20,7 +20,7 @@ def _case(k):
     return vgi_case(k)
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("k", [0, 1, 2])
 def test_overlap_test_is_bit_exact_with_the_reference(g8, k):
     from mopa_amd import vgi
     c = _case(k)
@@ -35,7 +35,7 @@ def test_overlap_test_is_bit_exact_with_the_reference(g8, k):
     assert int(m.status.item()) == 0
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("k", [0, 1, 2])
 def test_ground_insertion_matches_the_reference(g8, k):
     from mopa_amd import vgi
     from oracle import vgi as ovgi
@@ -62,7 +62,7 @@ def test_ground_insertion_matches_the_reference(g8, k):
     assert torch.equal(cat_pc[:n0].cpu(), torch.from_numpy(c["ori_pc"][:, :3]).double())
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("k", [0, 1, 2])
 def test_range_image_culling_and_post_process_bit_exact(g8, k):
     from mopa_amd import vgi
     c = _case(k)

@@ -121,3 +121,55 @@ def test_g7_synthetic_pins(golden_dir):
     g = scn3d.Geometry(c)
     assert g.num_active == pins["active"] and g.num_rules == pins["rules"]
     assert c.shape[0] == pins["n_points"] == 34880
+
+
+from oracle.dense3d import dense_case as _dense_case  # noqa: E402
+
+
+def _net3d_params(dtype=torch.float64, num_classes=5):
+    from oracle.params import det_state
+    shapes = scn3d.unet_param_shapes(1, 16, 7, prefix="net_3d.sparseModel.")
+    shapes.update({"linear.weight": (num_classes, 16), "linear.bias": (num_classes,),
+                   "linear2.weight": (num_classes, 16), "linear2.bias": (num_classes,)})
+    P = det_state(shapes, dtype=dtype)
+    for k, v in P.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    return P
+
+
+def test_unet_equals_dense_network():
+    """The whole Net3DSeg (7 levels, the shipped hyper-parameters) of oracle/scn3d.py == the same network executed as DENSE torch
+    ops (oracle/dense3d.py: conv3d / conv_transpose3d / masked batch-norm driven by the reference's own recorded layer graph,
+    fixture G6) -- logits, BatchNorm batch statistics and every parameter gradient, in float64.  Two unrelated formulations
+    (rule tables + canonical rows vs dense grids); this does not pin SparseConvNet, it removes 'one author, one restatement'."""
+    from oracle import dense3d
+    c, feats = _dense_case()
+    g = scn3d.Geometry(c, num_levels=7, full_scale=64)
+    assert g.num_active[6] >= 1 and g.num_active[0] < c.shape[0]       # all 7 levels populated, duplicate points present
+    up1 = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).standard_normal((c.shape[0], 5)))
+    up2 = torch.from_numpy(np.random.Generator(np.random.PCG64(4)).standard_normal((c.shape[0], 5)))
+
+    Pa, Pb = _net3d_params(), _net3d_params()
+    oa = scn3d.net3dseg_forward(Pa, g, feats, training=True)
+    stats = {}
+    ob = dense3d.net3dseg_dense(Pb, c, feats, 64, stats=stats)
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        np.testing.assert_allclose(oa[k].detach().numpy(), ob[k].detach().numpy(), rtol=1e-9, atol=1e-10)
+    ((oa["seg_logit"] * up1).sum() + (oa["seg_logit2"] * up2).sum()).backward()
+    ((ob["seg_logit"] * up1).sum() + (ob["seg_logit2"] * up2).sum()).backward()
+    worst = 0.0
+    for k in Pa:
+        if Pa[k].requires_grad:
+            ga, gb = Pa[k].grad, Pb[k].grad
+            assert ga is not None and gb is not None, k
+            scale = float(gb.abs().max()) + 1e-30
+            worst = max(worst, float((ga - gb).abs().max()) / scale)
+    assert worst < 1e-8, worst
+    # running statistics of the sparse oracle == 0.9 * init + 0.1 * (batch mean, UNBIASED batch variance) of the dense network
+    P0 = _net3d_params()
+    for name, (mean, var, n) in stats.items():
+        np.testing.assert_allclose(Pa[name + ".running_mean"].numpy(), (0.9 * P0[name + ".running_mean"] + 0.1 * mean).numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(Pa[name + ".running_var"].numpy(),
+                                   (0.9 * P0[name + ".running_var"] + 0.1 * var * n / max(n - 1, 1)).numpy(), rtol=1e-9, atol=1e-12)
+    assert len(stats) == 26
