@@ -434,6 +434,8 @@ def main():
         _s.record(); _e.record(); _ev.append((_s, _e))
     torch.cuda.synchronize()
     bracket_overhead_us = round(sorted(a.elapsed_time(b) * 1e3 for a, b in _ev)[50], 2)
+    from mopa_amd import sparse3d as sparse3d_mod
+    native_default = sparse3d_mod.NATIVE
     timer = ConvTimer()
     timer.install()
     timer2d = Conv2dTimer()
@@ -681,9 +683,12 @@ def main():
     for i in range(args.steps):
         timer.enabled = timer2d.enabled = ev_stride > 0 and i % ev_stride == 0
         n_ev_steps += int(timer.enabled)
+        # a bracketed step walks the 3D layer program from Python (same kernels, same order, bit-identical: tests/test_gpu_3d.py) so
+        # that every sparse-conv launch can be bracketed; all other steps run it as one native call per pass (csrc/scn_exec.hip)
+        sparse3d_mod.NATIVE = native_default and not timer.enabled
         # the bracketed steps run in the SAME stream configuration as every other step (weight-gradient stream and 3D side stream
         # on): the brackets then time each launch as it runs inside `value`'s step, sharing the chip with the other streams --
-        # which is also what `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r2_final_*)
+        # which is also what `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r3_final_*)
         loss = step(i)
         if step_times:   # diagnostics only (stderr): host clock after each step, "sync" adds a device sync per step
             if step_times == "sync":
@@ -710,6 +715,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = timer2d.enabled = False
+    sparse3d_mod.NATIVE = native_default
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -744,21 +750,40 @@ def main():
                   "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
-        t3 = os.path.join(ROOT, "profiles", "r2_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d` (profiles/traffic.py)
+        # PMC traffic and rocprofv3 launch durations come from COMMITTED files (counters need rocprofv3 around the process): the
+        # files carry the commit they were taken at (profiles/collect_final.py), the line says so
+        wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
+        fam_path = os.path.join(ROOT, "profiles", "r3_rocprof_family.json")
+        famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
+        t3 = os.path.join(ROOT, "profiles", "r3_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d` (profiles/traffic.py)
         if sp and os.path.exists(t3):
             d3 = json.load(open(t3))
             fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
-                sp["traffic_source"] = "profiles/r2_3d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload 3d`, per launch)"
+                sp["traffic_source"] = ("profiles/r3_3d_hbm_traffic.json at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "`bench.py --workload 3d`, per launch)" % d3.get("_commit", "?"))
         if sp and joint:
-            sp["note"] = ("launch times include contention: the 3D branch runs on a second stream concurrently with the 2D "
-                          "branch; `--workload 3d` gives the isolated figure")
+            # inside the joint step the family shares the chip and its (lower-priority) side stream with the 2D GEMMs: an event
+            # bracket there is mostly queue wait, not kernel time.  `frac` is therefore NOT reported from it; see frac_rocprof (kernel
+            # durations of the same command) and `--workload 3d` for the uncontended figure
+            sp["frac_event_bracket_with_queue_wait"] = sp.pop("frac")
+            sp["achieved_event_bracket_with_queue_wait"] = sp.pop("achieved")
+            sp["frac"], sp["achieved"] = None, None
+            sp["note"] = ("the 3D branch runs on a second stream beside the 2D branch: HIP-event brackets on it include queue wait; frac / achieved "
+                          "are taken from rocprofv3 kernel durations (frac_rocprof) -- `--workload 3d` measures the family on its own")
+        rf = famj.get(wl_key, {}).get("sparse_conv")
+        if sp and rf:
+            gbs = sp["algorithmic_bytes_per_launch"] / (rf["avg_us"] * 1e-6) / 1e9
+            sp["frac_rocprof"], sp["avg_launch_us_rocprof"], sp["rocprof_commit"] = round(gbs / HBM_PEAK_GBS, 4), rf["avg_us"], famj.get("commit")
+            if sp.get("frac") is None:
+                sp["frac"], sp["achieved"] = sp["frac_rocprof"], round(gbs, 1)
         roof = sp
         k2 = timer2d.summary() if joint else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2_joint_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if joint and os.path.exists(tpath):                                  # of this same command (profiles/traffic.py)
+        tpath = os.path.join(ROOT, "profiles", f"r3_{wl_key}_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tj = {}
+        if joint and os.path.exists(tpath):                                      # of this same command (profiles/traffic.py)
             tj = json.load(open(tpath))
             fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out") if k in tj]
             if fam:
@@ -766,7 +791,7 @@ def main():
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r2_joint_hbm_traffic.json (PMC passes of this command; HBM bytes per launch)",
+                    "traffic_source": f"profiles/r3_{wl_key}_hbm_traffic.json at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
                     "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
@@ -775,10 +800,14 @@ def main():
                     "note": ("HIP-event brackets measure from the retirement of the stream's previous packet to the end of the kernel: under "
                              "the three-stream overlap they include the launch gap in front of the kernel (command-processor arbitration, "
                              "waiting for free CUs), which rocprofv3's kernel durations of the same command do not "
-                             "(profiles/r2_final_joint_kernel_stats.md: ~10 % shorter)"),
+                             "(profiles/r3_final_joint_kernel_stats.md; frac_rocprof below)"),
                     "direct_conv_equivalent_tflops": round(k2["tflops_direct"], 1),   # NOT the roofline figure: what a direct 3x3 conv would have to sustain for the same launch times (Winograd executes 2.25x / 4x fewer flops)
                     "stream_configuration": "as timed for `value`: 2D main stream + " +
                                             ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
+            rd = famj.get(wl_key, {}).get("dense_mfma")
+            if rd:   # the same flops over rocprofv3's kernel durations of this command (no launch gaps): the two figures bracket the truth
+                roof["frac_rocprof"] = round(roof["algorithmic_flops_per_launch"] / (rd["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4)
+                roof["avg_launch_us_rocprof"], roof["rocprof_commit"] = rd["avg_us"], famj.get("commit")
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
               "Valid Ground-based Insertion of a 500-pt object per target scan on the device (overlap test, ground cells, "
@@ -806,7 +835,9 @@ def main():
                        # layer; "dgrad,wgrad" = exact-product forward pass)
                        "backend": (dist.get_backend() if multi else None),
                        "allreduces_per_step": round(sum(o.n_collectives for o in opts) / max(1, steps_run[0]), 2),
-                       "winograd_f4_roles": ",".join(f4_roles()) if joint else None},
+                       "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
+                       "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
+                       else "python walk (MOPA_SCN_NATIVE=0)"},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "value_with_host_inputs": None if host_value is None else round(host_value[0], 3),
             "host_inputs_note": None if host_value is None else (
@@ -814,6 +845,7 @@ def main():
                 "numpy arrays (the reference's collate output), uploaded on a copy stream beside the compute; not part of `value`"),
             "roofline": roof,
             "roofline_sparse_conv": sp,
+            "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),   # caching-allocator high-water mark of this rank
         }
         print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s (host enqueue {t_enqueued:.3f}s)", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only

@@ -46,12 +46,10 @@ SIGNATURES = {
     "mopa_spconv_pack_weights_batched": ("i", "pip"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
-    # ---- sparse conv, column-slice kernel on 128 / 256-row tiles (spconv_cs.hip)
-    "mopa_rulebook_cs_group_bound": ("z", "iii"),
-    "mopa_rulebook_cs_count": ("i", "piiipp"),
-    "mopa_rulebook_cs_fill": ("i", "piiippppp"),
-    "mopa_spconv_cs_supported": ("i", "ii"),
-    "mopa_spconv_fwd_cs": ("i", "ppppiiipiipiipip"),
+    # ---- native executor of the 3D layer program (scn_exec.hip)
+    "mopa_scn_workspace_bytes": ("z", "pipii"),
+    "mopa_scn_forward": ("i", "pippppppzp"),
+    "mopa_scn_backward": ("i", "pipippppppppzp"),
     # ---- VGI (vgi.hip)
     "mopa_vgi_zslots": ("i", ""),
     "mopa_vgi_first_points": ("i", "piifiiiiipppp"),

@@ -181,7 +181,8 @@ class Net3DSeg(_CachedParams, nn.Module):
         return _Spec(order=order, prefix="net_3d.sparseModel.", in_channels=n.in_channels, m=n.m,
                      num_planes=n.num_planes, block_reps=n.block_reps, residual_blocks=n.residual_blocks,
                      num_classes=self.num_classes,
-                     dual_head=bool(self.dual_head))
+                     dual_head=bool(self.dual_head),
+                     native_holder=self._cache)   # the native executor's per-network state lives (and dies) with the parameter cache
 
     def forward(self, data_batch):
         dev = _require_cuda(self)

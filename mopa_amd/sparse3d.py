@@ -43,7 +43,8 @@ class Geometry3D:
     """Active sets + rule tables of one batch on the device (bit-exact with oracle.scn3d.Geometry).
 
     Built in two phases: (A) all levels' hashes/active sets chained on the device with
-    worst-case buffers, (B) ONE host sync to read the 7 row counts, then exact-size rule tables.
+    worst-case buffers, (B) ONE host sync to read the 7 row counts, then exact-size rule tables (the grouped rulebooks are
+    sized from a bound: no second round trip).
     """
 
     def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None):
@@ -96,9 +97,12 @@ class Geometry3D:
             self.ch.append(ch)
             self.up.append(up)
         # grouped rulebooks (MFMA-ready 16-rule groups per 64-row tile) for ALL tables at once: tiles and groups are numbered
-        # globally -- one count launch, one scan, ONE more host sync for the group total, one fill launch.  Built once per
-        # geometry, used by every layer's fwd and bwd-data; a table's rulebook = its slice of the scan + the shared arrays.
-        self._rb, self._rb_cs = {}, {}
+        # globally -- one count launch, one scan, one fill launch.  Built once per geometry, used by every layer's fwd and
+        # bwd-data; a table's rulebook = its slice of the scan + the shared arrays.  The arrays are sized from a BOUND, not from
+        # the scanned total (that was a second host round trip per geometry): every (tile, offset) pair wastes less than one
+        # group, so groups <= rules / 16 + tiles * K <= K * (rows / 16 + tiles) -- ~0.08 * K * rows entries of 132 bytes, a few
+        # times the exact size (tens of MB per geometry; the caching allocator re-uses the blocks step after step).
+        self._rb = {}
         tables = list(self.nbr27) + list(self.ch) + list(self.up)
         tile0, desc = [0], []
         for t in tables:
@@ -112,7 +116,7 @@ class Geometry3D:
         call("mopa_rulebook_groups_count_batched", desc_h.data_ptr(), len(tables), ntile, ptr(tg), st)
         ws = _ws(query("mopa_scan_workspace_bytes", ntile), device)
         call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
-        ng = max(int(gs[-1].item()), 1)  # second (and last) host sync
+        ng = max(sum(t.shape[0] * ((t.shape[1] + 15) // 16 + (t.shape[1] + 63) // 64) for t in tables), 1)
         go = torch.empty(ng, **i32)
         gi = torch.empty(ng * 16, **i32)
         gout = torch.empty(ng * 16, **i32)
@@ -125,6 +129,24 @@ class Geometry3D:
         ws = _ws(wsb, device)
         call("mopa_points_csr", ptr(self.point_row), N, A[0], ptr(self.row_start), ptr(self.row_points), ptr(ws),
              ws.numel(), st)
+
+    def desc(self) -> np.ndarray:
+        """The geometry as the host table mopa_scn_forward / _backward read (layout: csrc/scn_exec.hip, geom_host)."""
+        d = getattr(self, "_desc", None)
+        if d is None:
+            L = self.num_levels
+            d = np.zeros(8 + 8 * (L + 1), np.int64)
+            gs0, go, gi, gout = self._rb[self.nbr27[0].data_ptr()]
+            d[0:8] = (L, self.n_points, self.point_row.data_ptr(), self.row_start.data_ptr(), self.row_points.data_ptr(),
+                      go.data_ptr(), gi.data_ptr(), gout.data_ptr())
+            for l in range(L):
+                r = d[8 + 8 * l:16 + 8 * l]
+                r[0], r[1], r[2] = self.num_active[l], self.nbr27[l].data_ptr(), self._rb[self.nbr27[l].data_ptr()][0].data_ptr()
+                if l < L - 1:
+                    r[3], r[4] = self.ch[l].data_ptr(), self._rb[self.ch[l].data_ptr()][0].data_ptr()
+                    r[5], r[6] = self.up[l].data_ptr(), self._rb[self.up[l].data_ptr()][0].data_ptr()
+            self._desc = d
+        return d
 
     def rule_table(self, kind: str, l: int) -> torch.Tensor:
         """subm: 27 offsets at level l; down / up: the stride-2 tables between levels l and l + 1; nin: the identity rule
@@ -139,15 +161,6 @@ class Geometry3D:
 
     def rulebook(self, table: torch.Tensor):
         return self._rb.get(table.data_ptr())
-
-    def rulebook_cs(self, table: torch.Tensor, tile_rows: int):
-        """Grouped rulebook of `table` over 128- or 256-row tiles for the column-slice kernel (mopa_spconv_fwd_cs); built on first
-        use, arrays sized from mopa_rulebook_cs_group_bound (no host round trip)."""
-        key = (table.data_ptr(), tile_rows)
-        hit = self._rb_cs.get(key)
-        if hit is None:
-            hit = self._rb_cs[key] = build_rulebook_cs([table], tile_rows)[0]
-        return hit
 
     def tensors(self):
         """Every device tensor this geometry owns."""
@@ -170,33 +183,6 @@ class Geometry3D:
     @property
     def num_rules(self):
         return [int((n >= 0).sum().item()) for n in self.nbr27]
-
-
-def build_rulebook_cs(tables, tile_rows: int):
-    """[(grp_start, grp_o, grp_in, grp_out)] per table: MFMA-ready 16-rule groups per `tile_rows`-row tile, ordered by filter
-    offset, every group tagged with the groups left in its (tile, offset) run.  All tables in one count / scan / fill chain."""
-    dev = tables[0].device
-    i32 = dict(dtype=torch.int32, device=dev)
-    st = stream()
-    tile0, desc, bound = [0], [], 0
-    for t in tables:
-        K, Ao = t.shape
-        desc += [t.data_ptr(), K, Ao, tile0[-1]]
-        tile0.append(tile0[-1] + (Ao + tile_rows - 1) // tile_rows)
-        bound += query("mopa_rulebook_cs_group_bound", K, Ao, tile_rows)
-    ntile = tile0[-1]
-    desc_h = torch.tensor(desc, dtype=torch.int64)
-    tg = torch.empty(ntile, **i32)
-    gs = torch.empty(ntile + 1, **i32)
-    call("mopa_rulebook_cs_count", desc_h.data_ptr(), len(tables), ntile, tile_rows, ptr(tg), st)
-    ws = _ws(query("mopa_scan_workspace_bytes", ntile), dev)
-    call("mopa_scan_exclusive_i32", ptr(tg), ptr(gs), ntile, ptr(gs, ntile), ptr(ws), ws.numel(), st)
-    bound = max(bound, 1)
-    go = torch.empty(bound, **i32)
-    gi = torch.empty(bound * 16, **i32)
-    gout = torch.empty(bound * 16, **i32)
-    call("mopa_rulebook_cs_fill", desc_h.data_ptr(), len(tables), ntile, tile_rows, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
-    return [(gs[tile0[i]:tile0[i + 1] + 1], go, gi, gout) for i in range(len(tables))]
 
 
 # --------------------------------------------------------------------------------------- kernels (thin wrappers)
@@ -500,6 +486,47 @@ class Program:
         self._bwd = (out_ref, plan)
         return self._bwd
 
+    def native_tables(self):
+        """The program as the host tables of the native executor (csrc/scn_exec.hip): built once per program.
+        -> dict(prog int32 [n_ops][12], names [n_ops] (parameter prefix or None), stats_floats, plan int32 [n_steps][10],
+        stem_step (index of the stem convolution's plan step), out (buf, col, C), x0 (buf, col, C), bufs [(level, width)])."""
+        nt = getattr(self, "_native", None)
+        if nt is not None:
+            return nt
+        kinds = {"subm": 0, "down": 1, "up": 2, "nin": 3}
+        prog = np.zeros((len(self.ops), 12), np.int32)
+        names, stat_off = [], 0
+        for i, op in enumerate(self.ops):
+            if op[0] == "bn":
+                _, name, src, dst = op
+                prog[i] = (0, 0, src.level, dst.level, src.buf, src.col, src.C, dst.buf, dst.col, dst.C, stat_off, 0)
+                stat_off += 4 * src.C
+                names.append(name)
+            elif op[0] == "conv":
+                _, name, kind, l, src, dst = op
+                prog[i] = (1, kinds[kind], src.level, dst.level, src.buf, src.col, src.C, dst.buf, dst.col, dst.C, 0, 0)
+                names.append(name)
+            else:
+                _, a, b, dst = op
+                prog[i] = (2, 0, a.level, dst.level, a.buf, a.col, a.C, dst.buf, dst.col, dst.C, b.buf, b.col)
+                names.append(None)
+        index = {n: i for i, n in enumerate(names) if n is not None}
+        out_ref, steps = self.backward_plan()
+        plan = np.zeros((len(steps), 10), np.int32)
+        stem_step = -1
+        for j, st in enumerate(steps):
+            if st[0] == "bn":
+                _, name, src, dy, dx, acc = st
+                plan[j] = (0, index[name], dy[0], dy[1], dy[2], dx[0], dx[1], dx[2], int(acc), 0)
+            else:
+                _, name, kind, l, src, dout, dx = st
+                plan[j] = (1, index[name], dout[0], dout[1], dout[2], dx[0], dx[1], dx[2], 0, 0)
+                if src is self.x0:
+                    stem_step = j
+        self._native = dict(prog=prog, names=names, stats_floats=stat_off, plan=plan, stem_step=stem_step, out=out_ref,
+                            x0=(self.x0.buf, self.x0.col, self.x0.C), bufs=list(self.bufs))
+        return self._native
+
     def layer_sequence(self):
         """The arithmetic layers in execution order, in the vocabulary of tests/golden/g6_scn_structure.json."""
         seq = [["InputLayer", self.x0.C, self.x0.C, None, 0]]
@@ -523,6 +550,158 @@ def program_for(spec) -> Program:
     if key not in _programs:
         _programs[key] = Program(*key)
     return _programs[key]
+
+
+NATIVE = os.environ.get("MOPA_SCN_NATIVE", "1") != "0"   # A/B switch: the Python walk of the layer program (round 1-2)
+_IO = dict(TRAINING=0, EPOCH=1, FEATS=2, CIN=3, X0BUF=4, X0COL=5, OUTBUF=6, OUTCOL=7, M=8, NCLS=9, W1=10, B1=11, W2=12, B2=13, OFEATS=14,
+           L1=15, L2=16, STATS=17, MOMENTUM=18, EPS=19, LEAK=20, DFEATS_OUT=21, DL1=22, DL2=23, DFEATS_IN=24, DW1=25, DB1=26, DW2=27,
+           DB2=28, HEADS_ACC=29, N=30)
+
+
+def _f64_bits(x: float) -> int:
+    return int(np.float64(x).view(np.int64))
+
+
+class NativeState:
+    """What the native executor (csrc/scn_exec.hip) needs beside the program tables, per network instance: the parameter
+    pointer table, the derived weight forms (buffers + the caller-owned record of what they hold) and the weight epoch.
+    Lives on the module's parameter cache (dropped with it whenever the parameter objects may have changed)."""
+
+    def __init__(self, prog: Program, P: dict, device):
+        self.nt = prog.native_tables()
+        n = len(self.nt["names"])
+        self.params = np.zeros((n, 4), np.int64)
+        self.forms = np.zeros((n, 2, 3), np.int64)
+        self.forms[:, :, 1] = -1
+        self._form_bufs = []
+        for i, name in enumerate(self.nt["names"]):
+            if name is not None and self.nt["prog"][i, 0] == 1:
+                w = P[name + ".weight"]
+                for f in range(2):
+                    t = torch.empty(w.numel(), dtype=torch.float32, device=device)
+                    self._form_bufs.append(t)
+                    self.forms[i, f, 0] = t.data_ptr()
+        self.epoch, self._tag = 0, None
+        self.grads = np.zeros((n, 3), np.int64)
+        self._grad_key = None
+
+    def refresh(self, P: dict):
+        """Parameter addresses (FlatAdam re-points .data at its flat buffer) and the weight epoch of this pass."""
+        names, prog = self.nt["names"], self.nt["prog"]
+        versions = []
+        for i, name in enumerate(names):
+            if name is None:
+                continue
+            if prog[i, 0] == 0:
+                self.params[i] = (P[name + ".weight"].data_ptr(), P[name + ".bias"].data_ptr(),
+                                  P[name + ".running_mean"].data_ptr(), P[name + ".running_var"].data_ptr())
+            else:
+                w = P[name + ".weight"]
+                self.params[i, 0] = w.data_ptr()
+                versions.append(w._version)
+        tag = (_lib.WEIGHTS_EPOCH[0], tuple(versions), int(self.params[:, 0].sum()))
+        if tag != self._tag:
+            self._tag = tag
+            self.epoch += 1
+
+    def buffers(self, A, device, with_stats: bool):
+        """One arena for the pass: [nbufs][2] (pointer, row stride) + the tensor that owns the memory (+ stats pointer)."""
+        sizes = [(A[level] * width * 4 + 255) // 256 * 256 for level, width in self.nt["bufs"]]
+        extra = (self.nt["stats_floats"] * 4 + 255) // 256 * 256 if with_stats else 0
+        arena = torch.empty(sum(sizes) + extra, dtype=torch.uint8, device=device)
+        base = arena.data_ptr()
+        bufs = np.zeros((len(sizes), 2), np.int64)
+        off = 0
+        for b, (sz, (level, width)) in enumerate(zip(sizes, self.nt["bufs"])):
+            bufs[b] = (base + off, width)
+            off += sz
+        return bufs, arena, base + off
+
+
+def _native_forward(ctx, spec, geom, training, feats, flat, P, prog):
+    dev = geom.device
+    holder = spec.native_holder
+    nat = getattr(holder, "native", None)
+    if nat is None or nat.nt is not prog.native_tables():
+        nat = holder.native = NativeState(prog, P, dev)
+    nat.refresh(P)
+    nt = nat.nt
+    A, m, C, N = geom.num_active, spec.m, spec.num_classes, geom.n_points
+    gd = geom.desc()
+    bufs, arena, stats_ptr = nat.buffers(A, dev, True)
+    out_feats = torch.empty(N, m, dtype=torch.float32, device=dev)
+    l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
+    l2 = torch.empty(N, C if spec.dual_head else 0, dtype=torch.float32, device=dev)
+    io = np.zeros(_IO["N"], np.int64)
+    x0, out = nt["x0"], nt["out"]
+    io[[_IO["TRAINING"], _IO["EPOCH"], _IO["FEATS"], _IO["CIN"], _IO["X0BUF"], _IO["X0COL"], _IO["OUTBUF"], _IO["OUTCOL"], _IO["M"],
+        _IO["NCLS"]]] = (int(training), nat.epoch, feats.data_ptr(), spec.in_channels, x0[0], x0[1], out[0], out[1], m, C)
+    io[_IO["W1"]], io[_IO["B1"]] = P["linear.weight"].data_ptr(), P["linear.bias"].data_ptr()
+    if spec.dual_head:
+        io[_IO["W2"]], io[_IO["B2"]], io[_IO["L2"]] = P["linear2.weight"].data_ptr(), P["linear2.bias"].data_ptr(), l2.data_ptr()
+    io[_IO["OFEATS"]], io[_IO["L1"]], io[_IO["STATS"]] = out_feats.data_ptr(), l1.data_ptr(), stats_ptr
+    io[_IO["MOMENTUM"]], io[_IO["EPS"]], io[_IO["LEAK"]] = _f64_bits(BN_MOMENTUM), _f64_bits(BN_EPS), _f64_bits(LEAK)
+    key = (id(nt), C, m)
+    wsb = geom._ws_bytes.get(key) if hasattr(geom, "_ws_bytes") else None
+    if wsb is None:
+        if not hasattr(geom, "_ws_bytes"):
+            geom._ws_bytes = {}
+        wsb = geom._ws_bytes[key] = int(_lib.load().mopa_scn_workspace_bytes(nt["prog"].ctypes.data, len(nt["prog"]), gd.ctypes.data, C, m))
+    ws = _ws(wsb, dev)
+    call("mopa_scn_forward", nt["prog"].ctypes.data, len(nt["prog"]), nat.params.ctypes.data, nat.forms.ctypes.data, gd.ctypes.data,
+         bufs.ctypes.data, io.ctypes.data, ptr(ws), ws.numel(), stream())
+    ctx.native = (nat, bufs, arena, io, wsb)
+    return out_feats, l1, l2
+
+
+def _native_backward(ctx, dfeats, dl1, dl2):
+    spec, geom, P, prog = ctx.spec, ctx.geom, ctx.P, ctx.prog
+    nat, bufs, arena, io_f, wsb = ctx.native
+    nt = nat.nt
+    dev = geom.device
+    N, m, C = geom.n_points, spec.m, spec.num_classes
+    A = geom.num_active
+    sink = GradSink(P, spec.order)
+
+    def cont(t):
+        return None if t is None else t.contiguous().float()
+
+    dfeats, dl1 = cont(dfeats), cont(dl1)
+    dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
+    gbufs, garena, _ = nat.buffers(A, dev, False)
+    nat.refresh(P)
+    io = io_f.copy()
+    io[_IO["EPOCH"]] = nat.epoch
+    io[_IO["DFEATS_OUT"]], io[_IO["DL1"]], io[_IO["DL2"]] = ptr(dfeats) or 0, ptr(dl1) or 0, ptr(dl2) or 0
+    hnames = (["linear.weight", "linear.bias"] if dl1 is not None else []) + (["linear2.weight", "linear2.bias"] if dl2 is not None else [])
+    hg, hacc = sink.take(*hnames)
+    hg = dict(zip(hnames, hg))
+    for key, name in (("DW1", "linear.weight"), ("DB1", "linear.bias"), ("DW2", "linear2.weight"), ("DB2", "linear2.bias")):
+        io[_IO[key]] = ptr(hg.get(name)) or 0
+    io[_IO["HEADS_ACC"]] = int(hacc)
+    grads = nat.grads
+    prog_t = nt["prog"]
+    for i, name in enumerate(nt["names"]):
+        if name is None:
+            continue
+        if prog_t[i, 0] == 0:
+            (dg, db), acc = sink.take(name + ".weight", name + ".bias")
+            grads[i] = (dg.data_ptr(), db.data_ptr(), int(acc))
+        else:
+            (dw,), acc = sink.take(name + ".weight")
+            grads[i] = (dw.data_ptr(), 0, int(acc))
+    plan = nt["plan"]
+    dfeat_in = None
+    if ctx.feats_needs_grad:
+        dfeat_in = torch.zeros(N, spec.in_channels, dtype=torch.float32, device=dev)
+        io[_IO["DFEATS_IN"]] = dfeat_in.data_ptr()
+    elif nt["stem_step"] >= 0:
+        plan = plan.copy()
+        plan[nt["stem_step"], 9] = 1      # no gradient w.r.t. the input features: the stem's backward-data is skipped
+    ws = _ws(wsb, dev)
+    call("mopa_scn_backward", prog_t.ctypes.data, len(prog_t), plan.ctypes.data, len(plan), nat.params.ctypes.data, nat.forms.ctypes.data,
+         grads.ctypes.data, geom.desc().ctypes.data, bufs.ctypes.data, gbufs.ctypes.data, io.ctypes.data, ptr(ws), ws.numel(), stream())
+    return (None, None, None, dfeat_in) + sink.returned()
 
 
 class SCNNetFunction(torch.autograd.Function):
@@ -558,6 +737,15 @@ class SCNNetFunction(torch.autograd.Function):
         cin = spec.in_channels
         if feats.shape[1] != cin or feats.shape[0] < geom.n_points:
             raise RuntimeError(f"feats must be (>= {geom.n_points}, {cin}), got {tuple(feats.shape)}")
+        # the whole pass as ONE C-ABI call (csrc/scn_exec.hip); synchronised BatchNorm has collectives between its kernels and
+        # keeps the per-layer walk below
+        if NATIVE and getattr(spec, "native_holder", None) is not None and not (training and syncbn.active()):
+            out_feats, l1, l2 = _native_forward(ctx, spec, geom, training, feats, flat, P, prog)
+            ctx.spec, ctx.geom, ctx.training, ctx.prog = spec, geom, training, prog
+            ctx.P, ctx.out_feats = P, out_feats.detach()
+            ctx.feats_needs_grad = feats.requires_grad
+            return out_feats, l1, l2
+        ctx.native = None
         x0 = view(prog.x0)
         call("mopa_input_layer_fwd", ptr(feats), cin, ptr(geom.row_start), ptr(geom.row_points), A[0], x0.p, x0.ld,
              stream())
@@ -604,6 +792,8 @@ class SCNNetFunction(torch.autograd.Function):
     def backward(ctx, dfeats, dl1, dl2):
         if dfeats is None and dl1 is None and dl2 is None:   # nothing flows back (e.g. only used as a detached KL target)
             return (None,) * (4 + len(ctx.spec.order))
+        if ctx.native is not None:
+            return _native_backward(ctx, dfeats, dl1, dl2)
         spec, geom, P, prog, views = ctx.spec, ctx.geom, ctx.P, ctx.prog, ctx.views
         dev = geom.device
         N, m, C = geom.n_points, spec.m, spec.num_classes

@@ -145,13 +145,15 @@ def _cyl(c):
 def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, obj_aug=None, insert_mode="ground",
                    search_voxel_size=0.5, search_range=(50, 50), search_z_min=-2.0, proj_matrix=None, image_size=(),
                    g_indices=None, front_axis="x"):
-    """``point_mixmatch`` of the reference in ground mode (``mixmatch_ss.py:47-212``).
+    """``point_mixmatch`` of the reference (``mixmatch_ss.py:42-212``), both insert modes ("ground": the shipped MoPA configs; "fv").
 
     ``ori_pc`` (N,>=3) float32, host or device; returns ``(cat_pc, cat_label, obj_mask, obj_ps_mask)`` with ``cat_pc`` a
     DEVICE float64 (N+M,3) tensor (scan points first), the other three device tensors of length N+M -- what
     ``post_process`` below consumes.  When no object fits: the scan alone and all-False masks, like the reference."""
+    if insert_mode == "fv":
+        return _point_mixmatch_fv(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc)
     if insert_mode != "ground":
-        raise NotImplementedError("only insert_mode='ground' (the shipped MoPA configs) runs on the device")
+        raise ValueError(f"insert_mode must be 'ground' or 'fv', got {insert_mode!r}")
     m = OverlapMap(ori_pc, search_voxel_size, search_range, search_z_min, front_axis, g_mask=g_indices)
     dev = m.pts.device
     n0 = m.pts.shape[0]
@@ -200,6 +202,38 @@ def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, ob
     none = torch.zeros(n0, dtype=torch.bool, device=dev)
     none.n_obj = 0
     return m.pts[:, :3].double().contiguous(), lab, none, none.clone()
+
+
+def _point_mixmatch_fv(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc):
+    """``insert_mode="fv"`` (``mixmatch_ss.py:83-105``): lift every object by the sensors' height discrepancy and, when its mean x
+    is negative, rotate it about z by twice its azimuth so that it lands in the front half space.  No search, no random draws.
+    The objects are small host arrays (a few hundred points): the angle and the rotation are the reference's own numpy
+    expressions in the objects' dtype (bit-identical), INCLUDING its in-place edit of the caller's arrays (:87,:99); the scan
+    stays on the device and the result has ``point_mixmatch``'s device layout (float64 xyz, scan points first)."""
+    pts = ori_pc if torch.is_tensor(ori_pc) else torch.from_numpy(np.ascontiguousarray(ori_pc))
+    if pts.device.type != "cuda":
+        pts = pts.cuda()
+    dev = pts.device
+    lab = torch.as_tensor(ori_label).to(dev)
+    new_pc, new_lab = [], []
+    for i in range(len(obj_pc_ls)):
+        obj_pc = obj_pc_ls[i]
+        obj_pc[:, 2] = obj_pc[:, 2] - z_disc
+        ctr = np.average(obj_pc, axis=0)
+        if ctr[0] < 0:
+            th = np.arccos(ctr[1] / np.sqrt(ctr[0] ** 2 + ctr[1] ** 2))
+            rot = np.array([[np.cos(2 * th), -np.sin(2 * th), 0], [np.sin(2 * th), np.cos(2 * th), 0], [0, 0, 1]], dtype=np.float32)
+            obj_pc[:, :3] = obj_pc[:, :3].dot(rot)
+        new_pc.append(obj_pc[:, :3])
+        new_lab.append(np.asarray(obj_label_ls[i]))
+    n0 = pts.shape[0]
+    obj = torch.from_numpy(np.concatenate(new_pc, 0).astype(np.float64)).to(dev)
+    cat_pc = torch.cat([pts[:, :3].double(), obj], 0).contiguous()
+    cat_label = torch.cat([lab, torch.from_numpy(np.concatenate(new_lab, 0)).to(dev).to(lab.dtype)], 0)
+    mask = torch.zeros(cat_pc.shape[0], dtype=torch.bool, device=dev)
+    mask[n0:] = True
+    mask.n_obj = cat_pc.shape[0] - n0
+    return cat_pc, cat_label, mask, mask.clone()
 
 
 def range_keep(cat_pc: torch.Tensor, n_scan: int, fov_up=0.05235, fov_down=-0.43633, proj_W=1024, proj_H=64) -> torch.Tensor:

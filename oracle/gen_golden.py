@@ -332,6 +332,13 @@ def gen_g6():
 
 
 # ----------------------------------------------------------------------------- G8
+def vgi_fv_objects(k: int):
+    """The objects of G8b: those of vgi_case(k) with the first one mirrored behind the sensor (mean x < 0)."""
+    objs = [o.copy() for o in vgi_case(k)["objs"]]
+    objs[0][:, 0] -= 2.0 * objs[0][:, 0].mean() + 3.0
+    return objs
+
+
 def vgi_case(k: int):
     """Synthetic VGI inputs of case k (shared by the generator and the tests; nothing reference-derived): a nuScenes-shape
     scan, a ground mask, two object clusters, a pinhole projection, the front axis."""
@@ -422,6 +429,19 @@ def gen_g8():
         print("G8 case", k, c["front"], "centres", len(vc), "inserted", int(obj_mask.sum()), "kept", int(pres.sum()), "of", len(pres),
               "locs", len(locs))
     np.savez_compressed(os.path.join(OUT, "g8_vgi.npz"), **save)
+    # G8b: insert_mode="fv" (mixmatch_ss.py:83-105) -- one object behind the sensor (rotated to the front), one in front (kept)
+    save = {}
+    for k in range(2):
+        c = vgi_case(k)
+        objs = [o.copy() for o in c["objs"]]
+        objs[0][:, 0] -= 2.0 * objs[0][:, 0].mean() + 3.0          # mean x < 0: takes the rotation branch
+        cat_pc, cat_label, obj_mask, _ = ref.point_mixmatch(c["ori_pc"], c["label"], objs, c["obj_labels"], z_disc=-0.324, insert_mode="fv")
+        n0 = len(c["ori_pc"])
+        assert obj_mask.sum() == sum(len(o) for o in objs) and cat_pc.dtype == np.float32
+        save[f"obj_xyz{k}"], save[f"cat_label_tail{k}"] = cat_pc[n0:], cat_label[n0:]
+        save[f"objs_after{k}_0"], save[f"objs_after{k}_1"] = objs[0], objs[1]    # the reference edits its inputs in place
+        print("G8b case", k, "fv: inserted", int(obj_mask.sum()), "mean x before/after", float(c["objs"][0][:, 0].mean() * -1 - 3.0), float(cat_pc[n0:n0 + len(objs[0]), 0].mean()))
+    np.savez_compressed(os.path.join(OUT, "g8b_vgi_fv.npz"), **save)
 
 
 # ----------------------------------------------------------------------------- G7

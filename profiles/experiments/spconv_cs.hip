@@ -118,51 +118,101 @@ MOPA_API int mopa_rulebook_cs_fill(const int64_t* desc_host, int32_t ntables, in
 }
 
 // ----------------------------------------------------------------------------------------------
-// The convolution.  NKC = Cin / 16, D = ring depth (groups of row gathers in flight per wave); waves per block = 16-column
-// slices per block (run time).
+// The convolution.  NKC = Cin / 16, NTW = 16-column tiles per wave (1 or 2), D = ring depth (groups of row gathers in flight
+// per wave); waves per block = column slices of 16 NTW columns per block (run time).
 //   lane l: r = l & 15, q = l >> 4.  A fragment of (group, chunk kk): lane holds in[rule r][16 kk + 4 q + s], s < 4.
-//   B fragment of (offset, chunk kk): lane holds Wc[o][16 kk + 4 q + s][16 ct + r]  (packed by mopa_spconv_pack_weight,
-//   ntw = 1: one contiguous 1 KiB piece per (column tile, offset, chunk)).  D: lane holds rules 4 q + j, column r.
+//   B fragment of (offset, chunk kk, tile t): lane holds Wc[o][16 kk + 4 q + s][16 (NTW ct + t) + r]  (packed by
+//   mopa_spconv_pack_weight, ntw = 1: one contiguous 1 KiB piece per (column tile, offset, chunk)).
+//   D tile t: lane holds rules 4 q + j, column 16 t + r of the wave's slice.
+//
+// What bounds k_spconv_t4 (profiles/r3_spconv_tcp_pmc.md): the vector L1 (TCP) is busy 82-87 % of the kernel's duration on the
+// layers that carry the bytes -- a 16-row gather touches 16 cache lines per KiB, a packed weight piece 8, and with the
+// weight operand re-loaded for every 16-rule group that is 4 line accesses per MFMA at two column tiles per wave.  Here the
+// weight slice of a RUN (the consecutive groups of one filter offset: 2-5 with 128 / 256-row tiles) is loaded ONCE.
+//
 // Every wave walks ALL groups of the tile on its own (no barrier in the main loop: a barrier-synchronous version with the
-// gathered rows shared through LDS paid a memory round trip per 2-3 group stage and ran 2-4x slower than k_spconv_t4, see
-// DESIGN.md section 3): its own ring of row gathers (unconditional, in-bounds loads -> the compiler's vmcnt counting stays
-// exact), its weight slice of the current run in registers with the next run's slice prefetched while the run's last
-// group is multiplied, its own 16 columns of the tile's accumulator.  The block's waves gather the same rows at about
-// the same time, so all but the first hit the vector L1.
+// gathered rows shared through LDS paid a memory round trip per 2-3 group stage and ran 2-4x slower than k_spconv_t4):
+//   * its own register ring of row gathers (unconditional, in-bounds loads: the compiler's vmcnt counting stays exact);
+//   * the NEXT run's weight slice is prefetched at a run's first group by LDS-DMA (global_load_lds, inline asm) into the
+//     wave's private LDS slot and moved to registers at the next run's start.  It has to bypass the compiler: a load issued
+//     under a (wave-uniform) branch makes hipcc's wait-count pass drain the whole ring with `s_waitcnt vmcnt(0)` at every
+//     join (measured: a memory round trip per run, 1.3-4x slower than k_spconv_t4), and an inline-asm load into REGISTERS is
+//     not safe either (the compiler copies the "already written" output registers before the data has landed).  Data in
+//     flight into LDS has no compiler-visible name; loads return in order, so "the slot has landed" = "at most the loads
+//     issued since are outstanding" = s_waitcnt vmcnt(iterations since the prefetch x NKC), counted by hand.  The compiler's own
+//     counted waits only get stricter by loads it does not know about, never weaker;
+//   * its own 16 NTW columns of the tile's accumulator.
+// The block's waves gather the same rows at about the same time, so all but the first hit the vector L1.
 // Summation order per output element: filter offsets ascending, per rule k ascending -- a rule's whole Cin product is formed in
 // the MFMA accumulator and added to the output row once (as k_spconv_fwd / k_spconv_blk do: bit-identical to them).
-template <int NKC, int D, bool DUAL>
+template <int NKC, int NTW, int D>
 __global__ __launch_bounds__(512) void k_spconv_cw(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
                                                     const int* __restrict__ grp_in, const int* __restrict__ grp_out,
                                                     int K, int A_out, const float* __restrict__ in, int ld_in,
                                                     const float* __restrict__ Wp, int w_flip, float* __restrict__ out,
                                                     int ld_out, int TM, int MU) {
+  constexpr int CP = 16 * NTW;                    // columns per wave
+  constexpr int NP = NKC * NTW;                   // 1 KiB weight pieces per run and wave
   extern __shared__ float4 cs_smem4[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int NW = blockDim.x >> 6;
-  const int LD = NW * 16 + 4;                                                           // accumulator row stride (floats)
+  const int LD = NW * CP + 4;                                                           // accumulator row stride (floats)
   const int MS = MU + 2 * D;                                                            // staged groups: chunk + ring look-ahead (the ring issues up to 2 D - 2 past the chunk)
-  float* ACC = reinterpret_cast<float*>(cs_smem4);                                      // [TM + 1][LD], row TM = sink of padding rules
+  float4* BS = cs_smem4;                                                                // [NW][NP][64] weight slot per wave (first: low LDS addresses for M0)
+  float* ACC = reinterpret_cast<float*>(BS + (size_t)NW * NP * 64);                     // [TM + 1][LD], row TM = sink of padding rules
   unsigned* m_in = reinterpret_cast<unsigned*>(ACC + (size_t)(TM + 1) * LD);            // [MS][16] byte offset / 16 of the input row
   unsigned short* m_out = reinterpret_cast<unsigned short*>(m_in + MS * 16);            // [MS][16] accumulator row
-  unsigned* m_o = reinterpret_cast<unsigned*>(m_out + MS * 16);                         // [MS]     filter offset
+  unsigned* m_o = reinterpret_cast<unsigned*>(m_out + MS * 16);                         // [MS]     filter offset | groups left in the run << 8
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, ntiles = gridDim.x;
   const int row0 = tile * TM;
-  const int ct = blockIdx.y * NW + wv;            // this wave's 16-column tile of the output
+  const int ct0 = (blockIdx.y * NW + wv) * NTW;   // this wave's first 16-column tile of the output
   const int gb = grp_start[tile], ge = grp_start[tile + 1], G = grp_start[ntiles];
   const unsigned ld4 = (unsigned)ld_in >> 2;
   for (int i = tid; i < (TM + 1) * LD / 4; i += blockDim.x) reinterpret_cast<float4*>(ACC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (gb < ge) {
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in) + q;
-    const float4* __restrict__ wl = reinterpret_cast<const float4*>(Wp) + (size_t)ct * K * NKC * 64 + lane;
-    float* acc_lane = ACC + wv * 16 + r;
+    const float4* __restrict__ wl = reinterpret_cast<const float4*>(Wp) + (size_t)ct0 * K * NKC * 64 + lane;   // + tile t: K * NKC * 64
+    float4* slot = BS + (size_t)wv * NP * 64;
+    const unsigned slot_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)slot);
+    float* acc_lane = ACC + wv * CP + r;
     const unsigned o_last = (unsigned)grp_o[ge - 1] & 0xffu;
 
     float4 A[D][NKC];
-    f32x4 Bc[NKC], Bn[NKC];   // vector type: inline-asm operands
-    unsigned o_prev = 0xffffu, o_bn = 0xffffu;   // offsets whose weights sit in Bc / Bn
-    int since_b = 0;                             // loop iterations (= NKC row-gather loads each) since the last weight prefetch
+    f32x4 Bc[NKC][NTW];
+    unsigned o_prev = 0xffffu, o_slot = 0xffffu;   // offsets whose weights sit in Bc / in the LDS slot (landed or in flight)
+    int since_b = 0;                               // loop iterations (= NKC row-gather loads each) since the last slot prefetch
+
+    // piece (kk, t) of offset O_ -> slot[(kk * NTW + t) * 64 + lane]; M0 = LDS target (saved / restored: M0 is the compiler's)
+#define CW_PREFETCH(O_)                                                                                       \
+  {                                                                                                           \
+    const float4* wo_ = wl + (size_t)(w_flip ? K - 1 - (int)(O_) : (int)(O_)) * (NKC * 64);                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slot's previous content has been read out */    \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < NKC; ++kk_)                                                     \
+      _Pragma("unroll") for (int t_ = 0; t_ < NTW; ++t_) {                                                    \
+        unsigned sv_;                                                                                         \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(sv_)                                                                             \
+                     : "v"(wo_ + (size_t)t_ * K * NKC * 64 + kk_ * 64), "s"(slot_lds + (unsigned)((kk_ * NTW + t_) * 1024)) \
+                     : "memory");                                                                             \
+      }                                                                                                       \
+    o_slot = (O_);                                                                                            \
+    since_b = 0;                                                                                              \
+  }
+#define CW_WAIT_N(N_) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory")
+#define CW_WAIT_SLOT()                                                                                        \
+  {                                                                                                           \
+    if (since_b >= 4 && 4 * NKC <= 60) CW_WAIT_N(4 * NKC <= 60 ? 4 * NKC : 0);                                \
+    else if (since_b == 3 && 3 * NKC <= 60) CW_WAIT_N(3 * NKC <= 60 ? 3 * NKC : 0);                           \
+    else if (since_b >= 2 && 2 * NKC <= 60) CW_WAIT_N(2 * NKC <= 60 ? 2 * NKC : 0);                           \
+    else if (since_b >= 1) CW_WAIT_N(NKC);                                                                    \
+    else CW_WAIT_N(0);                                                                                        \
+  }
+#define CW_ISSUE(S_, C_)                                                                                      \
+  {                                                                                                           \
+    const unsigned io_ = m_in[(C_) * 16 + r];                                                                 \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < NKC; ++kk_) A[S_][kk_] = in4[(size_t)io_ + (unsigned)(kk_ * 4)]; \
+  }
 
     for (int cb = gb; cb < ge; cb += MU) {
       __syncthreads();   // everyone is done with the previous chunk's metadata (first pass: the accumulator is zeroed)
@@ -184,40 +234,12 @@ __global__ __launch_bounds__(512) void k_spconv_cw(const int* __restrict__ grp_s
       for (int e = tid; e < MS; e += blockDim.x) m_o[e] = (cb + e < ge) ? (unsigned)grp_o[cb + e] : (o_last | 0x100u);
       __syncthreads();
       const int ng = min(MU, ge - cb);
-
-#define CW_ISSUE(S_, C_)                                                                     \
-  {                                                                                          \
-    const unsigned io_ = m_in[(C_) * 16 + r];                                                \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < NKC; ++kk_) A[S_][kk_] = in4[(size_t)io_ + (unsigned)(kk_ * 4)]; \
-  }
-      // The weight loads are INLINE ASM: the compiler must not see them.  A load that is issued under a (wave-uniform) branch makes
-      // hipcc's wait-count pass give up at the join -- it drained the whole ring with `s_waitcnt vmcnt(0)` at every run start,
-      // a full memory round trip per 2-3 groups (first version of this kernel: 1.3-4x slower than k_spconv_t4).  Loads return in
-      // order, so "the next run's weights have landed" = "at most (loads issued since) are outstanding": every loop iteration
-      // issues NKC row gathers, hence CW_WAITB(iterations since the prefetch).  The compiler's own counted waits for the ring
-      // only get stricter by loads it does not know about (never weaker).
-#define CW_LOADB(O_)                                                                         \
-  {                                                                                          \
-    const float4* wo_ = wl + (size_t)(w_flip ? K - 1 - (int)(O_) : (int)(O_)) * (NKC * 64);  \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < NKC; ++kk_)                                    \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Bn[kk_]) : "v"(wo_ + kk_ * 64) : "memory"); \
-    since_b = 0;                                                                             \
-  }
-#define CW_WAITB_N(N_) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory")
-#define CW_WAITB()                                                                           \
-  {                                                                                          \
-    if (since_b >= 4 && 4 * NKC <= 60) CW_WAITB_N(4 * NKC <= 60 ? 4 * NKC : 0);              \
-    else if (since_b == 3 && 3 * NKC <= 60) CW_WAITB_N(3 * NKC <= 60 ? 3 * NKC : 0);         \
-    else if (since_b >= 2 && 2 * NKC <= 60) CW_WAITB_N(2 * NKC <= 60 ? 2 * NKC : 0);         \
-    else if (since_b >= 1) CW_WAITB_N(NKC);                                                  \
-    else CW_WAITB_N(0);                                                                      \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < NKC; ++kk_) asm volatile("" : "+v"(Bn[kk_])); /* uses of Bn stay below the wait */ \
-  }
 #pragma unroll
       for (int s = 0; s < D; ++s) {
         CW_ISSUE(s, s);
         __builtin_amdgcn_sched_barrier(0);   // keep the ring in issue order: the loop's counted vmcnt relies on it
       }
+      since_b += D;   // (the staging loads above came after any prefetch in flight as well: the hand count only errs on the strict side)
       // metadata of the next group to multiply, fetched one group ahead: accumulator rows (per lane) and filter offsets
       uint2 mo_n = *reinterpret_cast<const uint2*>(m_out + q * 4);
       unsigned w_c = __builtin_amdgcn_readfirstlane(m_o[0]), w_n = __builtin_amdgcn_readfirstlane(m_o[1]);
@@ -229,97 +251,88 @@ __global__ __launch_bounds__(512) void k_spconv_cw(const int* __restrict__ grp_s
           float* p1 = acc_lane + (mo_n.x >> 16) * LD;
           float* p2 = acc_lane + (mo_n.y & 0xffffu) * LD;
           float* p3 = acc_lane + (mo_n.y >> 16) * LD;
-          const float v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;   // the 4 rules of a lane are distinct output rows (or the sink)
+          float v[4][NTW];                                      // the 4 rules of a lane are distinct output rows (or the sink)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) { v[0][t] = p0[16 * t]; v[1][t] = p1[16 * t]; v[2][t] = p2[16 * t]; v[3][t] = p3[16 * t]; }
           const unsigned w_nn = m_o[c + 2 < MS ? c + 2 : MS - 1];
           __builtin_amdgcn_sched_barrier(0);                    // keep the accumulator reads in flight under the MFMAs
           const unsigned o_c = w_c & 0xffu;
           if (o_c != o_prev) {                                  // a new run starts
-            if (o_bn != o_c) { CW_LOADB(o_c); }                 // (not prefetched: first run of the tile, or a run cut by a chunk)
-            CW_WAITB();
+            if (o_slot != o_c) CW_PREFETCH(o_c);                // (not prefetched: first run of the tile, or a run cut by a chunk)
+            CW_WAIT_SLOT();
 #pragma unroll
-            for (int kk = 0; kk < NKC; ++kk) Bc[kk] = Bn[kk];
+            for (int kk = 0; kk < NKC; ++kk)
+#pragma unroll
+              for (int t = 0; t < NTW; ++t) {
+                const float4 b_ = slot[(kk * NTW + t) * 64 + lane];
+                Bc[kk][t] = (f32x4){b_.x, b_.y, b_.z, b_.w};
+              }
             o_prev = o_c;
             // fetch the NEXT run's weights now: they have this whole run to arrive
             const int nx = min(c + (int)(w_c >> 8), MS - 1);
-            o_bn = __builtin_amdgcn_readfirstlane(m_o[nx]) & 0xffu;
-            CW_LOADB(o_bn);
+            const unsigned o_nx = __builtin_amdgcn_readfirstlane(m_o[nx]) & 0xffu;
+            CW_PREFETCH(o_nx);
           }
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          if (DUAL && NKC > 1) {   // two accumulation chains (even / odd 16-channel chunks), summed at the end: rounding differs
-            f32x4 d1 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 d[NTW];
 #pragma unroll
-            for (int kk = 0; kk + 1 < NKC; kk += 2) {
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].x, Bc[kk][0], d, 0, 0, 0);
-              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk + 1].x, Bc[kk + 1][0], d1, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].y, Bc[kk][1], d, 0, 0, 0);
-              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk + 1].y, Bc[kk + 1][1], d1, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].z, Bc[kk][2], d, 0, 0, 0);
-              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk + 1].z, Bc[kk + 1][2], d1, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].w, Bc[kk][3], d, 0, 0, 0);
-              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk + 1].w, Bc[kk + 1][3], d1, 0, 0, 0);
-            }
-            if (NKC & 1) {
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][NKC - 1].x, Bc[NKC - 1][0], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][NKC - 1].y, Bc[NKC - 1][1], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][NKC - 1].z, Bc[NKC - 1][2], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][NKC - 1].w, Bc[NKC - 1][3], d, 0, 0, 0);
-            }
-            d += d1;
-          } else {
+          for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < NKC; ++kk) {
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].x, Bc[kk][0], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].y, Bc[kk][1], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].z, Bc[kk][2], d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][kk].w, Bc[kk][3], d, 0, 0, 0);
-            }
+          for (int kk = 0; kk < NKC; ++kk) {
+            const float av[4] = {A[s][kk].x, A[s][kk].y, A[s][kk].z, A[s][kk].w};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+              for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], Bc[kk][t][s2], d[t], 0, 0, 0);
           }
           mo_n = *reinterpret_cast<const uint2*>(m_out + (c + 1) * 16 + q * 4);
           w_c = w_n;
           w_n = __builtin_amdgcn_readfirstlane(w_nn);
           CW_ISSUE(s, c + D);
           ++since_b;
-          *p0 = v0 + d[0]; *p1 = v1 + d[1]; *p2 = v2 + d[2]; *p3 = v3 + d[3];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            p0[16 * t] = v[0][t] + d[t][0]; p1[16 * t] = v[1][t] + d[t][1];
+            p2[16 * t] = v[2][t] + d[t][2]; p3[16 * t] = v[3][t] + d[t][3];
+          }
         }
       }
-#undef CW_ISSUE
-#undef CW_LOADB
-#undef CW_WAITB
-#undef CW_WAITB_N
     }
+#undef CW_ISSUE
+#undef CW_PREFETCH
+#undef CW_WAIT_SLOT
+#undef CW_WAIT_N
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a prefetch may still be in flight into this wave's slot
   }
   __syncthreads();
   // each output element is written exactly once
-  const int V = NW * 4;   // float4 per row of this block's columns
+  const int V = NW * CP / 4;   // float4 per row of this block's columns
   for (int i = tid; i < TM * V; i += blockDim.x) {
     const int rr = i / V, c4 = i - rr * V;
     if (row0 + rr < A_out)
-      *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + blockIdx.y * (NW * 16) + c4 * 4) =
+      *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + blockIdx.y * (NW * CP) + c4 * 4) =
           *reinterpret_cast<const float4*>(ACC + rr * LD + c4 * 4);
   }
 }
 
 static inline int cs_mu(int tile_rows) { return tile_rows == 256 ? 160 : 96; }
 
-template <int NKC, int D>
+template <int NKC, int NTW, int D>
 static int launch_cw(const int* gs, const int* go, const int* gi, const int* gout, int K, int A_out, int TM, const float* in, int ld_in,
                      const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
   const int MU = cs_mu(TM);
-  const int nct = cout / 16;
-  int nw = nct;                                 // waves per block = column tiles per block: all of them up to 8, else an even split
-  if (nw > 8) nw = (nct % 2 == 0) ? nct / 2 : (nct % 3 == 0 ? nct / 3 : 1);
-  const size_t lds = (size_t)(TM + 1) * (nw * 16 + 4) * 4 + (size_t)(MU + 2 * D) * 100;
-  if (lds > 160 * 1024) return MOPA_ERR_ARG;
-  static const bool dual = getenv("MOPA_CW_DUAL") && atoi(getenv("MOPA_CW_DUAL"));   // tuning only
-  auto kern = dual ? k_spconv_cw<NKC, D, true> : k_spconv_cw<NKC, D, false>;
-  static std::atomic<bool> attr_set{false};   // caches idempotent calls, carries no state a result depends on
+  const int nsl = cout / (16 * NTW);            // column slices = waves over all blocks of a tile
+  int nw = nsl;                                 // waves per block: all slices up to 8, else an even split
+  if (nw > 8) nw = (nsl % 2 == 0) ? nsl / 2 : (nsl % 3 == 0 ? nsl / 3 : 1);
+  const size_t lds = (size_t)nw * NKC * NTW * 1024 + (size_t)(TM + 1) * (nw * 16 * NTW + 4) * 4 + (size_t)(MU + 2 * D) * 100;
+  if (lds > 160 * 1024 || (size_t)nw * NKC * NTW * 1024 > 60 * 1024) return MOPA_ERR_ARG;   // weight slots stay below 64 KiB (M0)
+  auto kern = k_spconv_cw<NKC, NTW, D>;
+  static std::atomic<bool> attr_set{false};   // caches an idempotent call, carries no state a result depends on
   if (!attr_set.load(std::memory_order_acquire)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spconv_cw<NKC, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_spconv_cw<NKC, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MOPA_ERR_LAUNCH;
     attr_set.store(true, std::memory_order_release);
   }
-  dim3 grid((unsigned)cdiv64(A_out, TM), nct / nw);
+  dim3 grid((unsigned)cdiv64(A_out, TM), nsl / nw);
   kern<<<grid, 64 * nw, lds, st>>>(gs, go, gi, gout, K, A_out, in, ld_in, Wp, w_flip, out, ld_out, TM, MU);
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
@@ -333,7 +346,8 @@ MOPA_API int mopa_spconv_cs_supported(int32_t cin, int32_t cout) {
 }
 
 // Same contract as mopa_spconv_fwd_grouped with packed weights (mopa_spconv_pack_weight, ntw = 1), on the TM-row rulebook
-// of the table (mopa_rulebook_cs_count / _fill).  w_flip = 1: mirrored filter offsets (backward-data of a submanifold table).
+// of the table (mopa_rulebook_cs_count / _fill).  w_flip bit 0: mirrored filter offsets (backward-data of a submanifold table);
+// bits 8-15: 16-column tiles per wave (1 or 2; 0 = the default: 2 where Cout / 16 is even).
 MOPA_API int mopa_spconv_fwd_cs(const int32_t* grp_start, const int32_t* grp_o, const int32_t* grp_in, const int32_t* grp_out,
                                 int32_t K, int32_t num_out, int32_t tile_rows, const float* in, int32_t ld_in, int32_t cin,
                                 const float* weight_packed, int32_t cout, int32_t w_flip, float* out, int32_t ld_out, void* stream) {
@@ -341,18 +355,23 @@ MOPA_API int mopa_spconv_fwd_cs(const int32_t* grp_start, const int32_t* grp_o, 
   if (ld_in < cin || ld_out < cout || ld_in % 4 || ld_out % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight_packed) & 15)) return MOPA_ERR_ARG;
   if ((int64_t)num_out * 8 * ld_in * 4 >= (1ll << 36)) return MOPA_ERR_ARG;   // input rows are addressed by 32-bit float4 indices
   hipStream_t st = (hipStream_t)stream;
-#define CW(NKC_, D_) return launch_cw<NKC_, D_>(grp_start, grp_o, grp_in, grp_out, K, num_out, tile_rows, in, ld_in, weight_packed, cout, w_flip & 1, out, ld_out, st)
+  int ntw = (w_flip >> 8) & 0xff;
+  if (ntw == 0) ntw = ((cout / 16) % 2 == 0) ? 2 : 1;
+  if (ntw > 2 || (cout / 16) % ntw) return MOPA_ERR_ARG;
+#define CW(NKC_, D1_, D2_)                                                                                                   \
+  return ntw == 1 ? launch_cw<NKC_, 1, D1_>(grp_start, grp_o, grp_in, grp_out, K, num_out, tile_rows, in, ld_in, weight_packed, cout, w_flip & 1, out, ld_out, st) \
+                  : launch_cw<NKC_, 2, D2_>(grp_start, grp_o, grp_in, grp_out, K, num_out, tile_rows, in, ld_in, weight_packed, cout, w_flip & 1, out, ld_out, st)
   switch (cin / 16) {
-    case 1: CW(1, 8);
-    case 2: CW(2, 6);
-    case 3: CW(3, 4);
-    case 4: CW(4, 4);
-    case 5: CW(5, 3);
-    case 6: CW(6, 3);
-    case 7: CW(7, 2);
-    case 8: CW(8, 2);
-    case 10: CW(10, 2);
-    case 12: CW(12, 2);
+    case 1: CW(1, 8, 6);
+    case 2: CW(2, 6, 4);
+    case 3: CW(3, 4, 3);
+    case 4: CW(4, 4, 3);
+    case 5: CW(5, 3, 2);
+    case 6: CW(6, 3, 2);
+    case 7: CW(7, 2, 2);
+    case 8: CW(8, 2, 2);
+    case 10: CW(10, 2, 2);
+    case 12: CW(12, 2, 2);
     default: return MOPA_ERR_ARG;
   }
 #undef CW

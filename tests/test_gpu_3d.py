@@ -311,6 +311,47 @@ def test_net3dseg_equals_dense_network():
                                    (0.9 * sd0[name + ".running_var"].double() + 0.1 * var * n / max(n - 1, 1)).numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("residual,needs_dfeats", [(False, False), (False, True), (True, True)])
+def test_native_executor_is_bit_identical_to_the_python_walk(residual, needs_dfeats):
+    """One C-ABI call per pass (csrc/scn_exec.hip) runs the same kernels in the same order as the per-layer walk from Python
+    (kept for synchronised BatchNorm, MOPA_SCN_NATIVE=0): outputs, every parameter gradient, the input gradient and the running
+    statistics are equal bit for bit -- two training steps, so the second pass re-uses / refreshes the derived weight forms."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd.optim import FlatAdam
+    c = _cloud(17, n=9000, size=150)
+    rng = np.random.Generator(np.random.PCG64(6))
+    feats = torch.from_numpy(rng.random((c.shape[0], 1), dtype=np.float32) + 0.5)
+    gouts = None
+    results = []
+    for native in (True, False):
+        old = s3.NATIVE
+        s3.NATIVE = native
+        try:
+            model = _build_3d(7 if not residual else 4, residual=residual).train()
+            opt = FlatAdam(model.parameters(), lr=1e-3)
+            run = []
+            for step in range(2):
+                opt.zero_grad()
+                f = feats.cuda().requires_grad_(needs_dfeats)
+                out = model({"x": [torch.from_numpy(c), f]})
+                if gouts is None:
+                    gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)).cuda() for k, v in out.items()}
+                sum((out[k] * gouts[k]).sum() for k in out).backward()
+                run.append(({k: v.detach().clone() for k, v in out.items()}, opt.grad.clone(), None if f.grad is None else f.grad.clone()))
+                opt.step()
+            run.append({k: v.clone() for k, v in model.state_dict().items()})
+            results.append(run)
+        finally:
+            s3.NATIVE = old
+    a, b = results
+    for step in range(2):
+        for k in a[step][0]:
+            assert torch.equal(a[step][0][k], b[step][0][k]), (step, k)
+        assert torch.equal(a[step][1], b[step][1]), step
+        assert (a[step][2] is None) == (b[step][2] is None) and (a[step][2] is None or torch.equal(a[step][2], b[step][2]))
+    assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+
+
 def test_net3dseg_duplicate_points_and_extra_feature_rows():
     # nuScenes quirk (Appendix B.8): more feature rows than coords; and every point duplicated once.
     c = _cloud(9, n=800, size=24)

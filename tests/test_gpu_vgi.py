@@ -100,3 +100,25 @@ def test_no_valid_placement_returns_the_scan_unchanged():
                                               search_range=[25.0, 25.0], search_z_min=-2.0, proj_matrix=c["proj"],
                                               image_size=c["image_size"], g_indices=c["g_mask"], front_axis=c["front"])
     assert cat_pc.shape[0] == len(c["ori_pc"]) and not bool(mask.any())
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_front_view_insertion_matches_the_reference(golden_dir, k):
+    """insert_mode="fv" (mixmatch_ss.py:83-105) against fixture G8b: object coordinates bit-exact (float32 values in the float64
+    device cloud), labels, masks, and the reference's in-place edit of the caller's object arrays."""
+    import os
+    from mopa_amd import vgi
+    from oracle.gen_golden import vgi_fv_objects
+    g = dict(np.load(os.path.join(golden_dir, "g8b_vgi_fv.npz")))
+    c = _case(k)
+    objs = vgi_fv_objects(k)
+    cat_pc, cat_label, mask, ps_mask = vgi.point_mixmatch(torch.from_numpy(c["ori_pc"]).cuda(), c["label"], objs, c["obj_labels"],
+                                                          z_disc=-0.324, insert_mode="fv")
+    n0 = len(c["ori_pc"])
+    assert cat_pc.dtype == torch.float64 and cat_pc.is_cuda and int(mask.sum()) == len(g[f"obj_xyz{k}"]) and not bool(mask[:n0].any())
+    assert np.array_equal(cat_pc[n0:].cpu().numpy(), g[f"obj_xyz{k}"].astype(np.float64))
+    assert np.array_equal(cat_label[n0:].cpu().numpy(), g[f"cat_label_tail{k}"]) and torch.equal(mask, ps_mask)
+    assert torch.equal(cat_pc[:n0].cpu(), torch.from_numpy(c["ori_pc"][:, :3]).double())
+    assert np.array_equal(objs[0], g[f"objs_after{k}_0"]) and np.array_equal(objs[1], g[f"objs_after{k}_1"])
+    with pytest.raises(ValueError):
+        vgi.point_mixmatch(c["ori_pc"], c["label"], objs, c["obj_labels"], insert_mode="sideways")

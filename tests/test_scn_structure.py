@@ -153,3 +153,38 @@ def test_product_state_dict_matches_reference_names(g6, dual, key):
     # names, shapes and traversal order: torch optimizers / torch_ema index their state by parameter order
     assert got == want
     assert [k for k, _ in model.named_parameters()] == [k for k, _ in want if "running" not in k]
+
+
+def test_native_executor_tables_follow_the_program():
+    """The host tables the native executor walks (csrc/scn_exec.hip: one C-ABI call per pass) are a faithful encoding of the layer
+    program that G6 pins: same ops in the same order, every parameter named once, the backward plan covers every op once in
+    reverse, BatchNorm statistics slots do not overlap."""
+    from mopa_amd.sparse3d import Program
+    for reps, residual in ((1, False), (2, False), (1, True)):
+        prog = Program(1, 16, 7, reps, residual, "net_3d.sparseModel.")
+        nt = prog.native_tables()
+        assert nt is prog.native_tables()                      # built once
+        t, names = nt["prog"], nt["names"]
+        assert len(t) == len(prog.ops) == len(names)
+        kinds = {"bn": 0, "conv": 1, "add": 2}
+        ck = {"subm": 0, "down": 1, "up": 2, "nin": 3}
+        slots = []
+        for row, op, name in zip(t, prog.ops, names):
+            assert row[0] == kinds[op[0]]
+            if op[0] == "bn":
+                assert name == op[1] and (row[4], row[5], row[6]) == (op[2].buf, op[2].col, op[2].C) and row[9] == op[3].C
+                slots.append((int(row[10]), int(row[10]) + 4 * op[2].C))
+            elif op[0] == "conv":
+                assert name == op[1] and row[1] == ck[op[2]] and (row[2], row[3]) == (op[4].level, op[5].level)
+                assert (row[6], row[9]) == (op[4].C, op[5].C)
+            else:
+                assert name is None and (row[10], row[11]) == (op[2].buf, op[2].col)
+        slots.sort()
+        assert all(a[1] <= b[0] for a, b in zip(slots, slots[1:])) and slots[-1][1] == nt["stats_floats"]
+        named = [n for n in names if n is not None]
+        assert len(set(named)) == len(named)
+        plan = nt["plan"]
+        assert sorted(int(r[1]) for r in plan) == [i for i, n in enumerate(names) if n is not None]   # every bn / conv exactly once
+        order = [int(r[1]) for r in plan]
+        assert order == sorted(order, reverse=True)            # ... in reverse program order
+        assert plan[nt["stem_step"], 0] == 1 and names[plan[nt["stem_step"], 1]].endswith("sparseModel.1")
