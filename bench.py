@@ -485,12 +485,19 @@ def main():
             elif mopa:
                 l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
                 # Valid Ground-based Insertion (train_xmuda_mopa.py:516-555) on the device, then the third 3D pass on its output
-                cat_pc, cat_lab, cat_mask = [], [], []
-                for v in b["vgi"]:
-                    pc, lab, om, _ = vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
-                                                        search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
-                                                        proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
-                    cat_pc.append(pc); cat_lab.append(lab); cat_mask.append(om)
+                # (the per-scan loop of the reference as one batched call: same draws, same results, two host round trips per batch
+                # instead of four per scan -- mopa_amd/vgi.py::point_mixmatch_batch; MOPA_BENCH_VGI_LOOP=1: the loop)
+                if os.environ.get("MOPA_BENCH_VGI_LOOP") == "1":
+                    res = [vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
+                                              search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                              proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
+                           for v in b["vgi"]]
+                else:
+                    res = vgi.point_mixmatch_batch([dict(ori_pc=v["ori_pc"], ori_label=v["pslabel"], obj_pc_ls=v["objs"],
+                                                         obj_label_ls=v["obj_labels"], g_indices=v["g_mask"]) for v in b["vgi"]],
+                                                   search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                                   proj_matrix=b["vgi_proj"], image_size=(1600, 900), front_axis="y")
+                cat_pc, cat_lab, cat_mask = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
                 aug = {"noisy_rot": 0.1, "flip_x": 0.5, "rot_z": 6.2831, "transl": True}   # nuScenes target augmentation (yaml)
                 cat_input, cat_ps, _, _ = vgi.post_process(cat_pc, cat_lab, cat_mask, 20, 4096, aug, proj_W=1080, proj_H=32)
                 ov = model3d(cat_input)

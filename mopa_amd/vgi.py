@@ -90,8 +90,8 @@ class OverlapMap:
             call("mopa_vgi_ground_cells", ptr(self.first), ptr(self.g_mask), self.X, self.Y, ptr(self._ground2d), stream())
         return self._ground2d
 
-    def ground_cells(self, fc, pc_obj, proj_matrix, image_size):
-        """Centre filters + ground lookup -> (cells (m,2) int64 numpy in voxel units, lexicographic; n_free; n_filtered)."""
+    def ground_cells_enqueue(self, fc, pc_obj, proj_matrix, image_size):
+        """Centre filters + ground lookup, enqueued only -> (cells (X*Y,2) int32, ncell (1,), counts (2,)) device tensors."""
         free = fc["free"]
         obj = np.asarray(pc_obj)[:, :3]
         oc = (np.max(obj, axis=0) + np.min(obj, axis=0)) / 2
@@ -106,14 +106,23 @@ class OverlapMap:
         cells = torch.empty(self.X * self.Y, 2, dtype=torch.int32, device=dev)
         ncell = torch.empty(1, dtype=torch.int32, device=dev)
         call("mopa_vgi_compact_cells", ptr(cand), self.X, self.Y, self.ox, self.oy, ptr(cells), ptr(ncell), stream())
+        return cells, ncell, counts
+
+    def ground_cells(self, fc, pc_obj, proj_matrix, image_size):
+        """Centre filters + ground lookup -> (cells (m,2) int64 numpy in voxel units, lexicographic; n_free; n_filtered)."""
+        cells, ncell, counts = self.ground_cells_enqueue(fc, pc_obj, proj_matrix, image_size)
         n = int(ncell.item())                     # the one host sync of an anchor attempt
         c = counts.tolist()
         return cells[:n].cpu().numpy().astype(np.int64), c[0], c[1]
 
-    def road_height(self, cell):
-        out = torch.empty(2, dtype=torch.float64, device=self.pts.device)
+    def road_height_enqueue(self, cell, out):
+        """(sum z, count) of the ground points of `cell` into out (2,) float64, enqueued only."""
         call("mopa_vgi_road_height", ptr(self.pts), self.pts.shape[1], self.pts.shape[0], float(np.float32(self.vs)), ptr(self.first), ptr(self.g_mask),
              self.ox, self.oy, self.X, self.Y, self.zlo, int(cell[0]), int(cell[1]), ptr(out), stream())
+
+    def road_height(self, cell):
+        out = torch.empty(2, dtype=torch.float64, device=self.pts.device)
+        self.road_height_enqueue(cell, out)
         s, c = out.tolist()
         if c <= 0:
             raise RuntimeError("no ground point in the chosen cell")
@@ -139,6 +148,87 @@ def _cyl(c):
         out[1] -= np.pi
     if c[0] < 0 and c[1] > 0:
         out[1] += np.pi
+    return out
+
+
+def _place(o3, cell, road_z, jitter, voxel_size):
+    """The reference's placement of one object at a ground cell (``obj_on_road``, mixmatch_ss.py:411-453): move its centre to the
+    cell along its own azimuth, rotate by the azimuth difference, put its lowest point on the road (+ jitter).  -> moved (n,3)."""
+    new_center = cell * voxel_size
+    oc = (np.max(o3, axis=0) + np.min(o3, axis=0)) / 2
+    occ, ncc = _cyl(oc), _cyl(new_center)
+    d_r, d_theta = ncc - occ
+    disc = np.array([d_r * np.cos(occ[1]), d_r * np.sin(occ[1]), 0])
+    rot = np.array([[np.cos(d_theta), -np.sin(d_theta), 0, 0], [np.sin(d_theta), np.cos(d_theta), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    disc[2] = road_z - np.min(o3[:, 2], axis=0) + jitter
+    t = np.eye(4)
+    t[:3, 3] = disc
+    tr = rot @ t
+    h = np.concatenate((o3, np.ones((o3.shape[0], 1))), axis=1)
+    return (tr @ h.T).T[:, :3]
+
+
+def _assemble(m, lab, new_pc, new_lab):
+    dev = m.pts.device
+    n0 = m.pts.shape[0]
+    obj_pc = torch.from_numpy(np.concatenate(new_pc, 0)).to(dev)
+    cat_pc = torch.cat([m.pts[:, :3].double(), obj_pc], 0).contiguous()
+    cat_label = torch.cat([lab, torch.from_numpy(np.concatenate(new_lab, 0)).to(dev).to(lab.dtype)], 0)
+    mask = torch.zeros(cat_pc.shape[0], dtype=torch.bool, device=dev)
+    mask[n0:] = True
+    mask.n_obj = cat_pc.shape[0] - n0     # known on the host: post_process need not read it back from the device
+    return cat_pc, cat_label, mask, mask.clone()
+
+
+def point_mixmatch_batch(items, search_voxel_size=0.5, search_range=(50, 50), search_z_min=-2.0, proj_matrix=None, image_size=(),
+                         front_axis="x"):
+    """``[point_mixmatch(**it, insert_mode="ground", ...) for it in items]`` -- the loop of ``train_xmuda_mopa.py:516-555`` over the
+    target scans of a batch -- with TWO host round trips per batch instead of four per scan: (A) the overlap test, centre filters
+    and ground-cell compaction of every scan's first anchor are enqueued back to back and read together, (B) numpy's global RNG
+    is drawn per scan IN SCAN ORDER exactly as the loop draws it (``choice`` then one ``rand`` per object; the draws need the cell
+    counts only), the road-height lookups of all objects are enqueued and read together, (C) the placements are computed and the
+    clouds assembled.  A scan whose first anchor admits no placement takes the sequential function at its turn (more round
+    trips, same draws).  items: dicts with ori_pc, ori_label, obj_pc_ls, obj_label_ls, g_indices.  Same results bit for bit
+    (``tests/test_gpu_vgi.py::test_batched_insertion_equals_the_per_scan_loop``)."""
+    common = dict(insert_mode="ground", search_voxel_size=search_voxel_size, search_range=search_range, search_z_min=search_z_min,
+                  proj_matrix=proj_matrix, image_size=image_size, front_axis=front_axis)
+    st = []
+    for it in items:   # ---- (A) enqueue
+        m = OverlapMap(it["ori_pc"], search_voxel_size, search_range, search_z_min, front_axis, g_mask=it["g_indices"])
+        objs = it["obj_pc_ls"]
+        ext = np.array([np.linalg.norm(np.max(o, axis=0)[0:2] - np.min(o, axis=0)[0:2]) for o in objs])
+        anchor = np.asarray(objs[int(np.argsort(ext)[::-1][0])])
+        fc = m.free_cells(anchor[:, :3])
+        st.append(dict(m=m, dev=None if fc["free"] is None else m.ground_cells_enqueue(fc, anchor, proj_matrix, image_size)))
+    host = [None if e["dev"] is None else (e["dev"][1].cpu(), e["dev"][2].cpu(), e["dev"][0].cpu()) for e in st]   # first .cpu() waits, the rest are ready
+    heights = torch.zeros(max(1, sum(len(it["obj_pc_ls"]) for it in items)), 2, dtype=torch.float64, device=st[0]["m"].pts.device)
+    out, k = [None] * len(items), 0
+    for i, (it, e, h) in enumerate(zip(items, st, host)):   # ---- (B) draws in scan order, road heights enqueued
+        n = 0 if h is None else int(h[0][0])
+        if h is None or n == 0 or int(h[1][0]) == 0 or int(h[1][1]) == 0:
+            out[i] = point_mixmatch(it["ori_pc"], it["ori_label"], it["obj_pc_ls"], it["obj_label_ls"], g_indices=it["g_indices"], **common)
+            continue
+        cells = h[2][:n].numpy().astype(np.int64)
+        pick = np.random.choice(cells.shape[0], len(it["obj_pc_ls"]))
+        e["placed"] = []
+        for j in range(len(it["obj_pc_ls"])):
+            cell = cells[pick[j]]
+            e["m"].road_height_enqueue(cell, heights[k])
+            e["placed"].append((cell, np.random.rand() * 0.1, k))
+            k += 1
+    hz = heights.cpu().numpy()
+    for i, (it, e) in enumerate(zip(items, st)):   # ---- (C) placements
+        if out[i] is not None:
+            continue
+        new_pc, new_lab = [], []
+        for j, (cell, jitter, kk) in enumerate(e["placed"]):
+            if hz[kk, 1] <= 0:
+                raise RuntimeError("no ground point in the chosen cell")
+            o3 = np.asarray(it["obj_pc_ls"][j])[:, :3]
+            new_pc.append(_place(o3, cell, np.float32(hz[kk, 0] / hz[kk, 1]), jitter, search_voxel_size))
+            new_lab.append(np.asarray(it["obj_label_ls"][j]))
+        m = e["m"]
+        out[i] = _assemble(m, torch.as_tensor(it["ori_label"]).to(m.pts.device), new_pc, new_lab)
     return out
 
 
@@ -177,28 +267,12 @@ def point_mixmatch(ori_pc, ori_label, obj_pc_ls, obj_label_ls, z_disc=-0.324, ob
         for i, o in enumerate(obj_pc_ls):
             o3 = np.asarray(o)[:, :3]
             cell = cells[pick[i]]
-            new_center = cell * search_voxel_size
-            oc = (np.max(o3, axis=0) + np.min(o3, axis=0)) / 2
-            occ, ncc = _cyl(oc), _cyl(new_center)
-            d_r, d_theta = ncc - occ
-            disc = np.array([d_r * np.cos(occ[1]), d_r * np.sin(occ[1]), 0])
-            rot = np.array([[np.cos(d_theta), -np.sin(d_theta), 0, 0], [np.sin(d_theta), np.cos(d_theta), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
-            disc[2] = m.road_height(cell) - np.min(o3[:, 2], axis=0) + np.random.rand() * 0.1   # :444-446
+            moved = _place(o3, cell, m.road_height(cell), np.random.rand() * 0.1, search_voxel_size)   # :444-446
             if i in ignore:
                 continue
-            t = np.eye(4)
-            t[:3, 3] = disc
-            tr = rot @ t
-            h = np.concatenate((o3, np.ones((o3.shape[0], 1))), axis=1)
-            new_pc.append((tr @ h.T).T[:, :3])
+            new_pc.append(moved)
             new_lab.append(np.asarray(obj_label_ls[i]))
-        obj_pc = torch.from_numpy(np.concatenate(new_pc, 0)).to(dev)
-        cat_pc = torch.cat([m.pts[:, :3].double(), obj_pc], 0).contiguous()
-        cat_label = torch.cat([lab, torch.from_numpy(np.concatenate(new_lab, 0)).to(dev).to(lab.dtype)], 0)
-        mask = torch.zeros(cat_pc.shape[0], dtype=torch.bool, device=dev)
-        mask[n0:] = True
-        mask.n_obj = cat_pc.shape[0] - n0     # known on the host: post_process need not read it back from the device
-        return cat_pc, cat_label, mask, mask.clone()
+        return _assemble(m, lab, new_pc, new_lab)
     none = torch.zeros(n0, dtype=torch.bool, device=dev)
     none.n_obj = 0
     return m.pts[:, :3].double().contiguous(), lab, none, none.clone()

@@ -122,3 +122,30 @@ def test_front_view_insertion_matches_the_reference(golden_dir, k):
     assert np.array_equal(objs[0], g[f"objs_after{k}_0"]) and np.array_equal(objs[1], g[f"objs_after{k}_1"])
     with pytest.raises(ValueError):
         vgi.point_mixmatch(c["ori_pc"], c["label"], objs, c["obj_labels"], insert_mode="sideways")
+
+
+def test_batched_insertion_equals_the_per_scan_loop():
+    """`point_mixmatch_batch` (two host round trips per batch) == the reference's per-scan loop (`train_xmuda_mopa.py:516-555`) under
+    the same numpy seed: same RNG draws in the same order, so the same cells, the same placements, bit for bit -- including a scan
+    whose first anchor fits nowhere (case 2: it takes the sequential path at its turn, between the fast-path scans)."""
+    from mopa_amd import vgi
+    cases = [_case(k) for k in (0, 2, 4)]                      # all with front axis y (one projection per batch, like a data set)
+    assert {c["front"] for c in cases} == {"y"}
+    kw = dict(search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0, proj_matrix=cases[0]["proj"],
+              image_size=cases[0]["image_size"], front_axis="y")
+
+    def items():
+        return [dict(ori_pc=torch.from_numpy(c["ori_pc"]).cuda(), ori_label=c["label"], obj_pc_ls=[o.copy() for o in c["objs"]],
+                     obj_label_ls=c["obj_labels"], g_indices=c["g_mask"]) for c in cases]
+
+    np.random.seed(77)
+    loop = [vgi.point_mixmatch(it["ori_pc"], it["ori_label"], it["obj_pc_ls"], it["obj_label_ls"], insert_mode="ground",
+                               g_indices=it["g_indices"], **kw) for it in items()]
+    after_loop = np.random.rand()
+    np.random.seed(77)
+    batch = vgi.point_mixmatch_batch(items(), **kw)
+    assert np.random.rand() == after_loop                       # the global RNG ends in the same state
+    assert len(batch) == len(loop) == 3
+    for a, b in zip(loop, batch):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert a[2].n_obj == b[2].n_obj and int(b[2].sum()) > 0
