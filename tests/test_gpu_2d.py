@@ -371,6 +371,47 @@ def test_winograd_f4_network_level(monkeypatch):
         _close(of[k], o2[k], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 128, 128), (1, 112, 128), (1, 126, 130), (2, 90, 46)])
+def test_f4_forward_at_the_min_pixels_boundary(B, H, W, monkeypatch):
+    """Image sizes around dense2d.F4_FWD_MIN_PIXELS (4,096 samples per channel: below it the FORWARD pass keeps the exact-product
+    kernels because layers that normalise over few samples amplify ReLU flips): 128x128 puts layer1 exactly ON the threshold
+    (64 x 64), 112x128 just below (56 x 64 = 3,584), 126x130 is odd and pads to 128x144, 2x90x46 mixes both sides across the
+    stages.  Logits within the stated tolerance of the fp64 oracle, and within 1e-4 of the exact-product forward."""
+    from mopa_amd import dense2d
+    import os
+    if os.environ.get("MOPA_WINOGRAD", "1") == "0" or os.environ.get("MOPA_WINOGRAD_F4", "1") == "0":
+        pytest.skip("Winograd F(4x4) switched off for this run")
+    rng = np.random.Generator(np.random.PCG64(100 + H + W))
+    img = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32))
+    idx = [np.stack([rng.integers(0, H, 200), rng.integers(0, W, 200)], 1) for _ in range(B)]
+    picked = []
+    inner = dense2d.wino_tile
+
+    def spy(cin, cout, k, s, p, B_, H_, W_, role="fwd"):
+        f = inner(cin, cout, k, s, p, B_, H_, W_, role)
+        picked.append((role, B_ * H_ * W_, f))
+        return f
+
+    monkeypatch.setattr(dense2d, "wino_tile", spy)
+
+    def run(roles):
+        monkeypatch.setattr(dense2d, "F4_ROLES", roles)
+        model = _build_2d().train()
+        model.net_2d.dropout.p = 0.0
+        return {k: v.detach().cpu() for k, v in model({"img": img, "img_indices": idx}).items()}
+
+    of = run(("fwd", "dgrad", "wgrad"))
+    fwd = [(n, f) for role, n, f in picked if role == "fwd"]
+    assert all(f != 4 for n, f in fwd if n < dense2d.F4_FWD_MIN_PIXELS)          # below the threshold: never F(4x4) in the forward pass
+    assert any(f == 4 for n, f in fwd if n >= dense2d.F4_FWD_MIN_PIXELS)         # at / above it: F(4x4) runs
+    oe = run(("dgrad", "wgrad"))
+    P = {k: (det_tensor(k, v).double() if "num_batches" not in k else det_tensor(k, v)) for k, v in net2d.param_shapes(5, True).items()}
+    ref = net2d.net2dseg_forward(P, img.double(), idx, training=True, dropout_p=0.0)
+    for k in ("feats", "seg_logit", "seg_logit2", "seg_logit_all"):
+        _close(of[k], ref[k].detach().float(), rtol=1e-3, atol=2e-4)
+        _close(of[k], oe[k], rtol=1e-3, atol=1e-4)
+
+
 def test_cached_weight_layouts_follow_every_kind_of_weight_update():
     """Forward / backward-data weight layouts are cached per weight version: an optimizer step through the flat buffer
     (HIP kernel, invisible to autograd's version counters), a tracked in-place update and an EMA swap must all be seen."""
