@@ -762,14 +762,16 @@ def main():
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
         fam_path = os.path.join(ROOT, "profiles", "r3_rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
-        t3 = os.path.join(ROOT, "profiles", "r3_3d_hbm_traffic.json")  # PMC passes of `bench.py --workload 3d` (profiles/traffic.py)
-        if sp and os.path.exists(t3):
+        # (the joint step runs the 3D branch on the same scans as `--workload 3d`: its sparse-conv launches move the same bytes)
+        t3_key = {"3d": "3d", "joint": "3d", "kitti": "kitti"}.get(wl_key)
+        t3 = os.path.join(ROOT, "profiles", f"r3_{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
+        if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
             fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
-                sp["traffic_source"] = ("profiles/r3_3d_hbm_traffic.json at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                        "`bench.py --workload 3d`, per launch)" % d3.get("_commit", "?"))
+                sp["traffic_source"] = ("profiles/r3_%s_hbm_traffic.json at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "`bench.py --workload %s`, per launch)" % (t3_key, d3.get("_commit", "?"), t3_key))
         if sp and joint:
             # inside the joint step the family shares the chip and its (lower-priority) side stream with the 2D GEMMs: an event
             # bracket there is mostly queue wait, not kernel time.  `frac` is therefore NOT reported from it; see frac_rocprof (kernel
