@@ -323,10 +323,14 @@ __device__ __forceinline__ int table_lookup(const uint64_t* __restrict__ tk, con
 }
 
 // nbr[o][i] = row of voxel at pos(i) + off(o), o = (dx+1)*9 + (dy+1)*3 + (dz+1)  (A.4), or -1.
+// The table is point-symmetric -- nbr[o][i] = j  <=>  nbr[26 - o][j] = i -- so only offsets 0 .. 12 are probed (13 random hash
+// probes per row instead of 26: the probes were 7x the kernel's algorithmic bytes, a 64-byte sector per 8-byte key); a hit also
+// writes the mirrored entry, rows 14 .. 26 are pre-filled with -1 (every entry is written by at most one thread: the mirror of
+// (o, i) is unique).  Same table bit for bit.
 __global__ __launch_bounds__(256) void k_rulebook_subm(const uint64_t* __restrict__ row_keys, int A,
                                                         const uint64_t* __restrict__ tk, const int* __restrict__ tv,
                                                         uint32_t mask, int size, int* __restrict__ nbr) {
-  int64_t total = (int64_t)A * 27;
+  int64_t total = (int64_t)A * 14;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     int o = (int)(t / A), i = (int)(t - (int64_t)o * A);
     int r;
@@ -343,16 +347,21 @@ __global__ __launch_bounds__(256) void k_rulebook_subm(const uint64_t* __restric
         uint64_t q = (k & ~0xFFFFFFFFFull) | ((uint64_t)x << 24) | ((uint64_t)y << 12) | (uint64_t)z;
         r = table_lookup(tk, tv, mask, q);
       }
+      if (r >= 0) nbr[(int64_t)(26 - o) * A + r] = i;
     }
     nbr[t] = r;
   }
 }
 
+__global__ void k_fill_i32(int* __restrict__ p, int64_t n, int v);
+
 MOPA_API int mopa_rulebook_subm(const uint64_t* row_keys, int32_t num_rows, const uint64_t* table_keys,
                                 const int32_t* table_vals, int64_t table_cap, int32_t spatial_size,
                                 int32_t* nbr /*[27][num_rows]*/, void* stream) {
   if (num_rows <= 0 || (table_cap & (table_cap - 1)) != 0) return MOPA_ERR_ARG;
-  k_rulebook_subm<<<stream_grid((int64_t)num_rows * 27, 256), 256, 0, (hipStream_t)stream>>>(
+  k_fill_i32<<<stream_grid((int64_t)num_rows * 13, 256), 256, 0, (hipStream_t)stream>>>(nbr + (int64_t)14 * num_rows, (int64_t)num_rows * 13, -1);
+  MOPA_CHECK_LAUNCH();
+  k_rulebook_subm<<<stream_grid((int64_t)num_rows * 14, 256), 256, 0, (hipStream_t)stream>>>(
       row_keys, num_rows, table_keys, table_vals, (uint32_t)(table_cap - 1), spatial_size, nbr);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
