@@ -51,18 +51,33 @@ class _FlatCache:
     their identity under load_state_dict / optimizer updates; `Module._apply` (.cuda(), .to(), .float()) replaces buffer objects
     and assigning a sub-module or parameter to the network (`model.linear = nn.Linear(64, 11)` for another label set) replaces
     parameter objects: the owning module drops the cache in both cases (`_CachedParams`).  Anything that swaps tensor OBJECTS
-    deeper inside (`load_state_dict(..., assign=True)`, `model.net_2d.layer4 = ...`) must be followed by
-    `model.refresh_parameters()`."""
+    deeper inside (`load_state_dict(..., assign=True)`, `model.net_2d.layer4.to(...)`) is caught by the per-forward identity check
+    below when it keeps the module objects; replacing a whole sub-module (`model.net_2d.layer4 = ...`) still needs
+    `model.refresh_parameters()` (the cached owner dictionaries belong to the old module)."""
 
     def __init__(self):
-        self.order, self.flat = None, None
+        self.order, self.flat, self._owners = None, None, None
 
     def get(self, module):
+        if self.flat is not None:
+            # cheap per-forward validation (ADVICE r2): every cached tensor must still be the object its owning sub-module holds --
+            # two dict lookups per entry (~20-50 us per forward); a stale entry (sub-module .to() / load_state_dict(assign=True) /
+            # a replaced layer) would otherwise let the kernels update orphaned running statistics silently.  Stale -> rebuilt.
+            for (params, bufs, attr), t in zip(self._owners, self.flat):
+                if params.get(attr) is not t and bufs.get(attr) is not t:
+                    self.flat = None
+                    self.__dict__.pop("native", None)     # the native executor's pointer tables belong to the old objects
+                    break
         if self.flat is None:
             self.order = [k for k, _ in module.named_parameters() if not k.startswith("linear3.")] + [k for k, _ in module.named_buffers()]
             tensors = dict(module.named_parameters())
             tensors.update(dict(module.named_buffers()))
             self.flat = [tensors[k] for k in self.order]
+            self._owners = []
+            for k in self.order:
+                prefix, _, attr = k.rpartition(".")
+                owner = module.get_submodule(prefix) if prefix else module
+                self._owners.append((owner._parameters, owner._buffers, attr))
         return self.order, self.flat
 
 

@@ -167,3 +167,26 @@ def test_parameter_list_cache_follows_module_surgery():
         m._cache.get(m)
         m.refresh_parameters()
         assert m._cache.flat is None
+
+
+def test_parameter_cache_notices_replaced_tensor_objects():
+    """`load_state_dict(assign=True)` / `sub_module.to(...)` swap tensor OBJECTS inside sub-modules; the cached flat
+    list must follow (the kernels would otherwise update orphaned running statistics)."""
+    import torch
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    m, _ = build_model_3d(default_cfg())
+    order, flat = m._cache.get(m)
+    assert m._cache.get(m)[1] is flat                                    # unchanged objects: the same list
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)                                   # every parameter / buffer object is replaced
+    order2, flat2 = m._cache.get(m)
+    named = dict(m.named_parameters())
+    named.update(dict(m.named_buffers()))
+    assert order2 == order and all(t is named[k] for k, t in zip(order2, flat2)) and flat2 is not flat
+    bn = next(mod for mod in m.modules() if "running_mean" in mod._buffers)
+    bn.double()                                                          # Module._apply on a SUB-module replaces its buffers
+    _, flat3 = m._cache.get(m)
+    named = dict(m.named_parameters())
+    named.update(dict(m.named_buffers()))
+    assert all(t is named[k] for k, t in zip(order2, flat3))
