@@ -436,6 +436,8 @@ def main():
     bracket_overhead_us = round(sorted(a.elapsed_time(b) * 1e3 for a, b in _ev)[50], 2)
     from mopa_amd import sparse3d as sparse3d_mod
     native_default = sparse3d_mod.NATIVE
+    from mopa_amd import dense2d as dense2d_mod
+    graph2d_default = dense2d_mod.GRAPH_2D
     timer = ConvTimer()
     timer.install()
     timer2d = Conv2dTimer()
@@ -693,6 +695,7 @@ def main():
         # a bracketed step walks the 3D layer program from Python (same kernels, same order, bit-identical: tests/test_gpu_3d.py) so
         # that every sparse-conv launch can be bracketed; all other steps run it as one native call per pass (csrc/scn_exec.hip)
         sparse3d_mod.NATIVE = native_default and not timer.enabled
+        dense2d_mod.GRAPH_2D = graph2d_default and not timer2d.enabled   # same for the 2D backbone: brackets need the eager walk
         # the bracketed steps run in the SAME stream configuration as every other step (weight-gradient stream and 3D side stream
         # on): the brackets then time each launch as it runs inside `value`'s step, sharing the chip with the other streams --
         # which is also what `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r3_final_*)
@@ -723,6 +726,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = timer2d.enabled = False
     sparse3d_mod.NATIVE = native_default
+    dense2d_mod.GRAPH_2D = graph2d_default
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -846,7 +850,11 @@ def main():
                        "allreduces_per_step": round(sum(o.n_collectives for o in opts) / max(1, steps_run[0]), 2),
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
-                       else "python walk (MOPA_SCN_NATIVE=0)"},
+                       else "python walk (MOPA_SCN_NATIVE=0)",
+                       "net2d_executor": (None if not joint else
+                                          f"HIP-graph replay of the backbone ({dense2d_mod.GRAPH_STATS['forward_replays']} forward / "
+                                          f"{dense2d_mod.GRAPH_STATS['backward_replays']} backward replays in this process; heads and "
+                                          "bracketed steps eager)" if graph2d_default else "eager (default; MOPA_GRAPH_2D=1 replays the backbone from HIP graphs)")},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "value_with_host_inputs": None if host_value is None else round(host_value[0], 3),
             "host_inputs_note": None if host_value is None else (

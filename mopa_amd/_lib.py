@@ -112,6 +112,7 @@ SIGNATURES = {
     "mopa_maxpool3x3s2_fwd": ("i", "piiiiipipp"),
     "mopa_maxpool3x3s2_bwd": ("i", "pipiiiipiip"),
     "mopa_dropout_rows": ("i", "pipiliflp"),
+    "mopa_dropout_rows_dseed": ("i", "pipilifpip"),
     "mopa_pixel_head_fwd": ("i", "piiiiiiiipppp"),
     "mopa_pixel_head_bwd_workspace_bytes": ("z", "iiiii"),
     "mopa_pixel_head_bwd": ("i", "ppiiiiiiiippiippipzp"),

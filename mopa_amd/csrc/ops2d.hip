@@ -99,9 +99,11 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t i) {
   return (uint32_t)(z >> 16);
 }
 __global__ void k_dropout_rows(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int64_t rows, int C,
-                               uint64_t seed, uint32_t keep_thresh, float scale, int identity) {
+                               uint64_t seed, uint32_t keep_thresh, float scale, int identity,
+                               const int64_t* __restrict__ seed_dev, int site) {
   const int CQ = C >> 2;
   const int64_t total = rows * CQ;
+  if (seed_dev) seed = (uint64_t)seed_dev[0] * 2 + (uint64_t)site;   // the seed lives in device memory (HIP-graph replays)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / CQ;
     const int cq = (int)(i - row * CQ);
@@ -124,7 +126,22 @@ MOPA_API int mopa_dropout_rows(const float* x, int32_t ldx, float* y, int32_t ld
   const double keep = 1.0 - (double)p;
   const uint32_t thresh = keep >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(keep * 4294967296.0);
   k_dropout_rows<<<stream_grid(rows * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, rows, C, seed, thresh,
-                                                                                     (float)(1.0 / keep), p == 0.f);
+                                                                                     (float)(1.0 / keep), p == 0.f, nullptr, 0);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// The same op with the call's seed read from device memory at run time: mask of (seed_dev[0] * 2 + site), i.e. what
+// mopa_dropout_rows(..., seed = seed_dev[0] * 2 + site) draws.  For launches recorded once into a HIP graph and replayed with a
+// new seed per iteration (mopa_amd/dense2d.py, graph replay of the 2D backbone).
+MOPA_API int mopa_dropout_rows_dseed(const float* x, int32_t ldx, float* y, int32_t ldy, int64_t rows, int32_t C, float p,
+                                     const int64_t* seed_dev, int32_t site, void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 3) || ldx < C || ldy < C || ((ldx | ldy) & 3) || p < 0.f || p >= 1.f || !seed_dev || site < 0 || site > 1)
+    return MOPA_ERR_ARG;
+  const double keep = 1.0 - (double)p;
+  const uint32_t thresh = keep >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(keep * 4294967296.0);
+  k_dropout_rows<<<stream_grid(rows * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, rows, C, 0, thresh,
+                                                                                     (float)(1.0 / keep), p == 0.f, seed_dev, site);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

@@ -73,6 +73,11 @@ def relayout(src, dst, O, I, KH, KW, mode, inverse=False, accumulate=False):
     call("mopa_conv2d_relayout_weight", ptr(src), ptr(dst), O, I, KH, KW, mode, int(inverse), int(accumulate), stream())
 
 
+class _CaptureMiss(RuntimeError):
+    """Raised while recording a HIP graph when the pass needs something the eager first pass did not leave behind."""
+
+
+_CAPTURE = None   # raw handle of the stream that will replay the graph being recorded (None: not recording)
 _relayout_cache = {}
 _refreshed = {}   # stream -> WEIGHTS_EPOCH of the last batched refresh
 BATCHED_REFRESH = os.environ.get("MOPA_BATCHED_REFRESH", "1") != "0"   # A/B switch: one launch for all stale weight forms
@@ -116,6 +121,13 @@ def _cached_weight_form(w, form, build, meta=None):
     together with all other stale ones."""
     import weakref
     from ._lib import WEIGHTS_EPOCH
+    if _CAPTURE is not None:
+        # launches are being recorded into a HIP graph (Graph2D below): hand out the form that the replaying stream owns and record
+        # nothing -- Graph2D.replay brings every form of that stream up to date (one batched launch) before each replay
+        hit = _relayout_cache.get((id(w), form, _CAPTURE))
+        if hit is None or hit[2]() is not w:
+            raise _CaptureMiss(f"weight form {form} of a {tuple(w.shape)} weight was never built on the replaying stream")
+        return hit[1]
     st = stream()
     key = (id(w), form, st)
     tag = (WEIGHTS_EPOCH[0], w._version, w.data_ptr())
@@ -461,6 +473,358 @@ def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, train
          ptr(dgamma), ptr(dbeta), int(acc_params), int(acc_dx), ptr(ws), ws.numel(), stream())
 
 
+# ------------------------------------------------------------------------------------------------ the backbone passes
+def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev):
+    """UNetResNet34 on a contiguous fp32 (B,3,H,W) image -> (feat, tape, J).  feat: (B, Hp, Wp, 64) NHWC, the /16-padded decoder
+    output; tape: what the backward pass walks; J: the join buffers.  Every launch goes to the current stream, nothing is read
+    back: the pass can be recorded into a HIP graph (Graph2D).  seed_t: int64 device scalar holding the dropout seed (graph
+    replays), else the seed is passed by value."""
+    pre = "net_2d."
+    B, _, H, W = imgc.shape
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    tape = []
+    nbt = []   # BatchNorm2d.num_batches_tracked of every layer that ran: bumped together at the end (one launch, not 43)
+
+    def bn(name, x, act=1, res=None, out=None):
+        y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
+        stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
+        gathered = bn_fwd(x, y, P, name, act, res, training, stats)
+        if training:
+            nbt.append(P[name + ".num_batches_tracked"])
+        tape.append(("bn", name, x, y, stats, act, res, gathered))
+        return y
+
+    def conv(name, x, k, s, p, bias=False, out=None):
+        op = ConvOp(P[name + ".weight"], P[name + ".bias"] if bias else None, k, s, p)
+        oh, ow = op.out_hw(x.H, x.W)
+        out = out if out is not None else new_img(x.B, oh, ow, op.O, dev)
+        V = op.forward(x, out, keep_v=training)   # Winograd layers: the transformed input serves the weight gradient again
+        tape.append(("conv", name, op, x, out, V))
+        return out
+
+    def convT(name, x):
+        op = ConvTOp(P[name + ".weight"], P[name + ".bias"])
+        out = new_img(x.B, 2 * x.H, 2 * x.W, op.O, dev)
+        op.forward(x, out)
+        tape.append(("convT", name, op, x, out))
+        return out
+
+    def dropout(x, site, out=None):
+        y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
+        p = drop_p if training else 0.0
+        dropout_rows(x, y, p, drop_seed, seed_t, site)
+        tape.append(("dropout", site, x, y, p))
+        return y
+
+    # ---- stem (resnet34_unet.py:144-148): conv1 7x7 s1 p3 on the /16-padded image, bn1, relu, maxpool
+    x4 = torch.empty(B, Hp + 6, Wp + 8, 4, dtype=torch.float32, device=dev)
+    call("mopa_img_to_nhwc4", ptr(imgc), B, H, W, Hp, Wp, ptr(x4), stream())
+    w1 = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
+    call("mopa_conv2d_stem_relayout", ptr(P[pre + "conv1.weight"]), ptr(w1), 64, 0, 0, stream())
+    c1 = new_img(B, Hp, Wp, 64, dev)
+    stem_g = _geom(B=B, IH=Hp + 6, IW=Wp + 8, OHl=Hp, OWl=Wp, OHa=Hp, OWa=Wp, IDX=4, TH=7, TW=2, KWF=2, Cin=16,
+                   Cout=64, ld_in=4, ld_out=64)
+    igemm(ptr(x4), w1, None, c1.p, stem_g)
+    tape.append(("stem", x4, c1, stem_g))
+    J = {}  # join buffers: [skip | upsampled]
+    J[0] = torch.empty(B * Hp * Wp, 128, dtype=torch.float32, device=dev)
+    skip0 = bn(pre + "bn1", c1, out=Img(J[0], B, Hp, Wp, 0, 64))
+    H2, W2 = Hp // 2, Wp // 2
+    x = new_img(B, H2, W2, 64, dev)
+    amax = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)
+    call("mopa_maxpool3x3s2_fwd", skip0.p, skip0.ld, B, Hp, Wp, 64, x.p, x.ld, ptr(amax), stream())
+    tape.append(("maxpool", skip0, x, amax))
+    # ---- encoder stages
+    for li, (lname, c, nblocks, stride) in enumerate(LAYERS):
+        for b in range(nblocks):
+            q = f"{pre}{lname}.{b}."
+            s = stride if b == 0 else 1
+            has_ds = (q + "downsample.0.weight") in P
+            y1 = bn(q + "bn1", conv(q + "conv1", x, 3, s, 1))
+            z = conv(q + "conv2", y1, 3, 1, 1)
+            idt = bn(q + "downsample.1", conv(q + "downsample.0", x, 1, s, 0), act=0) if has_ds else x
+            last = b == nblocks - 1
+            out = None
+            if last and lname in ("layer1", "layer2"):
+                lvl = li + 1
+                J[lvl] = torch.empty(z.rows, 2 * c, dtype=torch.float32, device=dev)
+                out = Img(J[lvl], z.B, z.H, z.W, 0, c)
+            tape.append(("block_in", x))
+            x = bn(q + "bn2", z, act=1, res=idt, out=out)
+        if lname == "layer3":   # dropout, then the result is skip3 AND layer4's input (:153-155)
+            J[3] = torch.empty(x.rows, 2 * c, dtype=torch.float32, device=dev)
+            x = dropout(x, 0, out=Img(J[3], x.B, x.H, x.W, 0, c))
+        if lname == "layer4":
+            x = dropout(x, 1)
+    # ---- decoder (:165-182): ConvT+BN+ReLU into the right half of the join buffer, conv3x3 on [skip | up]
+    for stage, lvl in (("5", 3), ("4", 2), ("3", 1), ("2", 0)):
+        tname = f"{pre}dec_t_conv_stage{stage}."
+        up_raw = convT(tname + "0", x)
+        cj = J[lvl].shape[1] // 2
+        bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
+        joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
+        tape.append(("join", lvl, cj))
+        if lvl == 0:
+            x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
+        else:
+            cname = f"{pre}dec_conv_stage{int(stage) - 1}."
+            x = bn(cname + "1", conv(cname + "0", joined, 3, 1, 1, bias=True))
+    if nbt:
+        torch._foreach_add_(nbt, 1)
+    return x, tape, J   # x: (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
+
+
+def dropout_rows(x: View, y: View, p, seed, seed_t, site):
+    if seed_t is not None:
+        call("mopa_dropout_rows_dseed", x.p, x.ld, y.p, y.ld, x.rows, x.C, float(p), ptr(seed_t), site, stream())
+    else:
+        call("mopa_dropout_rows", x.p, x.ld, y.p, y.ld, x.rows, x.C, float(p), seed * 2 + site, stream())
+
+
+def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_t, want_dimg, H, W):
+    """Walk the tape backwards from dfeat = d(loss)/d(feat); parameter gradients go through `sink`.  -> d(loss)/d(img) (fp32,
+    (B,3,H,W)) if want_dimg else None.  Ends with the weight-gradient stream joined.  Recordable like _backbone_forward."""
+    dev = feat.t.device
+    pre = "net_2d."
+    B, Hp, Wp = feat.B, feat.H, feat.W
+    gmap = {}
+    dimg = None
+
+    def key(v):
+        return (v.t.data_ptr(), v.col, v.C)
+
+    def like(v: Img, zero=False):
+        return new_img(v.B, v.H, v.W, v.C, dev, zero=zero)
+
+    gmap[key(feat)] = dfeat
+    dJ = {}  # gradient buffers of the join tensors (full width)
+    for rec in reversed(tape):
+        kind = rec[0]
+        if kind == "bn":
+            _, name, x, y, stats, act, res, gathered = rec
+            dy = gmap.pop(key(y))
+            dres = None
+            acc_dres = False
+            if res is not None:
+                k = key(res)
+                if k in gmap:
+                    dres, acc_dres = gmap[k], True
+                else:
+                    dres = like(res)
+                    gmap[k] = dres
+            dx = like(x)
+            gmap[key(x)] = dx
+            (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
+            bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, training, dg, db,
+                   acc_params=pacc, gathered=gathered)
+        elif kind == "conv":
+            _, name, op, x, out, V = rec
+            dout = gmap.pop(key(out))
+            k = key(x)
+            acc = k in gmap
+            dx = gmap[k] if acc else like(x)
+            gmap[k] = dx
+            pg, pacc = sink.take(*([name + ".weight"] + ([name + ".bias"] if op.b is not None else [])))
+            op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc, V=V, wgrad_side=True)
+        elif kind == "convT":
+            _, name, op, x, out = rec
+            dout = gmap.pop(key(out))
+            dx = like(x)
+            gmap[key(x)] = dx
+            (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
+            op.backward(x, dout, dx, dw, db, acc_params=pacc, wgrad_side=True)
+        elif kind == "join":
+            _, lvl, cj = rec
+            full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
+            dJ[lvl] = full
+            if DEBUG is not None:
+                DEBUG[f"dJ{lvl}"] = full.t.clone()
+            gmap[(J[lvl].data_ptr(), 0, cj)] = Img(full.t, full.B, full.H, full.W, 0, cj)
+            gmap[(J[lvl].data_ptr(), cj, cj)] = Img(full.t, full.B, full.H, full.W, cj, cj)
+        elif kind == "dropout":
+            _, site, x, y, p = rec
+            dy = gmap.pop(key(y))
+            dx = like(x)
+            gmap[key(x)] = dx
+            dropout_rows(dy, dx, p, drop_seed, seed_t, site)
+        elif kind == "maxpool":
+            _, x, y, amax = rec
+            dy = gmap.pop(key(y))
+            k = key(x)
+            acc = k in gmap
+            dx = gmap[k] if acc else like(x)
+            gmap[k] = dx
+            call("mopa_maxpool3x3s2_bwd", dy.p, dy.ld, ptr(amax), x.B, x.H, x.W, x.C, dx.p, dx.ld, int(acc), stream())
+        elif kind == "stem":
+            _, x4, c1, g = rec
+            dout = gmap.pop(key(c1))
+            (dw,), pacc = sink.take(pre + "conv1.weight")
+            with _on(wgrad_stream(dev), x4, dout.t, dw):
+                dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
+                wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
+                call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
+            if want_dimg:   # gradient w.r.t. the image itself (not asked for by MoPA's training)
+                dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+                call("mopa_stem_dgrad_image", dout.p, dout.ld, B, Hp, Wp, H, W, ptr(P[pre + "conv1.weight"]), ptr(dimg), stream())
+        elif kind == "block_in":
+            pass
+    join_wgrad_stream(dev)   # the weight gradients are complete for whatever the caller queues next
+    return dimg
+
+
+# ------------------------------------------------------------------------------------------------ HIP-graph replay of the backbone
+# The backbone is ~200 launches forward and ~260 backward through the C ABI, every one of them with arguments that depend only on
+# (B, H, W), the parameter addresses and the mode flags: for a training loop on fixed-size crops the whole launch sequence is a
+# constant.  Enqueuing it from Python costs ~10 ms per forward + backward (6.6 us per launch + the interpreter around it,
+# profiles/host_profile_2d.py) -- as long as the GPU needs for a 2-image batch -- and leaves gaps between the short kernels of the
+# deep layers.  Graph2D records the forward launches once into a HIP graph and the backward launches into a second one (the fork to
+# the weight-gradient stream and its join included) and replays them: same kernels, same order, same addresses, bit-identical
+# results (tests/test_gpu_2d.py).  What stays outside the graphs is whatever depends on the number of points: the two heads, their
+# backward passes and the losses.
+#
+# Rules that keep a replay equal to the eager pass:
+#   * recorded on the SECOND call of a (shape, mode, stream) key -- the first runs eagerly and leaves every kernel attribute, weight
+#     form and workspace behind; while recording, a weight form is the tensor the replaying stream's cache owns (_CAPTURE above)
+#     and Graph2D.forward refreshes the stale ones in one launch before each replay, exactly as the eager pass does;
+#   * inputs are copied into fixed buffers (image, dropout seed, d(feat)); parameters, BatchNorm buffers and attached gradient
+#     buffers are addressed in place, and their addresses are checked before every replay (changed -> graphs dropped, eager);
+#   * the activations a forward replay leaves are the ones the next backward reads: a second forward before that backward (two
+#     batches through the network, then one loss) runs eagerly instead;
+#   * the backward graph accumulates into the attached .grad buffers (FlatAdam's flat buffer); a parameter without an attached
+#     gradient -> the backward walks the recorded tape eagerly (autograd gets its gradient tensors as usual).
+# OFF by default (MOPA_GRAPH_2D=1 switches it on), because it does not pay on this platform -- measured on an MI355X, ROCm 7.2
+# (profiles/graph_probe.py; gpurun_out/g2d_*): the 2D branch ALONE, 8 x 302 x 480, forward + backward: 26.3 ms eager -> 23.9 ms
+# replayed (the launch gaps of the deep layers close), but hipGraphLaunch itself keeps the host for 4.6 ms (2 images) to 11 ms (8)
+# per replay -- the runtime walks the ~460 nodes and enqueues one packet each -- and while it does, the host cannot feed the 3D
+# branch's stream: inside the joint step the replayed backbone LOSES, 319 -> 300 scans/s (nuScenes shape), 227 -> 190 (MoPA
+# iteration), 131-152 -> 135-142 (SemanticKITTI shape, within box noise).  Kept as an option for 2D-only loops and for a runtime
+# whose graph launch is cheap.  Training mode with gradients enabled only; not under synchronised BatchNorm (its collectives are
+# issued from Python between the kernels).
+GRAPH_2D = os.environ.get("MOPA_GRAPH_2D", "0") == "1"
+GRAPH_2D_MAX_KEYS = 4        # distinct (shape, mode, stream) keys recorded per network; further ones run eagerly
+GRAPH_STATS = {"recorded": 0, "forward_replays": 0, "backward_replays": 0, "eager_busy": 0, "eager_backward": 0, "dropped": 0}
+
+
+class _Token:
+    __slots__ = ("__weakref__",)
+
+
+class Graph2D:
+    """The recorded forward and backward pass of the backbone for one (B, H, W, training, dropout p, stream)."""
+
+    def __init__(self, B, H, W, dev):
+        self.B, self.H, self.W, self.dev = B, H, W, dev
+        self.calls = 0            # eligible passes seen with this key
+        self.eager_backward_seen = False   # recording starts once a whole eager forward + backward has run with this key
+        self.fwd = self.bwd = None
+        self.failed = False
+        self.pending = None       # weak reference to the token of the forward whose backward has not run yet
+        self.generation = 0       # bumped by every forward replay: a backward of an older forward must not read the activations
+
+    def busy(self):
+        return self.pending is not None and self.pending() is not None
+
+    # -- recording
+    def _record(self, fn, pool):
+        global _CAPTURE
+        g = torch.cuda.CUDAGraph()
+        main = stream()
+        _CAPTURE = main
+        try:
+            # thread-local error mode: other threads (RCCL's watchdog polls events) must not invalidate the recording
+            with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode="thread_local"):
+                out = fn()
+        finally:
+            _CAPTURE = None
+        return g, out
+
+    def record_forward(self, P, flat, training, drop_p):
+        self.side = torch.cuda.Stream(device=self.dev)   # the recording stream (replays run on the caller's)
+        self.img = torch.empty(self.B, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
+        self.seed_t = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.training, self.drop_p = training, drop_p
+        self.fwd, (self.feat, self.tape, self.J) = self._record(
+            lambda: _backbone_forward(P, self.img, training, drop_p, 0, self.seed_t, self.dev), None)
+        self.dfeat = new_img(self.feat.B, self.feat.H, self.feat.W, 64, self.dev)
+        self.ptrs = tuple(t.data_ptr() for t in flat)
+        GRAPH_STATS["recorded"] += 1
+
+    def params_moved(self, flat):
+        return len(flat) != len(self.ptrs) or any(t.data_ptr() != a for t, a in zip(flat, self.ptrs))
+
+    # -- replays
+    def forward(self, imgc, seed):
+        self.img.copy_(imgc)
+        if self.training and self.drop_p > 0.0:
+            self.seed_t.fill_(seed)
+        _refresh_stale_forms(stream())   # every cached weight form of this stream that an update made stale: one launch
+        self.fwd.replay()
+        self.generation += 1
+        GRAPH_STATS["forward_replays"] += 1
+
+    def grads_attached(self, P, order):
+        sink = GradSink(P, order)
+        ptrs = []
+        for n in order:
+            p = P[n]
+            if not p.requires_grad:
+                continue
+            if not sink._attached(p):
+                return None
+            ptrs.append(p.grad.data_ptr())
+        return tuple(ptrs)
+
+    def backward(self, P, order):
+        """Replay (recording first if need be) the backward pass from self.dfeat.  False: cannot (gradients not attached, or moved
+        since the recording) -- the caller walks self.tape eagerly."""
+        gp = self.grads_attached(P, order)
+        if gp is None or self.failed:
+            return False
+        if self.bwd is not None and gp != self.grad_ptrs:
+            self.bwd = None      # the optimizer re-attached its gradient buffers elsewhere: record again
+        if self.bwd is None:
+            try:
+                self.bwd, _ = self._record(
+                    lambda: _backbone_backward(P, GradSink(P, order), self.tape, self.J, self.feat, self.dfeat, self.training, 0,
+                                               self.seed_t, False, self.H, self.W), self.fwd.pool())
+            except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
+                self.failed = True
+                return False
+            self.grad_ptrs = gp
+        self.bwd.replay()
+        GRAPH_STATS["backward_replays"] += 1
+        return True
+
+
+def _graph_for(spec, imgc, training, drop_p, flat, want_dimg):
+    """-> (the Graph2D record of this pass's key or None, replay it?)."""
+    holder = getattr(spec, "graphs", None)
+    if (not GRAPH_2D or holder is None or not training or not getattr(spec, "grad_enabled", False) or syncbn.active()
+            or DEBUG is not None or want_dimg):
+        return None, False
+    graphs = holder.__dict__.setdefault("graphs2d", {})
+    B, _, H, W = imgc.shape
+    key = (B, H, W, float(drop_p), spec.num_classes, stream(), F4_ROLES, WGRAD_STREAM)
+    g = graphs.get(key)
+    if g is None:
+        if len(graphs) >= GRAPH_2D_MAX_KEYS:
+            return None, False
+        g = graphs[key] = Graph2D(B, H, W, imgc.device)
+    if g.failed:
+        return None, False
+    if g.fwd is not None and g.params_moved(flat):   # .data was re-pointed under the same parameter objects
+        del graphs[key]
+        GRAPH_STATS["dropped"] += 1
+        return None, False
+    g.calls += 1
+    if not g.eager_backward_seen:   # the first forward + backward of a key run eagerly
+        return g, False
+    if g.busy():      # the activations of the previous forward replay still wait for their backward pass
+        GRAPH_STATS["eager_busy"] += 1
+        return g, False
+    return g, True
+
+
 # ------------------------------------------------------------------------------------------------ the network
 class Net2DFunction(torch.autograd.Function):
     """img (B,3,H,W) -> feats (N,64), seg_logit, seg_logit2, seg_logit_all (B,H,W,C) as one autograd node."""
@@ -470,99 +834,26 @@ class Net2DFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # an output that no loss uses arrives as None in backward, not as a zero tensor
         dev = img.device
         P = dict(zip(spec.order, flat))
-        pre = "net_2d."
         B, _, H, W = img.shape
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-        tape = []
-        nbt = []   # BatchNorm2d.num_batches_tracked of every layer that ran: bumped together at the end (one launch, not 43)
-        ctx.bn_names = []
-
-        def bn(name, x, act=1, res=None, out=None):
-            y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
-            stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
-            gathered = bn_fwd(x, y, P, name, act, res, training, stats)
-            if training:
-                nbt.append(P[name + ".num_batches_tracked"])
-            tape.append(("bn", name, x, y, stats, act, res, gathered))
-            return y
-
-        def conv(name, x, k, s, p, bias=False, out=None):
-            op = ConvOp(P[name + ".weight"], P[name + ".bias"] if bias else None, k, s, p)
-            oh, ow = op.out_hw(x.H, x.W)
-            out = out if out is not None else new_img(x.B, oh, ow, op.O, dev)
-            V = op.forward(x, out, keep_v=training)   # Winograd layers: the transformed input serves the weight gradient again
-            tape.append(("conv", name, op, x, out, V))
-            return out
-
-        def convT(name, x):
-            op = ConvTOp(P[name + ".weight"], P[name + ".bias"])
-            out = new_img(x.B, 2 * x.H, 2 * x.W, op.O, dev)
-            op.forward(x, out)
-            tape.append(("convT", name, op, x, out))
-            return out
-
-        def dropout(x, site, out=None):
-            y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
-            p = drop_p if training else 0.0
-            call("mopa_dropout_rows", x.p, x.ld, y.p, y.ld, x.rows, x.C, float(p), drop_seed * 2 + site, stream())
-            tape.append(("dropout", site, x, y, p))
-            return y
-
-        # ---- stem (resnet34_unet.py:144-148): conv1 7x7 s1 p3 on the /16-padded image, bn1, relu, maxpool
-        x4 = torch.empty(B, Hp + 6, Wp + 8, 4, dtype=torch.float32, device=dev)
         imgc = img.contiguous().float()
-        call("mopa_img_to_nhwc4", ptr(imgc), B, H, W, Hp, Wp, ptr(x4), stream())
-        w1 = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
-        call("mopa_conv2d_stem_relayout", ptr(P[pre + "conv1.weight"]), ptr(w1), 64, 0, 0, stream())
-        c1 = new_img(B, Hp, Wp, 64, dev)
-        stem_g = _geom(B=B, IH=Hp + 6, IW=Wp + 8, OHl=Hp, OWl=Wp, OHa=Hp, OWa=Wp, IDX=4, TH=7, TW=2, KWF=2, Cin=16,
-                       Cout=64, ld_in=4, ld_out=64)
-        igemm(ptr(x4), w1, None, c1.p, stem_g)
-        tape.append(("stem", x4, c1, stem_g))
-        J = {}  # join buffers: [skip | upsampled]
-        J[0] = torch.empty(B * Hp * Wp, 128, dtype=torch.float32, device=dev)
-        skip0 = bn(pre + "bn1", c1, out=Img(J[0], B, Hp, Wp, 0, 64))
-        H2, W2 = Hp // 2, Wp // 2
-        x = new_img(B, H2, W2, 64, dev)
-        amax = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)
-        call("mopa_maxpool3x3s2_fwd", skip0.p, skip0.ld, B, Hp, Wp, 64, x.p, x.ld, ptr(amax), stream())
-        tape.append(("maxpool", skip0, x, amax))
-        # ---- encoder stages
-        for li, (lname, c, nblocks, stride) in enumerate(LAYERS):
-            for b in range(nblocks):
-                q = f"{pre}{lname}.{b}."
-                s = stride if b == 0 else 1
-                has_ds = (q + "downsample.0.weight") in P
-                y1 = bn(q + "bn1", conv(q + "conv1", x, 3, s, 1))
-                z = conv(q + "conv2", y1, 3, 1, 1)
-                idt = bn(q + "downsample.1", conv(q + "downsample.0", x, 1, s, 0), act=0) if has_ds else x
-                last = b == nblocks - 1
-                out = None
-                if last and lname in ("layer1", "layer2"):
-                    lvl = li + 1
-                    J[lvl] = torch.empty(z.rows, 2 * c, dtype=torch.float32, device=dev)
-                    out = Img(J[lvl], z.B, z.H, z.W, 0, c)
-                tape.append(("block_in", x))
-                x = bn(q + "bn2", z, act=1, res=idt, out=out)
-            if lname == "layer3":   # dropout, then the result is skip3 AND layer4's input (:153-155)
-                J[3] = torch.empty(x.rows, 2 * c, dtype=torch.float32, device=dev)
-                x = dropout(x, 0, out=Img(J[3], x.B, x.H, x.W, 0, c))
-            if lname == "layer4":
-                x = dropout(x, 1)
-        # ---- decoder (:165-182): ConvT+BN+ReLU into the right half of the join buffer, conv3x3 on [skip | up]
-        for stage, lvl in (("5", 3), ("4", 2), ("3", 1), ("2", 0)):
-            tname = f"{pre}dec_t_conv_stage{stage}."
-            up_raw = convT(tname + "0", x)
-            cj = J[lvl].shape[1] // 2
-            bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
-            joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
-            tape.append(("join", lvl, cj))
-            if lvl == 0:
-                x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
-            else:
-                cname = f"{pre}dec_conv_stage{int(stage) - 1}."
-                x = bn(cname + "1", conv(cname + "0", joined, 3, 1, 1, bias=True))
-        feat = x  # (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
+        ctx.graph_key, replay = _graph_for(spec, imgc, training, drop_p, flat, ctx.needs_input_grad[1])
+        graph = ctx.graph_key if replay else None
+        if graph is not None and graph.fwd is None:
+            try:
+                graph.record_forward(P, flat, training, drop_p)
+            except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
+                graph.failed, graph = True, None
+        if graph is not None:
+            graph.forward(imgc, drop_seed)
+            feat, tape, J = graph.feat, graph.tape, graph.J
+            ctx.token = _Token()
+            import weakref
+            graph.pending = weakref.ref(ctx.token)
+            ctx.generation = graph.generation
+        else:
+            feat, tape, J = _backbone_forward(P, imgc, training, drop_p, drop_seed, None, dev)
+        ctx.graph = graph
         # ---- heads (xmuda_arch.py:58-77)
         C = spec.num_classes
         pred_all = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
@@ -577,8 +868,6 @@ class Net2DFunction(torch.autograd.Function):
                  ptr(P["linear.bias"]), ptr(P["linear2.weight"]) if spec.dual_head else None,
                  ptr(P["linear2.bias"]) if spec.dual_head else None, ptr(feats), ptr(l1),
                  ptr(l2) if spec.dual_head else None, stream())
-        if nbt:
-            torch._foreach_add_(nbt, 1)
         ctx.spec, ctx.P, ctx.tape, ctx.J, ctx.training = spec, P, tape, J, training
         if DEBUG is not None:
             DEBUG.update({f"J{k}": v.clone() for k, v in J.items()})
@@ -597,7 +886,10 @@ class Net2DFunction(torch.autograd.Function):
         feat = ctx.feat
         dev = feat.t.device
         C = spec.num_classes
-        pre = "net_2d."
+        graph = ctx.graph
+        if graph is not None and ctx.generation != graph.generation:
+            raise RuntimeError("Net2DSeg backward: the activations of this forward pass were overwritten by a later graph replay "
+                               "(a second backward through the same pass after another forward?); set MOPA_GRAPH_2D=0")
         sink = GradSink(P, spec.order)   # gradients go straight into attached .grad buffers (accumulating)
 
         def cont(t):
@@ -606,7 +898,7 @@ class Net2DFunction(torch.autograd.Function):
         dfeats, dl1, dpred = cont(dfeats), cont(dl1), cont(dpred)
         dl2 = cont(dl2) if (spec.dual_head and dl2 is not None and dl2.numel()) else None
         # ---- heads: d(feat) = point-head part (dense over all pixels, zeros where no point) + full-image part
-        dfeat = new_img(B, Hp, Wp, 64, dev)
+        dfeat = graph.dfeat if graph is not None else new_img(B, Hp, Wp, 64, dev)
         head_w_acc = False
         if N > 0 and (dfeats is not None or dl1 is not None or dl2 is not None):
             rows = B * Hp * Wp
@@ -632,88 +924,16 @@ class Net2DFunction(torch.autograd.Function):
             ws = _ws(query("mopa_pixel_head_bwd_workspace_bytes", B, H, W, 64, C), dev)
             call("mopa_pixel_head_bwd", ptr(dpred), feat.p, feat.ld, B, Hp, Wp, H, W, 64, C, ptr(P["linear.weight"]),
                  dfeat.p, dfeat.ld, 1, ptr(pw), ptr(pb), int(head_w_acc or pacc), ptr(ws), ws.numel(), stream())
-
-        gmap = {}
         dimg = None
-
-        def key(v):
-            return (v.t.data_ptr(), v.col, v.C)
-
-        def like(v: Img, zero=False):
-            return new_img(v.B, v.H, v.W, v.C, dev, zero=zero)
-
-        gmap[key(feat)] = dfeat
-        dJ = {}  # gradient buffers of the join tensors (full width)
-        for rec in reversed(tape):
-            kind = rec[0]
-            if kind == "bn":
-                _, name, x, y, stats, act, res, gathered = rec
-                dy = gmap.pop(key(y))
-                dres = None
-                acc_dres = False
-                if res is not None:
-                    k = key(res)
-                    if k in gmap:
-                        dres, acc_dres = gmap[k], True
-                    else:
-                        dres = like(res)
-                        gmap[k] = dres
-                dx = like(x)
-                gmap[key(x)] = dx
-                (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-                bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, ctx.training, dg, db,
-                       acc_params=pacc, gathered=gathered)
-            elif kind == "conv":
-                _, name, op, x, out, V = rec
-                dout = gmap.pop(key(out))
-                k = key(x)
-                acc = k in gmap
-                dx = gmap[k] if acc else like(x)
-                gmap[k] = dx
-                pg, pacc = sink.take(*([name + ".weight"] + ([name + ".bias"] if op.b is not None else [])))
-                op.backward(x, dout, dx, pg[0], pg[1] if op.b is not None else None, acc, acc_params=pacc, V=V, wgrad_side=True)
-            elif kind == "convT":
-                _, name, op, x, out = rec
-                dout = gmap.pop(key(out))
-                dx = like(x)
-                gmap[key(x)] = dx
-                (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
-                op.backward(x, dout, dx, dw, db, acc_params=pacc, wgrad_side=True)
-            elif kind == "join":
-                _, lvl, cj = rec
-                full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
-                dJ[lvl] = full
-                if DEBUG is not None:
-                    DEBUG[f"dJ{lvl}"] = full.t.clone()
-                gmap[(J[lvl].data_ptr(), 0, cj)] = Img(full.t, full.B, full.H, full.W, 0, cj)
-                gmap[(J[lvl].data_ptr(), cj, cj)] = Img(full.t, full.B, full.H, full.W, cj, cj)
-            elif kind == "dropout":
-                _, site, x, y, p = rec
-                dy = gmap.pop(key(y))
-                dx = like(x)
-                gmap[key(x)] = dx
-                call("mopa_dropout_rows", dy.p, dy.ld, dx.p, dx.ld, x.rows, x.C, float(p), ctx.drop_seed * 2 + site,
-                     stream())
-            elif kind == "maxpool":
-                _, x, y, amax = rec
-                dy = gmap.pop(key(y))
-                k = key(x)
-                acc = k in gmap
-                dx = gmap[k] if acc else like(x)
-                gmap[k] = dx
-                call("mopa_maxpool3x3s2_bwd", dy.p, dy.ld, ptr(amax), x.B, x.H, x.W, x.C, dx.p, dx.ld, int(acc), stream())
-            elif kind == "stem":
-                _, x4, c1, g = rec
-                dout = gmap.pop(key(c1))
-                (dw,), pacc = sink.take(pre + "conv1.weight")
-                with _on(wgrad_stream(dev), x4, dout.t, dw):
-                    dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
-                    wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
-                    call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
-                if ctx.needs_input_grad[1]:   # gradient w.r.t. the image itself (not asked for by MoPA's training)
-                    dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
-                    call("mopa_stem_dgrad_image", dout.p, dout.ld, B, Hp, Wp, H, W, ptr(P[pre + "conv1.weight"]), ptr(dimg), stream())
-            elif kind == "block_in":
-                pass
-        join_wgrad_stream(feat.t.device)   # the weight gradients are complete for whatever the caller queues next
+        if graph is not None and graph.backward(P, spec.order):
+            pass
+        else:
+            if graph is not None:
+                GRAPH_STATS["eager_backward"] += 1
+            elif ctx.graph_key is not None:
+                ctx.graph_key.eager_backward_seen = True
+            dimg = _backbone_backward(P, sink, tape, J, feat, dfeat, ctx.training, ctx.drop_seed,
+                                      graph.seed_t if graph is not None else None, ctx.needs_input_grad[1], H, W)
+        if graph is not None:
+            graph.pending = None   # the activations are free for the next forward replay
         return (None, dimg if dimg is None else dimg.to(ctx.img_dtype), None, None, None, None) + sink.returned()

@@ -67,6 +67,7 @@ class _FlatCache:
                 if params.get(attr) is not t and bufs.get(attr) is not t:
                     self.flat = None
                     self.__dict__.pop("native", None)     # the native executor's pointer tables belong to the old objects
+                    self.__dict__.pop("graphs2d", None)   # so do the recorded HIP graphs of the 2D backbone
                     break
         if self.flat is None:
             self.order = [k for k, _ in module.named_parameters() if not k.startswith("linear3.")] + [k for k, _ in module.named_buffers()]
@@ -153,7 +154,9 @@ class Net2DSeg(_CachedParams, nn.Module):
                 raise IndexError("img_indices must hold one array per image")
             pix = self.pack_indices(data_batch["img_indices"], H, W, dev)
         order, flat = self._cache.get(self)
-        spec = _Spec(order=order, num_classes=self.num_classes, dual_head=bool(self.dual_head))
+        # graphs: where dense2d keeps the recorded HIP graphs of the backbone (dropped with the cache when tensor objects change)
+        spec = _Spec(order=order, num_classes=self.num_classes, dual_head=bool(self.dual_head), graphs=self._cache,
+                     grad_enabled=torch.is_grad_enabled())
         self._calls += 1
         seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFF
         scope = _teacher_scope_enter()

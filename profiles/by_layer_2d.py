@@ -4,6 +4,7 @@ mopa_amd/dense2d.py is bracketed with HIP events and aggregated by (entry point,
 the time and how fast is each, without cross-stream contention".  Usage: python profiles/by_layer_2d.py [B]"""
 import collections, ctypes, os, sys
 os.environ.setdefault("MOPA_WGRAD_STREAM", "0")
+os.environ.setdefault("MOPA_GRAPH_2D", "0")   # every launch goes through the wrapped Python calls
 import numpy as np
 import torch
 sys.path.insert(0, os.getcwd())

@@ -531,3 +531,103 @@ def test_net2dseg_well_conditioned_fixture_bounds_every_gradient_at_one_percent(
             got = named[k[6:]].grad.cpu().numpy()[: v.shape[0]]
             scale = float(np.abs(P[k[6:]].grad.numpy()).max())
             assert float(np.abs(got - v).max()) <= 1e-2 * scale, k
+
+
+def _graph_training_run(monkeypatch, graph, steps=4, pattern="alternate", seed_t=7):
+    """`steps` iterations of (source batch fwd+bwd, target batch fwd+bwd, FlatAdam step) on 2 x 64 x 96 images with dropout 0.4
+    and a different number of points per half.  -> logits of every pass, the final state_dict, dense2d.GRAPH_STATS."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    from mopa_amd.optim import FlatAdam
+    monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+    for k in dense2d.GRAPH_STATS:
+        dense2d.GRAPH_STATS[k] = 0
+    src, trg = synth.make_batch(2, H=64, W=96), synth.make_batch(2, first=5, H=64, W=96)
+    trg["img_indices"] = [a[: len(a) // 2] for a in trg["img_indices"]]   # the heads see a different N per half
+    torch.manual_seed(seed_t)
+    m = build_model_2d(default_cfg())[0].cuda().train()
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    outs = []
+
+    def loss(o):
+        return o["seg_logit"].square().mean() + o["seg_logit2"].square().mean() * 0.5 + o["feats"].mean()
+
+    for _ in range(steps):
+        opt.zero_grad()
+        if pattern == "alternate":
+            for b in (src, trg):
+                o = m(b)
+                loss(o).backward()
+                outs.append(o["seg_logit"].detach().clone())
+        else:   # both forwards first, one backward through both: the second forward finds the graph's activations in use
+            o1, o2 = m(src), m(trg)
+            (loss(o1) + loss(o2)).backward()
+            outs += [o1["seg_logit"].detach().clone(), o2["seg_logit"].detach().clone()]
+        opt.step()
+    torch.cuda.synchronize()
+    return outs, {k: v.detach().clone() for k, v in m.state_dict().items()}, dict(dense2d.GRAPH_STATS)
+
+
+def test_graph_replay_of_the_backbone_is_bit_identical_to_the_eager_pass(monkeypatch):
+    """dense2d.Graph2D: from the second pass of a shape on, the backbone's forward and backward launches are replayed from HIP
+    graphs.  Same kernels, same order, same addresses: logits of every pass, every parameter, BatchNorm running statistics and
+    num_batches_tracked after four iterations (dropout on, a new seed per pass, weight forms refreshed after each update) must
+    equal the eager run bit for bit."""
+    eo, es, est = _graph_training_run(monkeypatch, False)
+    go, gs, gst = _graph_training_run(monkeypatch, True)
+    assert est["forward_replays"] == 0 and gst["recorded"] == 1
+    assert gst["forward_replays"] == 7 and gst["backward_replays"] == 7 and gst["eager_backward"] == 0   # 8 passes, the first eager
+    for i, (a, b) in enumerate(zip(eo, go)):
+        assert torch.equal(a, b), f"logits of pass {i} differ: {float((a - b).abs().max())}"
+    assert not torch.equal(go[0], go[2])   # the weights did move
+    for k in es:
+        assert torch.equal(es[k], gs[k]), k
+
+
+def test_graph_replay_steps_aside_when_its_activations_are_still_in_use(monkeypatch):
+    """Two forwards, then one backward through both: the second forward must not replay over the activations the first one's
+    backward still needs -- it runs eagerly; results equal the all-eager run."""
+    eo, es, _ = _graph_training_run(monkeypatch, False, steps=3, pattern="both")
+    go, gs, gst = _graph_training_run(monkeypatch, True, steps=3, pattern="both")
+    assert gst["eager_busy"] >= 2 and gst["forward_replays"] >= 2
+    for a, b in zip(eo, go):
+        assert torch.equal(a, b)
+    for k in es:
+        assert torch.equal(es[k], gs[k]), k
+
+
+def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monkeypatch):
+    """(1) torch.optim.SGD with set_to_none: no attached .grad buffers -> the forward replays, the backward walks the recorded tape
+    eagerly and autograd receives the gradient tensors.  (2) Re-pointing .data of a parameter drops the graphs (they hold raw
+    addresses): the next passes run eagerly and record again."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    b = synth.make_batch(2, H=64, W=96)
+
+    def run(graph):
+        monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+        for k in dense2d.GRAPH_STATS:
+            dense2d.GRAPH_STATS[k] = 0
+        torch.manual_seed(3)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+        outs = []
+        for it in range(5):
+            opt.zero_grad(set_to_none=True)
+            if it == 3:
+                w = m.net_2d.layer2[0].conv1.weight
+                w.data = w.data.clone()
+            o = m(b)
+            (o["seg_logit"].square().mean() + o["seg_logit2"].square().mean()).backward()
+            opt.step()
+            outs.append(o["seg_logit"].detach().clone())
+        torch.cuda.synchronize()
+        return outs, dict(dense2d.GRAPH_STATS)
+
+    eo, _ = run(False)
+    go, st = run(True)
+    assert st["forward_replays"] >= 2 and st["eager_backward"] >= 2 and st["backward_replays"] == 0 and st["dropped"] == 1, st
+    for a, c in zip(eo, go):
+        assert torch.equal(a, c)
