@@ -102,8 +102,12 @@ class ConvTimer:
         flops = sum(r[3] for r in self.records)
         direct = sum(r[4] if len(r) > 4 else r[3] for r in self.records)   # flops of the direct convolutions the launches stand for
         n = len(self.records)
+        # per launch the tighter of the two ceilings: its algorithmic bytes at the HBM peak or its flops at the dense fp32 MFMA peak
+        ideal_us = sum(max(r[2] / (HBM_PEAK_GBS * 1e9), r[3] / (F32_PEAK_TFLOPS * 1e12)) for r in self.records) * 1e6
+        mfma_bound = sum(1 for r in self.records if r[3] / (F32_PEAK_TFLOPS * 1e12) > r[2] / (HBM_PEAK_GBS * 1e9))
         return dict(launches=n, avg_us=1e3 * ms / n, bytes_per_launch=nbytes / n, gbs=nbytes / (ms * 1e-3) / 1e9,
-                    tflops=flops / (ms * 1e-3) / 1e12, tflops_direct=direct / (ms * 1e-3) / 1e12)
+                    tflops=flops / (ms * 1e-3) / 1e12, tflops_direct=direct / (ms * 1e-3) / 1e12,
+                    ideal_us_per_launch=ideal_us / n, mfma_bound_launches=mfma_bound)
 
 
 class Conv2dTimer:
@@ -760,7 +764,13 @@ def main():
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
-                  "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2)}
+                  "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2),
+                  # the family is not HBM-bound on every level: from level 3 down (128 -> 64 channels and wider, few rows) a launch's
+                  # flops at the fp32 MFMA peak take longer than its bytes at the HBM peak.  mixed = sum over launches of
+                  # max(bytes / 8 TB/s, flops / 157.3 TF/s) / measured time -- the fraction of the tighter ceiling per launch
+                  "mixed_roofline": {"ideal_us_per_launch": round(ks["ideal_us_per_launch"], 2),
+                                     "mfma_bound_launches_per_step": ks["mfma_bound_launches"] // max(n_ev_steps, 1),
+                                     "frac_event_bracket": round(ks["ideal_us_per_launch"] / ks["avg_us"], 4)}}
         # PMC traffic and rocprofv3 launch durations come from COMMITTED files (counters need rocprofv3 around the process): the
         # files carry the commit they were taken at (profiles/collect_final.py), the line says so
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
@@ -789,6 +799,7 @@ def main():
         if sp and rf:
             gbs = sp["algorithmic_bytes_per_launch"] / (rf["avg_us"] * 1e-6) / 1e9
             sp["frac_rocprof"], sp["avg_launch_us_rocprof"], sp["rocprof_commit"] = round(gbs / HBM_PEAK_GBS, 4), rf["avg_us"], famj.get("commit")
+            sp["mixed_roofline"]["frac_rocprof"] = round(sp["mixed_roofline"]["ideal_us_per_launch"] / rf["avg_us"], 4)
             if sp.get("frac") is None:
                 sp["frac"], sp["achieved"] = sp["frac_rocprof"], round(gbs, 1)
         roof = sp

@@ -474,21 +474,38 @@ def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, train
 
 
 # ------------------------------------------------------------------------------------------------ the backbone passes
-def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev):
+def _group(v: Img, g, G):
+    """The g-th of G equal image groups of an NHWC activation (a row range of the same buffer)."""
+    if G == 1:
+        return v
+    n = v.rows // G
+    return Img(v.t[g * n:(g + 1) * n], v.B // G, v.H, v.W, v.col, v.C)
+
+
+def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=1):
     """UNetResNet34 on a contiguous fp32 (B,3,H,W) image -> (feat, tape, J).  feat: (B, Hp, Wp, 64) NHWC, the /16-padded decoder
     output; tape: what the backward pass walks; J: the join buffers.  Every launch goes to the current stream, nothing is read
     back: the pass can be recorded into a HIP graph (Graph2D).  seed_t: int64 device scalar holding the dropout seed (graph
-    replays), else the seed is passed by value."""
+    replays), else the seed is passed by value.
+
+    groups = G > 1: the batch is G consecutive, equally sized image groups that the reference would have sent through the network
+    in G separate calls (the source and the target batch of one xMUDA iteration, train_xmuda_mopa.py:342,426 -- no weight update
+    in between).  Convolutions and pooling do not see the difference; everything that does is done per group in call order:
+    BatchNorm batch statistics and the running-statistics update (group 0 first), num_batches_tracked (+G), the dropout masks
+    (drop_seed = one seed per group).  The result equals the G calls; the kernels see G times the rows per launch."""
     pre = "net_2d."
     B, _, H, W = imgc.shape
+    G = groups
+    seeds = tuple(drop_seed) if isinstance(drop_seed, (tuple, list)) else (drop_seed,) * G
     Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
     tape = []
     nbt = []   # BatchNorm2d.num_batches_tracked of every layer that ran: bumped together at the end (one launch, not 43)
 
     def bn(name, x, act=1, res=None, out=None):
         y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
-        stats = torch.empty(4, x.C, dtype=torch.float32, device=dev)
-        gathered = bn_fwd(x, y, P, name, act, res, training, stats)
+        stats = torch.empty(G, 4, x.C, dtype=torch.float32, device=dev)
+        gathered = [bn_fwd(_group(x, g, G), _group(y, g, G), P, name, act, None if res is None else _group(res, g, G), training,
+                           stats[g]) for g in range(G)]
         if training:
             nbt.append(P[name + ".num_batches_tracked"])
         tape.append(("bn", name, x, y, stats, act, res, gathered))
@@ -512,7 +529,8 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev):
     def dropout(x, site, out=None):
         y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
         p = drop_p if training else 0.0
-        dropout_rows(x, y, p, drop_seed, seed_t, site)
+        for g in range(G):
+            dropout_rows(_group(x, g, G), _group(y, g, G), p, seeds[g], seed_t, site)
         tape.append(("dropout", site, x, y, p))
         return y
 
@@ -570,7 +588,7 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev):
             cname = f"{pre}dec_conv_stage{int(stage) - 1}."
             x = bn(cname + "1", conv(cname + "0", joined, 3, 1, 1, bias=True))
     if nbt:
-        torch._foreach_add_(nbt, 1)
+        torch._foreach_add_(nbt, G)
     return x, tape, J   # x: (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
 
 
@@ -581,10 +599,14 @@ def dropout_rows(x: View, y: View, p, seed, seed_t, site):
         call("mopa_dropout_rows", x.p, x.ld, y.p, y.ld, x.rows, x.C, float(p), seed * 2 + site, stream())
 
 
-def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_t, want_dimg, H, W):
+def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_t, want_dimg, H, W, groups=1):
     """Walk the tape backwards from dfeat = d(loss)/d(feat); parameter gradients go through `sink`.  -> d(loss)/d(img) (fp32,
-    (B,3,H,W)) if want_dimg else None.  Ends with the weight-gradient stream joined.  Recordable like _backbone_forward."""
+    (B,3,H,W)) if want_dimg else None.  Ends with the weight-gradient stream joined.  Recordable like _backbone_forward.
+    groups: as in _backbone_forward (BatchNorm backward and dropout per group; the parameter gradients of the groups add up, as
+    the G backward passes of the reference accumulate into .grad)."""
     dev = feat.t.device
+    G = groups
+    seeds = tuple(drop_seed) if isinstance(drop_seed, (tuple, list)) else (drop_seed,) * G
     pre = "net_2d."
     B, Hp, Wp = feat.B, feat.H, feat.W
     gmap = {}
@@ -615,8 +637,10 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             dx = like(x)
             gmap[key(x)] = dx
             (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-            bn_bwd(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, training, dg, db,
-                   acc_params=pacc, gathered=gathered)
+            for g in range(G):
+                bn_bwd(_group(dy, g, G), _group(x, g, G), _group(dx, g, G), stats[g], act,
+                       _group(y, g, G) if res is not None else None, None if dres is None else _group(dres, g, G), acc_dres, training,
+                       dg, db, acc_params=pacc or g > 0, gathered=gathered[g])
         elif kind == "conv":
             _, name, op, x, out, V = rec
             dout = gmap.pop(key(out))
@@ -646,7 +670,8 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             dy = gmap.pop(key(y))
             dx = like(x)
             gmap[key(x)] = dx
-            dropout_rows(dy, dx, p, drop_seed, seed_t, site)
+            for g in range(G):
+                dropout_rows(_group(dy, g, G), _group(dx, g, G), p, seeds[g], seed_t, site)
         elif kind == "maxpool":
             _, x, y, amax = rec
             dy = gmap.pop(key(y))
@@ -800,7 +825,7 @@ def _graph_for(spec, imgc, training, drop_p, flat, want_dimg):
     """-> (the Graph2D record of this pass's key or None, replay it?)."""
     holder = getattr(spec, "graphs", None)
     if (not GRAPH_2D or holder is None or not training or not getattr(spec, "grad_enabled", False) or syncbn.active()
-            or DEBUG is not None or want_dimg):
+            or DEBUG is not None or want_dimg or getattr(spec, "groups", 1) != 1):
         return None, False
     graphs = holder.__dict__.setdefault("graphs2d", {})
     B, _, H, W = imgc.shape
@@ -852,7 +877,7 @@ class Net2DFunction(torch.autograd.Function):
             graph.pending = weakref.ref(ctx.token)
             ctx.generation = graph.generation
         else:
-            feat, tape, J = _backbone_forward(P, imgc, training, drop_p, drop_seed, None, dev)
+            feat, tape, J = _backbone_forward(P, imgc, training, drop_p, drop_seed, None, dev, getattr(spec, "groups", 1))
         ctx.graph = graph
         # ---- heads (xmuda_arch.py:58-77)
         C = spec.num_classes
@@ -933,7 +958,8 @@ class Net2DFunction(torch.autograd.Function):
             elif ctx.graph_key is not None:
                 ctx.graph_key.eager_backward_seen = True
             dimg = _backbone_backward(P, sink, tape, J, feat, dfeat, ctx.training, ctx.drop_seed,
-                                      graph.seed_t if graph is not None else None, ctx.needs_input_grad[1], H, W)
+                                      graph.seed_t if graph is not None else None, ctx.needs_input_grad[1], H, W,
+                                      getattr(spec, "groups", 1))
         if graph is not None:
             graph.pending = None   # the activations are free for the next forward replay
         return (None, dimg if dimg is None else dimg.to(ctx.img_dtype), None, None, None, None) + sink.returned()

@@ -154,11 +154,20 @@ class Net2DSeg(_CachedParams, nn.Module):
                 raise IndexError("img_indices must hold one array per image")
             pix = self.pack_indices(data_batch["img_indices"], H, W, dev)
         order, flat = self._cache.get(self)
+        # "bn_groups": G (extension, default 1): the batch is G consecutive equal groups of images that would otherwise be G calls
+        # (source batch, then target batch): BatchNorm statistics / running-statistics updates / dropout masks per group in that
+        # order -- same result as the G calls, one pass over G times the rows (dense2d._backbone_forward)
+        groups = int(data_batch.get("bn_groups", 1))
+        if groups < 1 or img.shape[0] % groups:
+            raise ValueError(f"bn_groups={groups} does not divide the batch of {img.shape[0]} images")
         # graphs: where dense2d keeps the recorded HIP graphs of the backbone (dropped with the cache when tensor objects change)
         spec = _Spec(order=order, num_classes=self.num_classes, dual_head=bool(self.dual_head), graphs=self._cache,
-                     grad_enabled=torch.is_grad_enabled())
-        self._calls += 1
-        seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFF
+                     grad_enabled=torch.is_grad_enabled(), groups=groups)
+        seeds = []
+        for _ in range(groups):   # one dropout seed per call that this pass stands for
+            self._calls += 1
+            seeds.append((torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFF)
+        seed = seeds[0] if groups == 1 else tuple(seeds)
         scope = _teacher_scope_enter()
         with torch.cuda.device(dev):   # kernels launch on the current stream of the device the tensors live on
             feats, l1, l2, pred_all = dense2d.Net2DFunction.apply(spec, img, pix, self.training, float(self.net_2d.dropout.p),

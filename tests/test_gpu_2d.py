@@ -631,3 +631,80 @@ def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monk
     assert st["forward_replays"] >= 2 and st["eager_backward"] >= 2 and st["backward_replays"] == 0 and st["dropped"] == 1, st
     for a, c in zip(eo, go):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("winograd", [False, True])
+def test_source_and_target_batch_in_one_pass_equal_two_calls(winograd, monkeypatch):
+    """data_batch["bn_groups"] = 2: source and target images go through the backbone as one batch, with BatchNorm statistics,
+    running-statistics updates and dropout masks per half in call order.  Against the two separate calls (the reference's loop,
+    train_xmuda_mopa.py:342,426), num_batches_tracked identical, logits and running statistics equal to fp32 round-off, and
+    * with the direct (exact-product) convolution kernels the per-image arithmetic is the same in both forms: parameter gradients
+      agree to 1e-4 of each tensor's scale (one reduction over 4 images instead of 2 + 2 accumulated);
+    * with the default algorithm choice the 3x3 layers may pick another Winograd tile for the larger batch (the thresholds
+      count pixels per launch): gradients then agree like two algorithms do on this tiny, badly conditioned input (dropout 0.4,
+      a few hundred samples per BatchNorm channel in layer4; profiles/f4_gradient_noise.py has the same figures against fp64):
+      5 % of each tensor's L2 norm."""
+    if not winograd:
+        monkeypatch.setenv("MOPA_WINOGRAD", "0")
+    from mopa_amd import synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    src, trg = synth.make_batch(2, H=64, W=96), synth.make_batch(2, first=5, H=64, W=96)
+
+    def loss(o, w):
+        return (o["seg_logit"] * w[0]).sum() + (o["seg_logit2"] * w[1]).sum() + (o["seg_logit_all"] * w[2]).sum()
+
+    def weights(o, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        return [torch.randn(o[k].shape, device="cuda", generator=g) for k in ("seg_logit", "seg_logit2", "seg_logit_all")]
+
+    def model():
+        torch.manual_seed(11)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        m.output_all = True   # the full-image head takes part (the MoPA SAM-mask loss reads seg_logit_all)
+        return m
+
+    a = model()
+    outs_a = []
+    for it in range(2):
+        for k, b in enumerate((src, trg)):
+            o = a(b)
+            loss(o, weights(o, 10 * it + k)).backward()
+            outs_a.append(o["seg_logit"].detach().clone())
+    b2 = model()
+    outs_b = []
+    ns = sum(len(i) for i in src["img_indices"])
+    for it in range(2):
+        o = b2({"img": torch.cat([src["img"], trg["img"]]), "img_indices": list(src["img_indices"]) + list(trg["img_indices"]),
+                "bn_groups": 2})
+        os_ = {k: v[:ns] if k != "seg_logit_all" else v[:2] for k, v in o.items()}
+        ot_ = {k: v[ns:] if k != "seg_logit_all" else v[2:] for k, v in o.items()}
+        (loss(os_, weights(os_, 10 * it)) + loss(ot_, weights(ot_, 10 * it + 1))).backward()
+        outs_b += [os_["seg_logit"].detach().clone(), ot_["seg_logit"].detach().clone()]
+    torch.cuda.synchronize()
+    for x, y in zip(outs_a, outs_b):
+        _close(y, x.cpu(), rtol=1e-4, atol=1e-5)
+    sa, sb = a.state_dict(), b2.state_dict()
+    for k in sa:
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 4, k
+        else:
+            _close(sb[k], sa[k].cpu(), rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    # (a bias in front of a BatchNorm has a zero gradient in exact arithmetic -- what it holds is round-off: norms below 1e-3 of the
+    #  largest tensor's are measured against that floor)
+    floor = 1e-3 * max(float(p.grad.norm()) for p in a.parameters() if p.grad is not None)
+    for (n, p), (_, q) in zip(a.named_parameters(), b2.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None, n
+            continue
+        if winograd:
+            err = float((p.grad - q.grad).norm() / (p.grad.norm() + floor))
+            assert err <= 5e-2, (n, err)
+        else:
+            err = float((p.grad - q.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-20)
+            assert err <= 1e-4, (n, err)
+        worst = max(worst, err)
+    print("worst parameter-gradient difference (relative):", worst)
+    with pytest.raises(ValueError):
+        b2({"img": src["img"][:1].repeat(3, 1, 1, 1), "img_indices": list(src["img_indices"][:1]) * 3, "bn_groups": 2})
