@@ -479,45 +479,54 @@ def main():
     # MOPA_BENCH_DECOUPLE_3D_OPT=0: the joined form (both updates on the main stream behind dual.join()).
     decoupled = joint and os.environ.get("MOPA_BENCH_DECOUPLE_3D_OPT", "1") != "0"
 
-    def half(b, lam_xm, supervised, ready=None):
-        """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
-        ready = ready or resident
-        o2, o3 = dual.forward(model2d, model3d, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
-                              {"x": [b["locs"], b["feats"]]}, inputs_ready=ready if geom_ahead else None)
-        def loss_3d():
-            l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
-            if supervised:
-                l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
-            elif mopa:
-                l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
-                # Valid Ground-based Insertion (train_xmuda_mopa.py:516-555) on the device, then the third 3D pass on its output
-                # (the per-scan loop of the reference as one batched call: same draws, same results, two host round trips per batch
-                # instead of four per scan -- mopa_amd/vgi.py::point_mixmatch_batch; MOPA_BENCH_VGI_LOOP=1: the loop)
-                if os.environ.get("MOPA_BENCH_VGI_LOOP") == "1":
-                    res = [vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
-                                              search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
-                                              proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
-                           for v in b["vgi"]]
-                else:
-                    res = vgi.point_mixmatch_batch([dict(ori_pc=v["ori_pc"], ori_label=v["pslabel"], obj_pc_ls=v["objs"],
-                                                         obj_label_ls=v["obj_labels"], g_indices=v["g_mask"]) for v in b["vgi"]],
-                                                   search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
-                                                   proj_matrix=b["vgi_proj"], image_size=(1600, 900), front_axis="y")
-                cat_pc, cat_lab, cat_mask = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
-                aug = {"noisy_rot": 0.1, "flip_x": 0.5, "rot_z": 6.2831, "transl": True}   # nuScenes target augmentation (yaml)
-                cat_input, cat_ps, _, _ = vgi.post_process(cat_pc, cat_lab, cat_mask, 20, 4096, aug, proj_W=1080, proj_H=32)
-                ov = model3d(cat_input)
-                l3 = l3 + seg_ce(ov["seg_logit"], cat_ps)
-            return l3
+    def loss_3d_of(o2, o3, b, lam_xm, supervised):
+        """3D losses of one domain (train_xmuda_mopa.py:354-363,389-398 source; :440-445,456-465,516-567 target)."""
+        l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
+        if supervised:
+            l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
+        elif mopa:
+            l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
+            # Valid Ground-based Insertion (train_xmuda_mopa.py:516-555) on the device, then the third 3D pass on its output
+            # (the per-scan loop of the reference as one batched call: same draws, same results, two host round trips per batch
+            # instead of four per scan -- mopa_amd/vgi.py::point_mixmatch_batch; MOPA_BENCH_VGI_LOOP=1: the loop)
+            if os.environ.get("MOPA_BENCH_VGI_LOOP") == "1":
+                res = [vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
+                                          search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                          proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
+                       for v in b["vgi"]]
+            else:
+                res = vgi.point_mixmatch_batch([dict(ori_pc=v["ori_pc"], ori_label=v["pslabel"], obj_pc_ls=v["objs"],
+                                                     obj_label_ls=v["obj_labels"], g_indices=v["g_mask"]) for v in b["vgi"]],
+                                               search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                               proj_matrix=b["vgi_proj"], image_size=(1600, 900), front_axis="y")
+            cat_pc, cat_lab, cat_mask = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
+            aug = {"noisy_rot": 0.1, "flip_x": 0.5, "rot_z": 6.2831, "transl": True}   # nuScenes target augmentation (yaml)
+            cat_input, cat_ps, _, _ = vgi.post_process(cat_pc, cat_lab, cat_mask, 20, 4096, aug, proj_W=1080, proj_H=32)
+            ov = model3d(cat_input)
+            l3 = l3 + seg_ce(ov["seg_logit"], cat_ps)
+        return l3
 
-        if tl is not None:
-            tl.mark("fwd_joined")
+    def loss_2d_of(o2, o3, b, lam_xm, supervised):
         l2 = lam_xm * xm_kl(o2["seg_logit2"], o3["seg_logit"])
         if supervised:
             l2 = l2 + seg_ce(o2["seg_logit"], b["label"], cw)
         elif mopa:
             l2 = l2 + seg_ce(o2["seg_logit"], b["pl2d"])                      # lambda_pl = 1.0, ignore rows skipped in-kernel
             l2 = l2 + 0.01 * mask_cons_loss(softmax_lastdim(o2["seg_logit_all"]), b["sam"], True)   # lambda_sam_cons (yaml :66)
+        return l2
+
+    def half(b, lam_xm, supervised, ready=None):
+        """One domain of the xMUDA iteration (train_xmuda_mopa.py:342-418 source, :426-449,:578-579 target)."""
+        ready = ready or resident
+        o2, o3 = dual.forward(model2d, model3d, {"img": b["img"], "point_pix_2d": b["pix"], "img_indices": None},
+                              {"x": [b["locs"], b["feats"]]}, inputs_ready=ready if geom_ahead else None)
+
+        def loss_3d():
+            return loss_3d_of(o2, o3, b, lam_xm, supervised)
+
+        if tl is not None:
+            tl.mark("fwd_joined")
+        l2 = loss_2d_of(o2, o3, b, lam_xm, supervised)
         if reorder and mopa and not supervised:
             # MoPA target half: the VGI inside loss_3d() reads a few numbers back per scan (cell counts for numpy's RNG draws) --
             # each read waits for the side stream.  The 2D backward is enqueued FIRST (the losses are independent graphs), so the
@@ -557,6 +566,57 @@ def main():
             l2.backward()
         else:
             l2.backward()
+            l3.backward()
+        return l2.detach(), l3.detach()
+
+    # ---- both domains with the 2D branch in ONE pass.  The reference sends the source batch and then the target batch through
+    # the 2D network (train_xmuda_mopa.py:342,426) with no weight update in between; the two passes are independent except for the
+    # order in which BatchNorm updates its running statistics.  Net2DSeg's "bn_groups": 2 keeps exactly that (statistics, running
+    # updates and dropout masks per half, in order: tests/test_gpu_2d.py) while every convolution sees both halves at once: half
+    # the launches, twice the rows per launch -- 2 x 22.0 ms -> 40.5 ms for forward + backward at 8 + 8 images, 2 x 13.1 -> 22.0 at
+    # 4 + 4, 2 x 8.8 -> 13.1 at 2 + 2 (2D branch alone, profiles/graph_probe.py).  The 3D branch still runs per domain (its rows
+    # are not grouped by scan), both forwards on the side stream beside the 2D forward, both backwards beside the 2D backward.
+    # MOPA_BENCH_PAIR=0: the two-call form (half() twice).
+    pair_mode = joint and os.environ.get("MOPA_BENCH_PAIR", "1") != "0" and reorder and (decoupled or mopa)
+
+    def pair_batch_of(bs, bt):
+        Bs = bs["img"].shape[0]
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        return {"img": torch.cat([bs["img"], bt["img"]]), "point_pix_2d": torch.cat([bs["pix"], bt["pix"] + Bs * Hp * Wp]),
+                "img_indices": None, "bn_groups": 2}
+
+    pair2d = pair_batch_of(batches[0], batches[1]) if pair_mode else None
+    if pair_mode:
+        torch.cuda.synchronize()
+        resident.record()
+
+    def pair(bs, bt, p2d, ready=None):
+        ready = ready or resident
+        main = torch.cuda.current_stream(dev)
+        dual.side.wait_stream(main)
+        o2 = model2d(p2d)                       # the long queue first; the 3D launches are enqueued while it runs
+        with torch.cuda.stream(dual.side):
+            dual.side.wait_event(ready)
+            o3 = []
+            for b in (bs, bt):
+                g = model3d.net_3d.geometry(b["locs"])
+                o3.append(model3d({"x": [b["locs"], b["feats"]], "geometry_3d": g}))
+        main.wait_stream(dual.side)
+        for o in o3:
+            for t in o.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        ns, nb = bs["pix"].numel(), bs["img"].shape[0]
+        o2s = {k: (v[:nb] if k == "seg_logit_all" else v[:ns]) for k, v in o2.items()}
+        o2t = {k: (v[nb:] if k == "seg_logit_all" else v[ns:]) for k, v in o2.items()}
+        l2 = loss_2d_of(o2s, o3[0], bs, lam_src, True) + loss_2d_of(o2t, o3[1], bt, lam_trg, False)
+        ev = torch.cuda.Event()
+        ev.record()
+        l2.backward()                           # main stream: the 2D backward of both halves
+        # the 3D losses (for MoPA: with the VGI and its host round trips) and both 3D backwards on the side stream, ordered behind
+        # the 2D losses only -- they run beside the 2D backward
+        with dual.on_side(o2["seg_logit"], o2["seg_logit2"], after=ev):
+            l3 = loss_3d_of(o2s, o3[0], bs, lam_src, True) + loss_3d_of(o2t, o3[1], bt, lam_trg, False)
             l3.backward()
         return l2.detach(), l3.detach()
 
@@ -612,13 +672,24 @@ def main():
             for o in opts:
                 o.zero_grad()
         work3 = None
-        if joint and host_fed:
+        if joint and host_fed and pair_mode:
+            d0, e0 = stage(host_batches[0])
+            d1, e1 = stage(host_batches[1])
+            torch.cuda.current_stream(dev).wait_event(e0)
+            torch.cuda.current_stream(dev).wait_event(e1)
+            parts = pair(d0, d1, pair_batch_of(d0, d1), ready=e1)   # (the copy stream is in order: e1 covers both uploads)
+        elif joint and host_fed:
             d0, e0 = stage(host_batches[0])
             d1, e1 = stage(host_batches[1])   # in flight while the source half computes
             torch.cuda.current_stream(dev).wait_event(e0)
             pa = half(d0, lam_src, True, ready=e0)
             torch.cuda.current_stream(dev).wait_event(e1)
             parts = pa + half(d1, lam_trg, False, ready=e1)
+        elif joint and pair_mode:
+            parts = pair(batches[0], batches[1], pair2d)
+            if multi and overlap_3d:
+                with torch.cuda.stream(dual.side):
+                    work3 = opts[0].all_reduce(async_op=True)
         elif joint:
             parts = half(batches[0], lam_src, True) + half(batches[1], lam_trg, False)   # source: CE + lambda_xm_src * KL, target: lambda_xm_trg * KL (yaml :56-57)
             if multi and overlap_3d and not host_fed:
@@ -649,7 +720,7 @@ def main():
             dual.join()  # 3D backward done before its gradients are reduced / applied
             for t in parts:   # the 3D parts live in the side stream's pool
                 t.record_stream(torch.cuda.current_stream())
-            loss = parts[0] + parts[1] + parts[2] + parts[3]
+            loss = sum(parts[1:], parts[0])
         for k, o in enumerate(opts):
             if k == 0 and work3 is not None:
                 continue
@@ -862,6 +933,10 @@ def main():
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
                        else "python walk (MOPA_SCN_NATIVE=0)",
+                       "net2d_pass": (None if not joint else
+                                      "source + target images in ONE pass of the 2D network (Net2DSeg bn_groups=2: BatchNorm statistics, "
+                                      "running-statistics updates and dropout masks per domain, in the reference's call order)" if pair_mode
+                                      else "one pass per domain (MOPA_BENCH_PAIR=0 or a stream configuration without the side stream)"),
                        "net2d_executor": (None if not joint else
                                           f"HIP-graph replay of the backbone ({dense2d_mod.GRAPH_STATS['forward_replays']} forward / "
                                           f"{dense2d_mod.GRAPH_STATS['backward_replays']} backward replays in this process; heads and "

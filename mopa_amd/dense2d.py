@@ -202,7 +202,10 @@ def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
     return 2 if max(cin, cout) >= 128 and B * H * W < 200000 else 0
 
 
-F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "1500000"))
+# (pixels per launch up to which F(4x4) is chosen: 16 x 304 x 480 = 2.3 M -- source + target batch in one pass -- is inside; the
+#  transformed operands V / M of one layer are 2.25 x its activations, and the fused kernel addresses one transform point with 32-bit
+#  byte offsets: mopa_wino4_gemm_output refuses T * Cin * 4 >= 2^32)
+F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "3000000"))
 # Which passes use F(4x4): all three (round 2; round 1 shipped "dgrad,wgrad").  In the backward passes its rounding error
 # (~1e-5 relative per layer) is a linear perturbation.  In the FORWARD pass the same error also moves a few ReLU pre-activations
 # across zero, and layers that normalise over few samples amplify such a flip -- measured against the fp64 oracle

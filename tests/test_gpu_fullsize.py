@@ -416,3 +416,54 @@ def test_cross_modal_kl_does_not_run_the_other_networks_backward():
     p3b = m3(b)
     (p3b["seg_logit"].sum() * 0.0 + xm_kl(p2["seg_logit2"].detach(), p3b["seg_logit2"].detach())).backward()
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for n, p in m3.named_parameters() if n.startswith("linear2"))
+
+
+def test_paired_2d_pass_at_the_bench_shape():
+    """8 source + 8 target images of 302 x 480 through Net2DSeg in ONE pass (bn_groups=2, what bench.py's joint step does) against
+    the two 8-image calls: 2.3 M pixels per launch (inside F4_MAX_PIXELS: the 304 x 480 layers stay on F(4x4) and their
+    transformed operands are 2-3 GB -- 64-bit strides), logits to 1e-4 of their scale, running statistics to 1e-5, and the
+    parameter gradients of the sum of both halves' losses to 1 % of each tensor's L2 norm (fp32 noise level of this network at
+    this size)."""
+    from mopa_amd import synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    src, trg = synth.make_batch(8), synth.make_batch(8, first=100)
+    for b in (src, trg):
+        b["img"] = b["img"].cuda()
+
+    def model():
+        torch.manual_seed(5)
+        return build_model_2d(default_cfg())[0].cuda().train()
+
+    def loss(o):
+        return o["seg_logit"].square().mean() + o["seg_logit2"].square().mean()
+
+    a = model()
+    oa = []
+    for b in (src, trg):
+        o = a(b)
+        loss(o).backward()
+        oa.append(o["seg_logit"].detach().clone())
+        del o
+    p = model()
+    o = p({"img": torch.cat([src["img"], trg["img"]]), "img_indices": list(src["img_indices"]) + list(trg["img_indices"]), "bn_groups": 2})
+    ns = oa[0].shape[0]
+    (loss({k: v[:ns] for k, v in o.items()}) + loss({k: v[ns:] for k, v in o.items()})).backward()
+    torch.cuda.synchronize()
+    for ref, got in ((oa[0], o["seg_logit"][:ns]), (oa[1], o["seg_logit"][ns:])):
+        assert float((ref - got).abs().max()) <= 1e-4 * float(ref.abs().max())
+    sa, sp = a.state_dict(), p.state_dict()
+    for k in sa:
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sp[k]) == 2
+        elif "running" in k:
+            assert float((sa[k] - sp[k]).abs().max()) <= 1e-5 * (float(sa[k].abs().max()) + 1e-3), k
+    floor = 1e-3 * max(float(q.grad.norm()) for q in a.parameters() if q.grad is not None)
+    worst = 0.0
+    for (n, x), (_, y) in zip(a.named_parameters(), p.named_parameters()):
+        if x.grad is None:
+            continue
+        err = float((x.grad - y.grad).norm() / (x.grad.norm() + floor))
+        worst = max(worst, err)
+        assert err <= 1e-2, (n, err)
+    print("paired vs two calls, worst parameter-gradient difference (relative L2):", worst)
