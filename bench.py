@@ -479,31 +479,38 @@ def main():
     # MOPA_BENCH_DECOUPLE_3D_OPT=0: the joined form (both updates on the main stream behind dual.join()).
     decoupled = joint and os.environ.get("MOPA_BENCH_DECOUPLE_3D_OPT", "1") != "0"
 
-    def loss_3d_of(o2, o3, b, lam_xm, supervised):
-        """3D losses of one domain (train_xmuda_mopa.py:354-363,389-398 source; :440-445,456-465,516-567 target)."""
+    def vgi_batch(b):
+        """Valid Ground-based Insertion (train_xmuda_mopa.py:516-555) on the device for the target batch -> (3D input of the
+        augmented batch, its pseudo labels).  The per-scan loop of the reference as one batched call: same draws, same results,
+        two host round trips per batch instead of four per scan (mopa_amd/vgi.py::point_mixmatch_batch; MOPA_BENCH_VGI_LOOP=1: the
+        loop).  Depends on the batch only (points, pseudo labels, ground mask, object bank), not on any network output."""
+        if os.environ.get("MOPA_BENCH_VGI_LOOP") == "1":
+            res = [vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
+                                      search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                      proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
+                   for v in b["vgi"]]
+        else:
+            res = vgi.point_mixmatch_batch([dict(ori_pc=v["ori_pc"], ori_label=v["pslabel"], obj_pc_ls=v["objs"],
+                                                 obj_label_ls=v["obj_labels"], g_indices=v["g_mask"]) for v in b["vgi"]],
+                                           search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
+                                           proj_matrix=b["vgi_proj"], image_size=(1600, 900), front_axis="y")
+        cat_pc, cat_lab, cat_mask = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
+        aug = {"noisy_rot": 0.1, "flip_x": 0.5, "rot_z": 6.2831, "transl": True}   # nuScenes target augmentation (yaml)
+        cat_input, cat_ps, _, _ = vgi.post_process(cat_pc, cat_lab, cat_mask, 20, 4096, aug, proj_W=1080, proj_H=32)
+        return cat_input, cat_ps
+
+    def loss_3d_of(o2, o3, b, lam_xm, supervised, third=None):
+        """3D losses of one domain (train_xmuda_mopa.py:354-363,389-398 source; :440-445,456-465,516-567 target).  third: (3D
+        predictions on the VGI batch, its pseudo labels) when the caller ran that pass already."""
         l3 = lam_xm * xm_kl(o3["seg_logit2"], o2["seg_logit"])
         if supervised:
             l3 = l3 + seg_ce(o3["seg_logit"], b["label"], cw)
         elif mopa:
             l3 = l3 + seg_ce(o3["seg_logit"], b["pl3d"])
-            # Valid Ground-based Insertion (train_xmuda_mopa.py:516-555) on the device, then the third 3D pass on its output
-            # (the per-scan loop of the reference as one batched call: same draws, same results, two host round trips per batch
-            # instead of four per scan -- mopa_amd/vgi.py::point_mixmatch_batch; MOPA_BENCH_VGI_LOOP=1: the loop)
-            if os.environ.get("MOPA_BENCH_VGI_LOOP") == "1":
-                res = [vgi.point_mixmatch(v["ori_pc"], v["pslabel"], v["objs"], v["obj_labels"], insert_mode="ground",
-                                          search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
-                                          proj_matrix=b["vgi_proj"], image_size=(1600, 900), g_indices=v["g_mask"], front_axis="y")
-                       for v in b["vgi"]]
-            else:
-                res = vgi.point_mixmatch_batch([dict(ori_pc=v["ori_pc"], ori_label=v["pslabel"], obj_pc_ls=v["objs"],
-                                                     obj_label_ls=v["obj_labels"], g_indices=v["g_mask"]) for v in b["vgi"]],
-                                               search_voxel_size=0.5, search_range=[25.0, 25.0], search_z_min=-2.0,
-                                               proj_matrix=b["vgi_proj"], image_size=(1600, 900), front_axis="y")
-            cat_pc, cat_lab, cat_mask = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
-            aug = {"noisy_rot": 0.1, "flip_x": 0.5, "rot_z": 6.2831, "transl": True}   # nuScenes target augmentation (yaml)
-            cat_input, cat_ps, _, _ = vgi.post_process(cat_pc, cat_lab, cat_mask, 20, 4096, aug, proj_W=1080, proj_H=32)
-            ov = model3d(cat_input)
-            l3 = l3 + seg_ce(ov["seg_logit"], cat_ps)
+            if third is None:   # the VGI, then the third 3D pass on its output
+                cat_input, cat_ps = vgi_batch(b)
+                third = (model3d(cat_input), cat_ps)
+            l3 = l3 + seg_ce(third[0]["seg_logit"], third[1])
         return l3
 
     def loss_2d_of(o2, o3, b, lam_xm, supervised):
@@ -595,12 +602,23 @@ def main():
         main = torch.cuda.current_stream(dev)
         dual.side.wait_stream(main)
         o2 = model2d(p2d)                       # the long queue first; the 3D launches are enqueued while it runs
+        if tl is not None:
+            tl.mark("fwd2d_end", main)
+        third = None
         with torch.cuda.stream(dual.side):
             dual.side.wait_event(ready)
+            # MoPA: the VGI needs the batch only -- it runs FIRST, while the main stream is busy with the 2D forward: its host round
+            # trips then wait for a short side-stream queue, and its third 3D pass joins the other two forwards (behind the 3D
+            # losses the whole chain VGI -> third forward -> three backward passes was the step's critical path: 33.6 -> ms)
+            vin = vgi_batch(bt) if mopa else None
             o3 = []
             for b in (bs, bt):
                 g = model3d.net_3d.geometry(b["locs"])
                 o3.append(model3d({"x": [b["locs"], b["feats"]], "geometry_3d": g}))
+            if vin is not None:
+                third = (model3d(vin[0]), vin[1])
+        if tl is not None:
+            tl.mark("fwd3d_end", dual.side)
         main.wait_stream(dual.side)
         for o in o3:
             for t in o.values():
@@ -613,11 +631,15 @@ def main():
         ev = torch.cuda.Event()
         ev.record()
         l2.backward()                           # main stream: the 2D backward of both halves
+        if tl is not None:
+            tl.mark("bwd2d_end", main)
         # the 3D losses (for MoPA: with the VGI and its host round trips) and both 3D backwards on the side stream, ordered behind
         # the 2D losses only -- they run beside the 2D backward
         with dual.on_side(o2["seg_logit"], o2["seg_logit2"], after=ev):
-            l3 = loss_3d_of(o2s, o3[0], bs, lam_src, True) + loss_3d_of(o2t, o3[1], bt, lam_trg, False)
+            l3 = loss_3d_of(o2s, o3[0], bs, lam_src, True) + loss_3d_of(o2t, o3[1], bt, lam_trg, False, third)
             l3.backward()
+        if tl is not None:
+            tl.mark("bwd3d_end", dual.side)
         return l2.detach(), l3.detach()
 
     # Loss means are per rank; the reference's single-process mean over the global batch weights rank r by N_r / sum N

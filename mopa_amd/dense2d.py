@@ -533,7 +533,7 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
         y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
         p = drop_p if training else 0.0
         for g in range(G):
-            dropout_rows(_group(x, g, G), _group(y, g, G), p, seeds[g], seed_t, site)
+            dropout_rows(_group(x, g, G), _group(y, g, G), p, seeds[g], None if seed_t is None else seed_t[g:], site)
         tape.append(("dropout", site, x, y, p))
         return y
 
@@ -674,7 +674,7 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             dx = like(x)
             gmap[key(x)] = dx
             for g in range(G):
-                dropout_rows(_group(dy, g, G), _group(dx, g, G), p, seeds[g], seed_t, site)
+                dropout_rows(_group(dy, g, G), _group(dx, g, G), p, seeds[g], None if seed_t is None else seed_t[g:], site)
         elif kind == "maxpool":
             _, x, y, amax = rec
             dy = gmap.pop(key(y))
@@ -725,7 +725,8 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
 # replayed (the launch gaps of the deep layers close), but hipGraphLaunch itself keeps the host for 4.6 ms (2 images) to 11 ms (8)
 # per replay -- the runtime walks the ~460 nodes and enqueues one packet each -- and while it does, the host cannot feed the 3D
 # branch's stream: inside the joint step the replayed backbone LOSES, 319 -> 300 scans/s (nuScenes shape), 227 -> 190 (MoPA
-# iteration), 131-152 -> 135-142 (SemanticKITTI shape, within box noise).  Kept as an option for 2D-only loops and for a runtime
+# iteration), 131-152 -> 135-142 (SemanticKITTI shape, within box noise); with source + target images in one pass (bn_groups = 2,
+# where the host has twice the slack): 334 -> 311, 240 -> 210, 188 -> 175.  Kept as an option for 2D-only loops and for a runtime
 # whose graph launch is cheap.  Training mode with gradients enabled only; not under synchronised BatchNorm (its collectives are
 # issued from Python between the kernels).
 GRAPH_2D = os.environ.get("MOPA_GRAPH_2D", "0") == "1"
@@ -740,8 +741,8 @@ class _Token:
 class Graph2D:
     """The recorded forward and backward pass of the backbone for one (B, H, W, training, dropout p, stream)."""
 
-    def __init__(self, B, H, W, dev):
-        self.B, self.H, self.W, self.dev = B, H, W, dev
+    def __init__(self, B, H, W, dev, groups=1):
+        self.B, self.H, self.W, self.dev, self.groups = B, H, W, dev, groups
         self.calls = 0            # eligible passes seen with this key
         self.eager_backward_seen = False   # recording starts once a whole eager forward + backward has run with this key
         self.fwd = self.bwd = None
@@ -769,10 +770,10 @@ class Graph2D:
     def record_forward(self, P, flat, training, drop_p):
         self.side = torch.cuda.Stream(device=self.dev)   # the recording stream (replays run on the caller's)
         self.img = torch.empty(self.B, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
-        self.seed_t = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.seed_t = torch.zeros(self.groups, dtype=torch.int64, device=self.dev)   # one dropout seed per image group
         self.training, self.drop_p = training, drop_p
         self.fwd, (self.feat, self.tape, self.J) = self._record(
-            lambda: _backbone_forward(P, self.img, training, drop_p, 0, self.seed_t, self.dev), None)
+            lambda: _backbone_forward(P, self.img, training, drop_p, 0, self.seed_t, self.dev, self.groups), None)
         self.dfeat = new_img(self.feat.B, self.feat.H, self.feat.W, 64, self.dev)
         self.ptrs = tuple(t.data_ptr() for t in flat)
         GRAPH_STATS["recorded"] += 1
@@ -784,7 +785,11 @@ class Graph2D:
     def forward(self, imgc, seed):
         self.img.copy_(imgc)
         if self.training and self.drop_p > 0.0:
-            self.seed_t.fill_(seed)
+            if self.groups == 1:
+                self.seed_t.fill_(seed)
+            else:
+                for g, sd in enumerate(seed):   # (fill kernels: a host -> device copy here would wait for the stream)
+                    self.seed_t[g:g + 1].fill_(sd)
         _refresh_stale_forms(stream())   # every cached weight form of this stream that an update made stale: one launch
         self.fwd.replay()
         self.generation += 1
@@ -814,7 +819,7 @@ class Graph2D:
             try:
                 self.bwd, _ = self._record(
                     lambda: _backbone_backward(P, GradSink(P, order), self.tape, self.J, self.feat, self.dfeat, self.training, 0,
-                                               self.seed_t, False, self.H, self.W), self.fwd.pool())
+                                               self.seed_t, False, self.H, self.W, self.groups), self.fwd.pool())
             except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
                 self.failed = True
                 return False
@@ -828,16 +833,17 @@ def _graph_for(spec, imgc, training, drop_p, flat, want_dimg):
     """-> (the Graph2D record of this pass's key or None, replay it?)."""
     holder = getattr(spec, "graphs", None)
     if (not GRAPH_2D or holder is None or not training or not getattr(spec, "grad_enabled", False) or syncbn.active()
-            or DEBUG is not None or want_dimg or getattr(spec, "groups", 1) != 1):
+            or DEBUG is not None or want_dimg):
         return None, False
     graphs = holder.__dict__.setdefault("graphs2d", {})
     B, _, H, W = imgc.shape
-    key = (B, H, W, float(drop_p), spec.num_classes, stream(), F4_ROLES, WGRAD_STREAM)
+    groups = getattr(spec, "groups", 1)
+    key = (B, H, W, groups, float(drop_p), spec.num_classes, stream(), F4_ROLES, WGRAD_STREAM)
     g = graphs.get(key)
     if g is None:
         if len(graphs) >= GRAPH_2D_MAX_KEYS:
             return None, False
-        g = graphs[key] = Graph2D(B, H, W, imgc.device)
+        g = graphs[key] = Graph2D(B, H, W, imgc.device, groups)
     if g.failed:
         return None, False
     if g.fwd is not None and g.params_moved(flat):   # .data was re-pointed under the same parameter objects

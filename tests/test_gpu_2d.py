@@ -585,6 +585,41 @@ def test_graph_replay_of_the_backbone_is_bit_identical_to_the_eager_pass(monkeyp
         assert torch.equal(es[k], gs[k]), k
 
 
+def test_graph_replay_of_a_grouped_pass(monkeypatch):
+    """bn_groups = 2 under graph replay: one dropout seed per group in device memory, BatchNorm per group inside the graphs."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    from mopa_amd.optim import FlatAdam
+    src, trg = synth.make_batch(2, H=64, W=96), synth.make_batch(2, first=5, H=64, W=96)
+    batch = {"img": torch.cat([src["img"], trg["img"]]), "img_indices": list(src["img_indices"]) + list(trg["img_indices"]), "bn_groups": 2}
+
+    def run(graph):
+        monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+        for k in dense2d.GRAPH_STATS:
+            dense2d.GRAPH_STATS[k] = 0
+        torch.manual_seed(9)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        outs = []
+        for _ in range(4):
+            opt.zero_grad()
+            o = m(batch)
+            (o["seg_logit"].square().mean() + o["seg_logit2"].square().mean()).backward()
+            opt.step()
+            outs.append(o["seg_logit"].detach().clone())
+        torch.cuda.synchronize()
+        return outs, {k: v.detach().clone() for k, v in m.state_dict().items()}, dict(dense2d.GRAPH_STATS)
+
+    eo, es, _ = run(False)
+    go, gs, st = run(True)
+    assert st["forward_replays"] == 3 and st["backward_replays"] == 3, st
+    for a, b in zip(eo, go):
+        assert torch.equal(a, b)
+    for k in es:
+        assert torch.equal(es[k], gs[k]), k
+
+
 def test_graph_replay_steps_aside_when_its_activations_are_still_in_use(monkeypatch):
     """Two forwards, then one backward through both: the second forward must not replay over the activations the first one's
     backward still needs -- it runs eagerly; results equal the all-eager run."""
