@@ -601,15 +601,17 @@ def main():
         ready = ready or resident
         main = torch.cuda.current_stream(dev)
         dual.side.wait_stream(main)
-        o2 = model2d(p2d)                       # the long queue first; the 3D launches are enqueued while it runs
+        # the long queue first; the 3D launches are enqueued while it runs.  (Measured alternatives, no gain: the 3D passes enqueued
+        # first -- 238 -> 220 scans/s MoPA, 191 -> 176 kitti; the side stream not ordered behind the main stream at the step
+        # boundary -- unchanged: at 4 + 4 and 2 + 2 images the 3D chain fills its stream for the whole step)
+        o2 = model2d(p2d)
         if tl is not None:
             tl.mark("fwd2d_end", main)
         third = None
         with torch.cuda.stream(dual.side):
             dual.side.wait_event(ready)
             # MoPA: the VGI needs the batch only -- it runs FIRST, while the main stream is busy with the 2D forward: its host round
-            # trips then wait for a short side-stream queue, and its third 3D pass joins the other two forwards (behind the 3D
-            # losses the whole chain VGI -> third forward -> three backward passes was the step's critical path: 33.6 -> ms)
+            # trips then wait for a short side-stream queue, and its third 3D pass joins the other two forwards
             vin = vgi_batch(bt) if mopa else None
             o3 = []
             for b in (bs, bt):
@@ -870,7 +872,7 @@ def main():
         fam_path = os.path.join(ROOT, "profiles", "r3_rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
         # (the joint step runs the 3D branch on the same scans as `--workload 3d`: its sparse-conv launches move the same bytes)
-        t3_key = {"3d": "3d", "joint": "3d", "kitti": "kitti"}.get(wl_key)
+        t3_key = {"3d": "3d", "joint": "3d", "kitti": "kitti", "mopa": "mopa"}.get(wl_key)
         t3 = os.path.join(ROOT, "profiles", f"r3_{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
         if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
@@ -888,7 +890,16 @@ def main():
             sp["frac"], sp["achieved"] = None, None
             sp["note"] = ("the 3D branch runs on a second stream beside the 2D branch: HIP-event brackets on it include queue wait; frac / achieved "
                           "are taken from rocprofv3 kernel durations (frac_rocprof) -- `--workload 3d` measures the family on its own")
+        def _fresh(rf_, launches_per_step):
+            """A committed rocprofv3 figure belongs to this code only if the family is launched as often per step as when it was taken
+            (e.g. one 2D pass per iteration instead of two halves the launch count and doubles the launch size)."""
+            cps = rf_.get("calls_per_step")
+            return cps is None or abs(cps - launches_per_step) <= 0.06 * launches_per_step
+
         rf = famj.get(wl_key, {}).get("sparse_conv")
+        if sp and rf and not _fresh(rf, sp["launches_per_step"]):
+            sp["rocprof_note"] = "profiles/r3_rocprof_family.json was taken with another launch count per step: not used"
+            rf = None
         if sp and rf:
             gbs = sp["algorithmic_bytes_per_launch"] / (rf["avg_us"] * 1e-6) / 1e9
             sp["frac_rocprof"], sp["avg_launch_us_rocprof"], sp["rocprof_commit"] = round(gbs / HBM_PEAK_GBS, 4), rf["avg_us"], famj.get("commit")
@@ -922,6 +933,9 @@ def main():
                     "stream_configuration": "as timed for `value`: 2D main stream + " +
                                             ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
             rd = famj.get(wl_key, {}).get("dense_mfma")
+            if rd and not _fresh(rd, roof["launches_per_step"]):
+                roof["rocprof_note"] = "profiles/r3_rocprof_family.json was taken with another launch count per step: not used"
+                rd = None
             if rd:   # the same flops over rocprofv3's kernel durations of this command (no launch gaps): the two figures bracket the truth
                 roof["frac_rocprof"] = round(roof["algorithmic_flops_per_launch"] / (rd["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4)
                 roof["avg_launch_us_rocprof"], roof["rocprof_commit"] = rd["avg_us"], famj.get("commit")

@@ -9,9 +9,12 @@ F = os.path.join(R, "..", "gpurun_out", "final")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
 TITLE = {"3d": "Net3DSeg-only training step (bs 8, 1x MI355X) -- BASELINE configs[1]",
          "joint": "joint 2D+3D xMUDA step (bs 8+8, 1x MI355X) -- BASELINE configs[2]",
-         "kitti": "A2D2->SemanticKITTI-shape joint step (bs 2+2, 120,000-pt scans, 10 classes, 1x MI355X) -- BASELINE configs[4] per GPU"}
+         "kitti": "A2D2->SemanticKITTI-shape joint step (bs 2+2, 120,000-pt scans, 10 classes, 1x MI355X) -- BASELINE configs[4] per GPU",
+         "mopa": "MoPA iteration (bs 4+4, VGI + third 3D pass + pseudo-label CE + SAM-mask loss, 1x MI355X) -- BASELINE configs[3] per GPU"}
 CMD = {"3d": "python bench.py --workload 3d --steps 50 --warmup 5", "joint": "python bench.py --steps 20 --warmup 5",
-       "kitti": "python bench.py --workload kitti --steps 10 --warmup 3"}
+       "kitti": "python bench.py --workload kitti --steps 10 --warmup 3",
+       "mopa": "python bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline"}
+STEPS = {"3d": 55, "joint": 35, "kitti": 23, "mopa": 13}   # steps traced by make_final.sh (warm-up + timed + host-input steps)
 FAMILY = {"sparse_conv": ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk"),
           "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out")}
 
@@ -22,7 +25,7 @@ def git(*a):
 
 commit = git("rev-parse", "--short", "HEAD") + ("+dirty" if git("status", "--porcelain", "--", "mopa_amd", "bench.py") else "")
 fam = {"commit": commit, "note": "rocprofv3 --kernel-trace --stats of the bench command (profiles/make_final.sh); avg_us = total duration / calls over the family"}
-for w in ("3d", "joint", "kitti"):
+for w in ("3d", "joint", "kitti", "mopa"):
     if not os.path.exists(os.path.join(F, f"bench_{w}.json")):
         continue
     line = open(os.path.join(F, f"bench_{w}.json")).read().strip().splitlines()[-1]
@@ -48,7 +51,7 @@ for w in ("3d", "joint", "kitti"):
         calls = sum(agg[k][0] for k in kernels if k in agg)
         ns = sum(agg[k][1] for k in kernels if k in agg)
         if calls:
-            fam[w][name] = {"calls": calls, "avg_us": round(ns / calls / 1e3, 3)}
+            fam[w][name] = {"calls": calls, "avg_us": round(ns / calls / 1e3, 3), "calls_per_step": round(calls / STEPS[w], 2)}
 json.dump(fam, open(os.path.join(R, f"{RND}_rocprof_family.json"), "w"), indent=1)
 print(json.dumps(fam))
 if os.path.exists(os.path.join(F, "bench_mopa.json")):

@@ -9,14 +9,14 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 > $O/bench_joint.json 2> $O/b
 timeout 600 python3 bench.py --workload 3d --steps 50 --warmup 5 > $O/bench_3d.json 2> $O/bench_3d.err
 timeout 600 python3 bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_mopa.json 2> $O/bench_mopa.err
 timeout 600 python3 bench.py --workload kitti --steps 10 --warmup 3 > $O/bench_kitti.json 2> $O/bench_kitti.err   # BASELINE configs[4] per GPU
-for W in 3d joint kitti; do
-  A=""; [ $W = 3d ] && A="--workload 3d"; [ $W = kitti ] && A="--workload kitti"
+for W in 3d joint kitti mopa; do
+  A=""; [ $W = 3d ] && A="--workload 3d"; [ $W = kitti ] && A="--workload kitti"; [ $W = mopa ] && A="--workload mopa"
   # kernel statistics of the SAME command the bench line comes from (joint: --steps 20 --warmup 5 = the driver's; 25 steps traced)
-  S="--steps 20 --warmup 5"; [ $W = 3d ] && S="--steps 50 --warmup 5"; [ $W = kitti ] && S="--steps 10 --warmup 3"
+  S="--steps 20 --warmup 5"; [ $W = 3d ] && S="--steps 50 --warmup 5"; [ $W = kitti ] && S="--steps 10 --warmup 3"; [ $W = mopa ] && S="--steps 10 --warmup 3"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -o run -- python3 bench.py $A $S --no-cpu-baseline > $O/trace_$W.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$W -o run -- python3 bench.py $A --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$W.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$W -o run -- python3 bench.py $A --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
-  N=35; [ $W = 3d ] && N=55; [ $W = kitti ] && N=23   # joint: 5 warm-up + 20 timed + 2 + 8 steps of the host-inputs measurement (kitti: 3 + 10 + 2 + 8)
+  N=35; [ $W = 3d ] && N=55; [ $W = kitti ] && N=23; [ $W = mopa ] && N=13   # joint: 5 warm-up + 20 timed + 2 + 8 steps of the host-inputs measurement (kitti: 3 + 10 + 2 + 8)
   python3 profiles/summarize.py $O/trace_$W/run_kernel_stats.csv $N > $O/stats_$W.md
   python3 profiles/traffic.py $O/pmc_fetch_$W/run_counter_collection.csv $O/pmc_write_$W/run_counter_collection.csv > $O/traffic_$W.json
   cp $O/trace_$W/run_kernel_stats.csv $O/stats_$W.csv

@@ -190,3 +190,18 @@ def test_parameter_cache_notices_replaced_tensor_objects():
     named = dict(m.named_parameters())
     named.update(dict(m.named_buffers()))
     assert all(t is named[k] for k, t in zip(order2, flat3))
+
+
+def test_paired_batch_point_rows_equal_the_concatenated_calls():
+    """bench.py::pair_batch_of builds the point-row ids of the source + target pass as cat([pix_src, pix_trg + B_src * Hp * Wp]):
+    the same ids as packing the concatenated img_indices list (what Net2DSeg does with a bn_groups=2 batch given as a dict)."""
+    from mopa_amd.models.xmuda_arch import Net2DSeg
+    rng = np.random.Generator(np.random.PCG64(3))
+    H, W, Bs, Bt = 30, 45, 2, 3
+    idx_s = [np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], 1) for n in (7, 0)]
+    idx_t = [np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], 1) for n in (5, 9, 1)]
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    ps, pt = Net2DSeg.pack_indices(idx_s, H, W, "cpu"), Net2DSeg.pack_indices(idx_t, H, W, "cpu")
+    both = Net2DSeg.pack_indices(idx_s + idx_t, H, W, "cpu")
+    assert torch.equal(both, torch.cat([ps, pt + Bs * Hp * Wp]))
+    assert both.dtype == torch.int32 and int(both.max()) < (Bs + Bt) * Hp * Wp
