@@ -586,13 +586,34 @@ def main():
     # MOPA_BENCH_PAIR=0: the two-call form (half() twice).
     pair_mode = joint and os.environ.get("MOPA_BENCH_PAIR", "1") != "0" and reorder and (decoupled or mopa)
 
+    # The same for the 3D network (Net3DSeg "bn_group_points"): both domains' scans as one sparse tensor, BatchNorm per domain on row
+    # ranges (the source's rows come first at every level).  The 3D branch is bound by per-launch costs, not by rows: one pass over
+    # 16 scans takes 9.3 ms where two passes over 8 take 11.2, 8 scans 5.6 where two of 4 take 7.9 (`--workload 3d --batch`).
+    # MOPA_BENCH_PAIR_3D=0: one 3D pass per domain.
+    pair_3d = os.environ.get("MOPA_BENCH_PAIR_3D", "1") != "0"
+    vgi_stream = torch.cuda.Stream(device=dev) if (mopa and os.environ.get("MOPA_BENCH_VGI_STREAM", "1") != "0") else None
+
     def pair_batch_of(bs, bt):
         Bs = bs["img"].shape[0]
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-        return {"img": torch.cat([bs["img"], bt["img"]]), "point_pix_2d": torch.cat([bs["pix"], bt["pix"] + Bs * Hp * Wp]),
-                "img_indices": None, "bn_groups": 2}
+        p2 = {"img": torch.cat([bs["img"], bt["img"]]), "point_pix_2d": torch.cat([bs["pix"], bt["pix"] + Bs * Hp * Wp]),
+              "img_indices": None, "bn_groups": 2}
+        p3 = None
+        if pair_3d:
+            lt = bt["locs"].clone()
+            lt[:, 3] += Bs   # the target's scans behind the source's
+            p3 = {"x": [torch.cat([bs["locs"], lt]), torch.cat([bs["feats"], bt["feats"]])], "bn_group_points": int(bs["locs"].shape[0])}
+        return p2, p3
 
     pair2d = pair_batch_of(batches[0], batches[1]) if pair_mode else None
+    if pair_mode and pair2d[1] is not None:   # rule counts of the joint geometry for the algorithmic-bytes model (as above)
+        g = Geometry3D(pair2d[1]["x"][0], 7, 4096, dev, group_points=pair2d[1]["bn_group_points"])
+        for l in range(7):
+            timer.rules[(27, g.num_active[l], g.num_active[l])] = g.num_rules[l]
+        for l in range(6):
+            timer.rules[(8, g.num_active[l + 1], g.num_active[l])] = g.num_active[l]
+            timer.rules[(8, g.num_active[l], g.num_active[l + 1])] = g.num_active[l]
+        del g
     if pair_mode:
         torch.cuda.synchronize()
         resident.record()
@@ -600,24 +621,45 @@ def main():
     def pair(bs, bt, p2d, ready=None):
         ready = ready or resident
         main = torch.cuda.current_stream(dev)
+        # MoPA: the VGI needs the batch only.  Its two host round trips wait for whatever is queued in front of its kernels: on the
+        # side stream that is the tail of the previous step's 3D backward (5-6 ms into the step), and the host cannot enqueue the 3D
+        # forwards until they are through.  On a stream of its own they return as soon as the VGI kernels have run
+        # (MOPA_BENCH_VGI_STREAM=0: on the side stream, after the 2D forward's enqueue).
+        vin, vgi_done = None, None
+        if mopa and vgi_stream is not None:
+            with torch.cuda.stream(vgi_stream):
+                vgi_stream.wait_event(ready)
+                vin = vgi_batch(bt)
+                vgi_done = torch.cuda.Event()
+                vgi_done.record()
         dual.side.wait_stream(main)
         # the long queue first; the 3D launches are enqueued while it runs.  (Measured alternatives, no gain: the 3D passes enqueued
         # first -- 238 -> 220 scans/s MoPA, 191 -> 176 kitti; the side stream not ordered behind the main stream at the step
         # boundary -- unchanged: at 4 + 4 and 2 + 2 images the 3D chain fills its stream for the whole step)
-        o2 = model2d(p2d)
+        o2 = model2d(p2d[0])
         if tl is not None:
             tl.mark("fwd2d_end", main)
         third = None
         with torch.cuda.stream(dual.side):
             dual.side.wait_event(ready)
-            # MoPA: the VGI needs the batch only -- it runs FIRST, while the main stream is busy with the 2D forward: its host round
-            # trips then wait for a short side-stream queue, and its third 3D pass joins the other two forwards
-            vin = vgi_batch(bt) if mopa else None
-            o3 = []
-            for b in (bs, bt):
-                g = model3d.net_3d.geometry(b["locs"])
-                o3.append(model3d({"x": [b["locs"], b["feats"]], "geometry_3d": g}))
+            if mopa and vin is None:
+                vin = vgi_batch(bt)
+            if p2d[1] is not None:
+                p3 = p2d[1]
+                o3m = model3d(dict(p3, geometry_3d=model3d.net_3d.geometry(p3["x"][0], group_points=p3["bn_group_points"])))
+                n3 = p3["bn_group_points"]
+                o3 = [{k: v[:n3] for k, v in o3m.items()}, {k: v[n3:] for k, v in o3m.items()}]
+            else:
+                o3 = []
+                for b in (bs, bt):
+                    g = model3d.net_3d.geometry(b["locs"])
+                    o3.append(model3d({"x": [b["locs"], b["feats"]], "geometry_3d": g}))
             if vin is not None:
+                if vgi_done is not None:
+                    dual.side.wait_event(vgi_done)
+                    for t in list(vin[0]["x"]) + [vin[1]]:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(dual.side)
                 third = (model3d(vin[0]), vin[1])
         if tl is not None:
             tl.mark("fwd3d_end", dual.side)
@@ -980,6 +1022,8 @@ def main():
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
                        else "python walk (MOPA_SCN_NATIVE=0)",
+                       "net3d_pass": (None if not joint else "source + target scans as ONE sparse tensor (Net3DSeg bn_group_points: BatchNorm per domain "
+                                      "on row ranges)" if (pair_mode and pair_3d) else "one pass per domain"),
                        "net2d_pass": (None if not joint else
                                       "source + target images in ONE pass of the 2D network (Net2DSeg bn_groups=2: BatchNorm statistics, "
                                       "running-statistics updates and dropout masks per domain, in the reference's call order)" if pair_mode

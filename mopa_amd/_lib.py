@@ -22,6 +22,7 @@ SIGNATURES = {
     "mopa_voxel_hash_workspace_bytes": ("z", "l"),
     "mopa_voxel_hash_build": ("i", "plpplpppppzp"),
     "mopa_coarsen_workspace_bytes": ("z", "l"),
+    "mopa_group_split": ("i", "ppiipp"),
     "mopa_coarsen_build": ("i", "pippplppppzp"),
     "mopa_rulebook_subm": ("i", "pipplipp"),
     "mopa_rulebook_updown": ("i", "ppiippp"),

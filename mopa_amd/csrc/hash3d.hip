@@ -310,6 +310,26 @@ MOPA_API int mopa_coarsen_build(const uint64_t* fine_keys, int32_t n_fine_cap, c
                            num_coarse, uws, st);
 }
 
+// ---------------------------------------------------------------- row ranges of scan groups
+// Rows are numbered in first-seen order (points in the order given; a coarse row at the first fine row that maps to it), and a
+// voxel key carries its scan index: when the points of scans 0 .. B0-1 come first in the batch, their rows come first at EVERY
+// level.  out[0] = max(item_row[i]) + 1 over i < n (n = *n_dev if n_dev else n_host): the number of rows of the first group at the
+// level `item_row` maps into, given the number of its items (points, or rows of the finer level).  out[0] must be 0 before.
+__global__ void k_group_split(const int* __restrict__ item_row, const int* __restrict__ n_dev, int n_host, int* __restrict__ out) {
+  const int n = n_dev ? *n_dev : n_host;
+  int m = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, item_row[i] + 1);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+// Integer max: the result does not depend on the order of the atomics.
+MOPA_API int mopa_group_split(const int32_t* item_row, const int32_t* n_dev, int32_t n_host, int32_t n_cap, int32_t* out, void* stream) {
+  if (!item_row || !out || n_cap <= 0 || (!n_dev && (n_host < 0 || n_host > n_cap))) return MOPA_ERR_ARG;
+  k_group_split<<<stream_grid(n_cap, 256), 256, 0, (hipStream_t)stream>>>(item_row, n_dev, n_host, out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
 // ---------------------------------------------------------------- rule tables
 __device__ __forceinline__ int table_lookup(const uint64_t* __restrict__ tk, const int* __restrict__ tv,
                                             uint32_t mask, uint64_t key) {

@@ -26,9 +26,11 @@ enum { C_SUBM = 0, C_DOWN = 1, C_UP = 2, C_NIN = 3 };
 // forms_host  int64 [n_ops][2][3]: per convolution and pass (0 forward, 1 backward-data): buffer (K*Cin*Cout floats), column-group
 //             width the buffer was packed for (0 = plain per-offset transpose, -1 = never built), weight epoch it was built at
 // geom_host   int64: [0] levels L, [1] n_points, [2] point_row, [3] row_start, [4] row_points, [5] grp_o, [6] grp_in, [7] grp_out,
-//             then per level l at 8 + 8 l: rows A_l, nbr27, its grp_start, ch (rows A_{l+1}), its grp_start, up (rows A_l), its grp_start, -
+//             then per level l at 8 + 8 l: rows A_l, nbr27, its grp_start, ch (rows A_{l+1}), its grp_start, up (rows A_l), its grp_start,
+//             split_l (0: one BatchNorm group; s: rows [0, s) and [s, A_l) are two groups of scans whose BatchNorm statistics, running
+//             updates and gradients are computed separately, first group first -- mopa_amd/sparse3d.py::Geometry3D.split)
 enum { G_L = 0, G_NPTS, G_PROW, G_RSTART, G_RPTS, G_GO, G_GI, G_GOUT, G_LEVELS = 8, G_LW = 8 };
-enum { GL_A = 0, GL_NBR, GL_NBR_GS, GL_CH, GL_CH_GS, GL_UP, GL_UP_GS };
+enum { GL_A = 0, GL_NBR, GL_NBR_GS, GL_CH, GL_CH_GS, GL_UP, GL_UP_GS, GL_SPLIT };
 // bufs_host   int64 [nbufs][2]: base pointer, row stride (floats) of the activation (or gradient) buffers
 // io_host     int64: see IO_* below (doubles travel as their bit patterns)
 enum { IO_TRAINING = 0, IO_EPOCH, IO_FEATS, IO_CIN, IO_X0BUF, IO_X0COL, IO_OUTBUF, IO_OUTCOL, IO_M, IO_NCLS, IO_W1, IO_B1, IO_W2, IO_B2,
@@ -52,6 +54,18 @@ static inline View view_of(const int64_t* bufs, const int64_t* geom, int buf, in
   v.C = C;
   v.rows = (int)geom[G_LEVELS + G_LW * level + GL_A];
   return v;
+}
+
+// row ranges of the BatchNorm groups at a level: (0, rows) or (0, split), (split, rows)
+static inline int bn_groups(const int64_t* geom, int level, int rows, int r0[2], int r1[2]) {
+  const int s = (int)geom[G_LEVELS + G_LW * level + GL_SPLIT];
+  if (s <= 0 || s >= rows) { r0[0] = 0; r1[0] = rows; return 1; }
+  r0[0] = 0; r1[0] = s; r0[1] = s; r1[1] = rows;
+  return 2;
+}
+static inline int n_bn_groups(const int64_t* geom) {
+  for (int l = 0; l < (int)geom[G_L]; ++l) if (geom[G_LEVELS + G_LW * l + GL_SPLIT] > 0) return 2;
+  return 1;
 }
 
 struct Table { const int32_t* nbr; const int32_t* gs; int K; int rows_out; };
@@ -172,6 +186,7 @@ MOPA_API int mopa_scn_forward(const int32_t* prog_host, int32_t n_ops, const int
   const int training = (int)io[IO_TRAINING];
   const float momentum = (float)io_f(io, IO_MOMENTUM), eps = (float)io_f(io, IO_EPS), leak = (float)io_f(io, IO_LEAK);
   float* stats = reinterpret_cast<float*>(io[IO_STATS]);
+  const int NG = n_bn_groups(geom_host);   // the statistics arena holds NG slots of 4 C floats per BatchNorm
   int rc = refresh_forms(prog_host, n_ops, params_host, forms_host, geom_host, bufs_host, nullptr, nullptr, 0, io[IO_EPOCH], 0, st);
   if (rc) return rc;
   {   // InputLayer (mode 4: mean of the points of a voxel)
@@ -186,8 +201,12 @@ MOPA_API int mopa_scn_forward(const int32_t* prog_host, int32_t n_ops, const int
     const View dst = view_of(bufs_host, geom_host, o[OP_DBUF], o[OP_DCOL], o[OP_DC], o[OP_LDST]);
     if (o[OP_KIND] == K_BN) {
       const int64_t* p = params_host + i * 4;
-      rc = mopa_bnrelu_rows_fwd(src.p, src.ld, dst.p, dst.ld, src.rows, src.C, (const float*)p[0], (const float*)p[1], (float*)p[2],
-                                (float*)p[3], momentum, eps, leak, training, stats + o[OP_ABUF], ws, ws_bytes, st);
+      int r0[2], r1[2];
+      const int ng = bn_groups(geom_host, o[OP_LSRC], src.rows, r0, r1);
+      for (int g = 0; g < ng && !rc; ++g)
+        rc = mopa_bnrelu_rows_fwd(src.p + (int64_t)r0[g] * src.ld, src.ld, dst.p + (int64_t)r0[g] * dst.ld, dst.ld, r1[g] - r0[g], src.C,
+                                  (const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], momentum, eps, leak, training,
+                                  stats + (int64_t)NG * o[OP_ABUF] + g * 4 * src.C, ws, ws_bytes, st);
     } else if (o[OP_KIND] == K_CONV) {
       const int l = o[OP_LSRC] < o[OP_LDST] ? o[OP_LSRC] : o[OP_LDST];
       const Table t = table_of(geom_host, o[OP_CKIND], l, false);
@@ -221,6 +240,7 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
   const int training = (int)io[IO_TRAINING];
   const float leak = (float)io_f(io, IO_LEAK);
   const float* stats = reinterpret_cast<const float*>(io[IO_STATS]);
+  const int NG = n_bn_groups(geom_host);
   const int M = (int)io[IO_M], NC = (int)io[IO_NCLS];
   int rc = refresh_forms(prog_host, n_ops, params_host, forms_host, geom_host, bufs_host, gbufs_host, plan_host, n_steps, io[IO_EPOCH], 1, st);
   if (rc) return rc;
@@ -242,8 +262,12 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
     const View dy = view_of(gbufs_host, geom_host, pl[PL_DYBUF], pl[PL_DYCOL], pl[PL_DYC], o[OP_LDST]);
     const View dx = view_of(gbufs_host, geom_host, pl[PL_DXBUF], pl[PL_DXCOL], pl[PL_DXC], o[OP_LSRC]);
     if (pl[PL_KIND] == K_BN) {
-      rc = mopa_bnrelu_rows_bwd(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, stats + o[OP_ABUF], leak, training, (float*)g[0],
-                                (float*)g[1], (int)g[2], pl[PL_ACC], ws, ws_bytes, st);
+      int r0[2], r1[2];
+      const int ng = bn_groups(geom_host, o[OP_LSRC], x.rows, r0, r1);
+      for (int k = 0; k < ng && !rc; ++k)   // (the parameter gradients of the groups add up)
+        rc = mopa_bnrelu_rows_bwd(dy.p + (int64_t)r0[k] * dy.ld, dy.ld, x.p + (int64_t)r0[k] * x.ld, x.ld, dx.p + (int64_t)r0[k] * dx.ld, dx.ld,
+                                  r1[k] - r0[k], x.C, stats + (int64_t)NG * o[OP_ABUF] + k * 4 * x.C, leak, training, (float*)g[0],
+                                  (float*)g[1], (int)g[2] || k > 0, pl[PL_ACC], ws, ws_bytes, st);
       if (rc) return rc;
       continue;
     }

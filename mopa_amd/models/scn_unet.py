@@ -125,9 +125,10 @@ class UNetSCN(nn.Module):
         U(sm.put(2, _Slot()), planes)
         sm.put(3, _BNParams(m))
 
-    def geometry(self, locs) -> sparse3d.Geometry3D:
+    def geometry(self, locs, group_points=None) -> sparse3d.Geometry3D:
+        """group_points: see Geometry3D (two groups of scans in one batch, BatchNorm per group)."""
         dev = next(self.parameters()).device
-        return sparse3d.Geometry3D(locs, self.num_planes, self.full_scale, dev)
+        return sparse3d.Geometry3D(locs, self.num_planes, self.full_scale, dev, group_points=group_points)
 
 
 def checkpoint_shapes(model: nn.Module):

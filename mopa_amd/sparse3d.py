@@ -47,7 +47,12 @@ class Geometry3D:
     sized from a bound: no second round trip).
     """
 
-    def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None):
+    def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None, group_points: int | None = None):
+        """group_points (extension): the first `group_points` points belong to a first group of scans (e.g. the source batch, the
+        rest being the target batch, with its scan indices behind the source's).  Rows are numbered in first-seen order and a voxel
+        belongs to one scan, so the first group's rows come first at every level: `self.split[l]` = their number.  BatchNorm then
+        runs per group on row ranges (statistics, running updates, gradients: as two calls of the network would), everything else
+        sees one batch."""
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise RuntimeError(f"coords must be (N,4) [x,y,z,batch], got {tuple(coords.shape)}")
         device = torch.device(device if device is not None else "cuda")
@@ -68,7 +73,7 @@ class Geometry3D:
         tk = [torch.empty(cap, **i64) for _ in range(L)]
         tv = [torch.empty(cap, **i32) for _ in range(L)]
         item_row = [torch.empty(N, **i32) for _ in range(L)]  # [0]: point->row0 ; [l>0]: parent of level l-1 rows
-        meta = torch.zeros(L + 1, **i32)                       # counts[0..L-1], status
+        meta = torch.zeros(2 * L + 1, **i32)                   # counts[0..L-1], status, first-group rows [0..L-1] (group_points)
         wsb = query("mopa_voxel_hash_workspace_bytes", N)
         ws = _ws(wsb, device)
         st = stream()
@@ -77,11 +82,18 @@ class Geometry3D:
         for l in range(L - 1):
             call("mopa_coarsen_build", ptr(keys[l]), N, ptr(meta, l), ptr(tk[l + 1]), ptr(tv[l + 1]), cap,
                  ptr(item_row[l + 1]), ptr(keys[l + 1]), ptr(meta, l + 1), ptr(ws), ws.numel(), st)
+        if group_points is not None:
+            if not 0 < group_points < N:
+                raise ValueError(f"group_points={group_points} must split the {N} points into two non-empty groups")
+            call("mopa_group_split", ptr(item_row[0]), None, int(group_points), N, ptr(meta, L + 1), st)
+            for l in range(L - 1):   # parents of the first group's rows at level l
+                call("mopa_group_split", ptr(item_row[l + 1]), ptr(meta, L + 1 + l), 0, N, ptr(meta, L + 2 + l), st)
         m = meta.cpu().tolist()  # the one host sync of the geometry build
         if m[L] != 0:
             raise RuntimeError("voxel coordinates out of range: need 0 <= x,y,z < 4096 and batch >= 0")
         self.num_active = m[:L]
         A = self.num_active
+        self.split = m[L + 1:2 * L + 1] if group_points is not None else None
         self.point_row = item_row[0]
         self.row_keys = [keys[l][:A[l]] for l in range(L)]
         self.parent = [item_row[l + 1][:A[l]] for l in range(L - 1)]
@@ -145,6 +157,7 @@ class Geometry3D:
                 if l < L - 1:
                     r[3], r[4] = self.ch[l].data_ptr(), self._rb[self.ch[l].data_ptr()][0].data_ptr()
                     r[5], r[6] = self.up[l].data_ptr(), self._rb[self.up[l].data_ptr()][0].data_ptr()
+                r[7] = self.split[l] if self.split is not None else 0
             self._desc = d
         return d
 
@@ -331,6 +344,18 @@ def spconv_bwd_weight(nbr: torch.Tensor, x: View, dout: View, dw: torch.Tensor, 
     ws = _ws(wsb, dw.device)
     call("mopa_spconv_bwd_weight", ptr(nbr), K, A_out, x.p, x.ld, x.C, dout.p, dout.ld, dout.C, ptr(dw),
          int(accumulate), ptr(ws), ws.numel(), stream())
+
+
+def bn_row_groups(geom, level: int):
+    """Row ranges BatchNorm treats as separate batches at `level`: [(0, A)] or, for a geometry built with group_points,
+    [(0, split), (split, A)] (same rule as csrc/scn_exec.hip::bn_groups)."""
+    A = geom.num_active[level]
+    s = geom.split[level] if geom.split is not None else 0
+    return [(0, A)] if s <= 0 or s >= A else [(0, s), (s, A)]
+
+
+def rows_of(v: View, r0: int, r1: int) -> View:
+    return v if (r0 == 0 and r1 == v.rows) else View(v.t[r0:r1], v.col, v.C)
 
 
 def bnrelu_fwd(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats: torch.Tensor):
@@ -604,10 +629,11 @@ class NativeState:
             self._tag = tag
             self.epoch += 1
 
-    def buffers(self, A, device, with_stats: bool):
-        """One arena for the pass: [nbufs][2] (pointer, row stride) + the tensor that owns the memory (+ stats pointer)."""
+    def buffers(self, A, device, with_stats: bool, groups: int = 1):
+        """One arena for the pass: [nbufs][2] (pointer, row stride) + the tensor that owns the memory (+ stats pointer; `groups`
+        slots of 4 C floats per BatchNorm)."""
         sizes = [(A[level] * width * 4 + 255) // 256 * 256 for level, width in self.nt["bufs"]]
-        extra = (self.nt["stats_floats"] * 4 + 255) // 256 * 256 if with_stats else 0
+        extra = (self.nt["stats_floats"] * groups * 4 + 255) // 256 * 256 if with_stats else 0
         arena = torch.empty(sum(sizes) + extra, dtype=torch.uint8, device=device)
         base = arena.data_ptr()
         bufs = np.zeros((len(sizes), 2), np.int64)
@@ -628,7 +654,7 @@ def _native_forward(ctx, spec, geom, training, feats, flat, P, prog):
     nt = nat.nt
     A, m, C, N = geom.num_active, spec.m, spec.num_classes, geom.n_points
     gd = geom.desc()
-    bufs, arena, stats_ptr = nat.buffers(A, dev, True)
+    bufs, arena, stats_ptr = nat.buffers(A, dev, True, 2 if geom.split is not None else 1)
     out_feats = torch.empty(N, m, dtype=torch.float32, device=dev)
     l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
     l2 = torch.empty(N, C if spec.dual_head else 0, dtype=torch.float32, device=dev)
@@ -753,11 +779,13 @@ class SCNNetFunction(torch.autograd.Function):
         for op in prog.ops:
             if op[0] == "bn":
                 _, name, src, dst = op
-                st = torch.empty(4, src.C, dtype=torch.float32, device=dev)
-                gathered = bnrelu_fwd(view(src), view(dst), P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
-                                      P[name + ".running_var"], training, st)
+                groups = bn_row_groups(geom, src.level)
+                st = torch.empty(len(groups), 4, src.C, dtype=torch.float32, device=dev)
+                gathered = [bnrelu_fwd(rows_of(view(src), r0, r1), rows_of(view(dst), r0, r1), P[name + ".weight"], P[name + ".bias"],
+                                       P[name + ".running_mean"], P[name + ".running_var"], training, st[g])
+                            for g, (r0, r1) in enumerate(groups)]
                 stats[name] = st
-                if gathered is not None:
+                if gathered[0] is not None:
                     stats[name + "/moments"] = gathered
             elif op[0] == "conv":
                 _, name, kind, l, src, dst = op
@@ -836,8 +864,11 @@ class SCNNetFunction(torch.autograd.Function):
             if step[0] == "bn":
                 _, name, src, dy_ref, dx_ref, acc = step
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-                bnrelu_bwd(gview(dy_ref), views[src.key], gview(dx_ref), ctx.stats[name], ctx.training, dg, db, acc, pacc,
-                           gathered=ctx.stats.get(name + "/moments"))
+                moments = ctx.stats.get(name + "/moments")
+                for g, (r0, r1) in enumerate(bn_row_groups(geom, src.level)):   # (the groups' parameter gradients add up)
+                    bnrelu_bwd(rows_of(gview(dy_ref), r0, r1), rows_of(views[src.key], r0, r1), rows_of(gview(dx_ref), r0, r1),
+                               ctx.stats[name][g], ctx.training, dg, db, acc, pacc or g > 0,
+                               gathered=None if moments is None else moments[g])
             else:
                 _, name, kind, l, src, dout_ref, dx_ref = step
                 dout = gview(dout_ref)

@@ -22,7 +22,7 @@ def _protos():
 def test_header_lists_the_whole_abi():
     protos = _protos()
     assert len(protos) >= 49
-    for required in ("mopa_voxel_hash_build", "mopa_rulebook_subm", "mopa_spconv_fwd", "mopa_spconv_bwd_weight",
+    for required in ("mopa_voxel_hash_build", "mopa_group_split", "mopa_rulebook_subm", "mopa_spconv_fwd", "mopa_spconv_bwd_weight",
                      "mopa_bnrelu_rows_fwd", "mopa_output_layer_heads_fwd", "mopa_conv2d_igemm", "mopa_conv2d_bwd_weight",
                      "mopa_maxpool3x3s2_fwd", "mopa_dropout_rows", "mopa_dropout_rows_dseed", "mopa_softmax_kl_fwd", "mopa_wce_fwd",
                      "mopa_mask_cons_fwd", "mopa_adam_flat"):

@@ -458,3 +458,63 @@ def test_cached_weight_forms_3d_follow_weight_updates_batched_and_single(monkeyp
     for x, y in zip(a, s):
         assert torch.equal(x, y)
     assert not torch.equal(a[0], a[1]) and not torch.equal(a[3], a[4]) and torch.equal(a[3], a[5])
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_two_groups_of_scans_in_one_3d_pass_equal_two_calls(native, monkeypatch):
+    """data_batch["bn_group_points"] = N0: the scans of two batches (source, target) go through Net3DSeg as ONE sparse tensor,
+    BatchNorm statistics / running updates / gradients per group on row ranges (the first group's rows come first at every
+    level: Geometry3D.split).  Against the two calls the reference makes (train_xmuda_mopa.py:343,427): the split row counts
+    equal the first batch's own active-row counts at every level (integers, exact); logits, running statistics and parameter
+    gradients agree to fp32 round-off (a row's sum is the same set of exact products in another order when its 64-row tile holds
+    other rows; the weight gradient is one sum over both groups instead of two accumulated)."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd.sparse3d import Geometry3D
+    monkeypatch.setattr(s3, "NATIVE", native)
+    ca = _cloud(21, n=7000, size=130, batch=2)
+    cb = _cloud(22, n=5000, size=130, batch=3)
+    ca = ca[np.argsort(ca[:, 3], kind="stable")]   # scans in batch order, as collate builds them
+    cb = cb[np.argsort(cb[:, 3], kind="stable")]
+    cb2 = cb.copy()
+    cb2[:, 3] += 2
+    both = np.concatenate([ca, cb2])
+    rng = np.random.Generator(np.random.PCG64(8))
+    fa = torch.from_numpy(rng.random((len(ca), 1), dtype=np.float32) + 0.5).cuda()
+    fb = torch.from_numpy(rng.random((len(cb), 1), dtype=np.float32) + 0.5).cuda()
+    g = Geometry3D(torch.from_numpy(both), 7, 4096, "cuda", group_points=len(ca))
+    ga = Geometry3D(torch.from_numpy(ca), 7, 4096, "cuda")
+    assert g.split == ga.num_active and all(0 < s < a for s, a in zip(g.split, g.num_active))
+    assert Geometry3D(torch.from_numpy(both), 7, 4096, "cuda").split is None
+
+    def gout(shape, seed):
+        return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape, dtype=np.float32)).cuda()
+
+    two = _build_3d(7).train()
+    outs = []
+    for k, (c, f) in enumerate(((ca, fa), (cb, fb))):
+        o = two({"x": [torch.from_numpy(c), f]})
+        sum((o[n] * gout(tuple(o[n].shape), 100 * k + i)).sum() for i, n in enumerate(sorted(o))).backward()
+        outs.append({n: v.detach().clone() for n, v in o.items()})
+    one = _build_3d(7).train()
+    o = one({"x": [torch.from_numpy(both), torch.cat([fa, fb])], "bn_group_points": len(ca)})
+    na = len(ca)
+    loss = 0
+    for k, sl in enumerate((slice(0, na), slice(na, None))):
+        loss = loss + sum((o[n][sl] * gout(tuple(o[n][sl].shape), 100 * k + i)).sum() for i, n in enumerate(sorted(o)))
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, sl in enumerate((slice(0, na), slice(na, None))):
+        for n in outs[k]:
+            ref, got = outs[k][n], o[n][sl]
+            assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, n)
+    sa, sb = two.state_dict(), one.state_dict()
+    for n in sa:
+        assert float((sa[n] - sb[n]).abs().max()) <= 1e-5 * (float(sa[n].abs().max()) + 1e-6), n
+    worst = 0.0
+    for (n, p), (_, q) in zip(two.named_parameters(), one.named_parameters()):
+        err = float((p.grad - q.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-20)
+        worst = max(worst, err)
+        assert err <= 2e-4, (n, err)
+    print("two calls vs one grouped pass: worst parameter-gradient difference / tensor max", worst)
+    with pytest.raises(ValueError):
+        one({"x": [torch.from_numpy(both), torch.cat([fa, fb])], "bn_group_points": len(ca), "geometry_3d": Geometry3D(torch.from_numpy(both), 7, 4096, "cuda")})
