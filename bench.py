@@ -591,6 +591,7 @@ def main():
     # 16 scans takes 9.3 ms where two passes over 8 take 11.2, 8 scans 5.6 where two of 4 take 7.9 (`--workload 3d --batch`).
     # MOPA_BENCH_PAIR_3D=0: one 3D pass per domain.
     pair_3d = os.environ.get("MOPA_BENCH_PAIR_3D", "1") != "0"
+    pair_3d_three = os.environ.get("MOPA_BENCH_PAIR_3D_THREE", "1") != "0"   # MoPA: the VGI batch as a third group of that pass
     vgi_stream = torch.cuda.Stream(device=dev) if (mopa and os.environ.get("MOPA_BENCH_VGI_STREAM", "1") != "0") else None
 
     def pair_batch_of(bs, bt):
@@ -644,22 +645,32 @@ def main():
             dual.side.wait_event(ready)
             if mopa and vin is None:
                 vin = vgi_batch(bt)
+            if vin is not None and vgi_done is not None:
+                dual.side.wait_event(vgi_done)
+                for t in list(vin[0]["x"]) + [vin[1]]:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(dual.side)
             if p2d[1] is not None:
                 p3 = p2d[1]
-                o3m = model3d(dict(p3, geometry_3d=model3d.net_3d.geometry(p3["x"][0], group_points=p3["bn_group_points"])))
+                locs3, feats3, cuts = p3["x"][0], p3["x"][1], p3["bn_group_points"]
+                if vin is not None and pair_3d_three:   # MoPA: the VGI batch as a third group of the same pass (scan indices behind)
+                    lv = vin[0]["x"][0].clone()
+                    lv[:, 3] += 2 * bs["img"].shape[0]
+                    cuts = [cuts, int(locs3.shape[0])]
+                    locs3, feats3 = torch.cat([locs3, lv]), torch.cat([feats3, vin[0]["x"][1]])
+                o3m = model3d({"x": [locs3, feats3], "bn_group_points": cuts,
+                               "geometry_3d": model3d.net_3d.geometry(locs3, group_points=cuts)})
                 n3 = p3["bn_group_points"]
-                o3 = [{k: v[:n3] for k, v in o3m.items()}, {k: v[n3:] for k, v in o3m.items()}]
+                n4 = int(p3["x"][0].shape[0])
+                o3 = [{k: v[:n3] for k, v in o3m.items()}, {k: v[n3:n4] for k, v in o3m.items()}]
+                if vin is not None and pair_3d_three:
+                    third = ({k: v[n4:] for k, v in o3m.items()}, vin[1])
             else:
                 o3 = []
                 for b in (bs, bt):
                     g = model3d.net_3d.geometry(b["locs"])
                     o3.append(model3d({"x": [b["locs"], b["feats"]], "geometry_3d": g}))
-            if vin is not None:
-                if vgi_done is not None:
-                    dual.side.wait_event(vgi_done)
-                    for t in list(vin[0]["x"]) + [vin[1]]:
-                        if torch.is_tensor(t) and t.is_cuda:
-                            t.record_stream(dual.side)
+            if vin is not None and third is None:
                 third = (model3d(vin[0]), vin[1])
         if tl is not None:
             tl.mark("fwd3d_end", dual.side)

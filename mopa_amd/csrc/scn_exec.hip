@@ -27,8 +27,9 @@ enum { C_SUBM = 0, C_DOWN = 1, C_UP = 2, C_NIN = 3 };
 //             width the buffer was packed for (0 = plain per-offset transpose, -1 = never built), weight epoch it was built at
 // geom_host   int64: [0] levels L, [1] n_points, [2] point_row, [3] row_start, [4] row_points, [5] grp_o, [6] grp_in, [7] grp_out,
 //             then per level l at 8 + 8 l: rows A_l, nbr27, its grp_start, ch (rows A_{l+1}), its grp_start, up (rows A_l), its grp_start,
-//             split_l (0: one BatchNorm group; s: rows [0, s) and [s, A_l) are two groups of scans whose BatchNorm statistics, running
-//             updates and gradients are computed separately, first group first -- mopa_amd/sparse3d.py::Geometry3D.split)
+//             split_l (0: one BatchNorm group; s: rows [0, s) and [s, A_l) are groups of scans whose BatchNorm statistics, running
+//             updates and gradients are computed separately, first group first -- mopa_amd/sparse3d.py::Geometry3D.split);
+//             behind the L + 1 level rows: a tail of 8 values, tail[l] = second split of level l (0: none) -- three groups
 enum { G_L = 0, G_NPTS, G_PROW, G_RSTART, G_RPTS, G_GO, G_GI, G_GOUT, G_LEVELS = 8, G_LW = 8 };
 enum { GL_A = 0, GL_NBR, GL_NBR_GS, GL_CH, GL_CH_GS, GL_UP, GL_UP_GS, GL_SPLIT };
 // bufs_host   int64 [nbufs][2]: base pointer, row stride (floats) of the activation (or gradient) buffers
@@ -56,16 +57,26 @@ static inline View view_of(const int64_t* bufs, const int64_t* geom, int buf, in
   return v;
 }
 
-// row ranges of the BatchNorm groups at a level: (0, rows) or (0, split), (split, rows)
-static inline int bn_groups(const int64_t* geom, int level, int rows, int r0[2], int r1[2]) {
-  const int s = (int)geom[G_LEVELS + G_LW * level + GL_SPLIT];
-  if (s <= 0 || s >= rows) { r0[0] = 0; r1[0] = rows; return 1; }
-  r0[0] = 0; r1[0] = s; r0[1] = s; r1[1] = rows;
-  return 2;
+// row ranges of the BatchNorm groups at a level: (0, rows) | (0, s1), (s1, rows) | (0, s1), (s1, s2), (s2, rows)
+#define SCN_MAX_GROUPS 3
+static inline int bn_groups(const int64_t* geom, int level, int rows, int r0[SCN_MAX_GROUPS], int r1[SCN_MAX_GROUPS]) {
+  const int s1 = (int)geom[G_LEVELS + G_LW * level + GL_SPLIT];
+  const int s2 = (int)geom[G_LEVELS + G_LW * ((int)geom[G_L] + 1) + level];
+  if (s1 <= 0 || s1 >= rows) { r0[0] = 0; r1[0] = rows; return 1; }
+  r0[0] = 0; r1[0] = s1; r0[1] = s1;
+  if (s2 <= s1 || s2 >= rows) { r1[1] = rows; return 2; }
+  r1[1] = s2; r0[2] = s2; r1[2] = rows;
+  return 3;
 }
+// slots of 4 C floats per BatchNorm in the statistics arena (the same for every layer of a pass)
 static inline int n_bn_groups(const int64_t* geom) {
-  for (int l = 0; l < (int)geom[G_L]; ++l) if (geom[G_LEVELS + G_LW * l + GL_SPLIT] > 0) return 2;
-  return 1;
+  const int L = (int)geom[G_L];
+  int n = 1;
+  for (int l = 0; l < L; ++l) {
+    if (geom[G_LEVELS + G_LW * l + GL_SPLIT] > 0 && n < 2) n = 2;
+    if (geom[G_LEVELS + G_LW * (L + 1) + l] > 0) n = 3;
+  }
+  return n;
 }
 
 struct Table { const int32_t* nbr; const int32_t* gs; int K; int rows_out; };
@@ -201,7 +212,7 @@ MOPA_API int mopa_scn_forward(const int32_t* prog_host, int32_t n_ops, const int
     const View dst = view_of(bufs_host, geom_host, o[OP_DBUF], o[OP_DCOL], o[OP_DC], o[OP_LDST]);
     if (o[OP_KIND] == K_BN) {
       const int64_t* p = params_host + i * 4;
-      int r0[2], r1[2];
+      int r0[SCN_MAX_GROUPS], r1[SCN_MAX_GROUPS];
       const int ng = bn_groups(geom_host, o[OP_LSRC], src.rows, r0, r1);
       for (int g = 0; g < ng && !rc; ++g)
         rc = mopa_bnrelu_rows_fwd(src.p + (int64_t)r0[g] * src.ld, src.ld, dst.p + (int64_t)r0[g] * dst.ld, dst.ld, r1[g] - r0[g], src.C,
@@ -262,7 +273,7 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
     const View dy = view_of(gbufs_host, geom_host, pl[PL_DYBUF], pl[PL_DYCOL], pl[PL_DYC], o[OP_LDST]);
     const View dx = view_of(gbufs_host, geom_host, pl[PL_DXBUF], pl[PL_DXCOL], pl[PL_DXC], o[OP_LSRC]);
     if (pl[PL_KIND] == K_BN) {
-      int r0[2], r1[2];
+      int r0[SCN_MAX_GROUPS], r1[SCN_MAX_GROUPS];
       const int ng = bn_groups(geom_host, o[OP_LSRC], x.rows, r0, r1);
       for (int k = 0; k < ng && !rc; ++k)   // (the parameter gradients of the groups add up)
         rc = mopa_bnrelu_rows_bwd(dy.p + (int64_t)r0[k] * dy.ld, dy.ld, x.p + (int64_t)r0[k] * x.ld, x.ld, dx.p + (int64_t)r0[k] * dx.ld, dx.ld,

@@ -215,10 +215,11 @@ class Net3DSeg(_CachedParams, nn.Module):
         dev = _require_cuda(self)
         locs, feats = data_batch["x"][0], data_batch["x"][1]
         geom = data_batch.get("geometry_3d") if isinstance(data_batch, dict) else None
-        # "bn_group_points": N0 (extension, like Net2DSeg's "bn_groups"): the first N0 points are the scans of a first batch (source),
-        # the rest those of a second (target; its scan indices behind the first's) that the reference sends through the network in
-        # two calls (train_xmuda_mopa.py:343,427): BatchNorm statistics, running updates and gradients per group in that order,
-        # everything else on the joint batch (sparse3d.Geometry3D.split).  A geometry passed in must have been built the same way.
+        # "bn_group_points": N0 or [N0, N1] (extension, like Net2DSeg's "bn_groups"): the first N0 points are the scans of a first batch
+        # (source), the following ones those of a second (target; its scan indices behind the first's) and, with N1, a third (the
+        # VGI batch) that the reference sends through the network in separate calls (train_xmuda_mopa.py:343,427,558): BatchNorm
+        # statistics, running updates and gradients per group in that order, everything else on the joint batch
+        # (sparse3d.Geometry3D.split).  A geometry passed in must have been built the same way.
         gp = data_batch.get("bn_group_points") if isinstance(data_batch, dict) else None
         if geom is None:
             with torch.cuda.device(dev):

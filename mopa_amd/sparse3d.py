@@ -47,12 +47,12 @@ class Geometry3D:
     sized from a bound: no second round trip).
     """
 
-    def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None, group_points: int | None = None):
-        """group_points (extension): the first `group_points` points belong to a first group of scans (e.g. the source batch, the
-        rest being the target batch, with its scan indices behind the source's).  Rows are numbered in first-seen order and a voxel
-        belongs to one scan, so the first group's rows come first at every level: `self.split[l]` = their number.  BatchNorm then
-        runs per group on row ranges (statistics, running updates, gradients: as two calls of the network would), everything else
-        sees one batch."""
+    def __init__(self, coords: torch.Tensor, num_levels: int = 7, full_scale: int = 4096, device=None, group_points=None):
+        """group_points (extension): an int N0 -- the first N0 points belong to a first group of scans (e.g. the source batch, the
+        rest being the target batch, with its scan indices behind the source's) -- or up to two increasing point counts [N0, N1]
+        (three groups).  Rows are numbered in first-seen order and a voxel belongs to one scan, so the groups' rows are consecutive
+        ranges at every level: `self.split[l]` = the boundaries.  BatchNorm then runs per group on row ranges (statistics, running
+        updates, gradients: as separate calls of the network would), everything else sees one batch."""
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise RuntimeError(f"coords must be (N,4) [x,y,z,batch], got {tuple(coords.shape)}")
         device = torch.device(device if device is not None else "cuda")
@@ -73,7 +73,10 @@ class Geometry3D:
         tk = [torch.empty(cap, **i64) for _ in range(L)]
         tv = [torch.empty(cap, **i32) for _ in range(L)]
         item_row = [torch.empty(N, **i32) for _ in range(L)]  # [0]: point->row0 ; [l>0]: parent of level l-1 rows
-        meta = torch.zeros(2 * L + 1, **i32)                   # counts[0..L-1], status, first-group rows [0..L-1] (group_points)
+        bounds = [] if group_points is None else ([int(group_points)] if np.isscalar(group_points) else [int(b) for b in group_points])
+        if len(bounds) > 2 or any(not 0 < b < N for b in bounds) or any(a >= b for a, b in zip(bounds, bounds[1:])):
+            raise ValueError(f"group_points={group_points}: need at most two increasing point counts inside (0, {N})")
+        meta = torch.zeros((1 + len(bounds)) * L + 1, **i32)   # counts[0..L-1], status, then per boundary: rows in front of it [0..L-1]
         wsb = query("mopa_voxel_hash_workspace_bytes", N)
         ws = _ws(wsb, device)
         st = stream()
@@ -82,18 +85,18 @@ class Geometry3D:
         for l in range(L - 1):
             call("mopa_coarsen_build", ptr(keys[l]), N, ptr(meta, l), ptr(tk[l + 1]), ptr(tv[l + 1]), cap,
                  ptr(item_row[l + 1]), ptr(keys[l + 1]), ptr(meta, l + 1), ptr(ws), ws.numel(), st)
-        if group_points is not None:
-            if not 0 < group_points < N:
-                raise ValueError(f"group_points={group_points} must split the {N} points into two non-empty groups")
-            call("mopa_group_split", ptr(item_row[0]), None, int(group_points), N, ptr(meta, L + 1), st)
-            for l in range(L - 1):   # parents of the first group's rows at level l
-                call("mopa_group_split", ptr(item_row[l + 1]), ptr(meta, L + 1 + l), 0, N, ptr(meta, L + 2 + l), st)
+        for k, b in enumerate(bounds):
+            base = L + 1 + k * L
+            call("mopa_group_split", ptr(item_row[0]), None, b, N, ptr(meta, base), st)
+            for l in range(L - 1):   # parents of the rows in front of the boundary at level l
+                call("mopa_group_split", ptr(item_row[l + 1]), ptr(meta, base + l), 0, N, ptr(meta, base + l + 1), st)
         m = meta.cpu().tolist()  # the one host sync of the geometry build
         if m[L] != 0:
             raise RuntimeError("voxel coordinates out of range: need 0 <= x,y,z < 4096 and batch >= 0")
         self.num_active = m[:L]
         A = self.num_active
-        self.split = m[L + 1:2 * L + 1] if group_points is not None else None
+        # split[l]: the row boundaries between the groups at level l ([] for every level = None)
+        self.split = [[m[L + 1 + k * L + l] for k in range(len(bounds))] for l in range(L)] if bounds else None
         self.point_row = item_row[0]
         self.row_keys = [keys[l][:A[l]] for l in range(L)]
         self.parent = [item_row[l + 1][:A[l]] for l in range(L - 1)]
@@ -147,7 +150,7 @@ class Geometry3D:
         d = getattr(self, "_desc", None)
         if d is None:
             L = self.num_levels
-            d = np.zeros(8 + 8 * (L + 1), np.int64)
+            d = np.zeros(8 + 8 * (L + 1) + 8, np.int64)   # header, L + 1 level rows, tail (second group boundary per level)
             gs0, go, gi, gout = self._rb[self.nbr27[0].data_ptr()]
             d[0:8] = (L, self.n_points, self.point_row.data_ptr(), self.row_start.data_ptr(), self.row_points.data_ptr(),
                       go.data_ptr(), gi.data_ptr(), gout.data_ptr())
@@ -157,7 +160,10 @@ class Geometry3D:
                 if l < L - 1:
                     r[3], r[4] = self.ch[l].data_ptr(), self._rb[self.ch[l].data_ptr()][0].data_ptr()
                     r[5], r[6] = self.up[l].data_ptr(), self._rb[self.up[l].data_ptr()][0].data_ptr()
-                r[7] = self.split[l] if self.split is not None else 0
+                if self.split is not None:
+                    r[7] = self.split[l][0]
+                    if len(self.split[l]) > 1:
+                        d[8 + 8 * (L + 1) + l] = self.split[l][1]
             self._desc = d
         return d
 
@@ -348,10 +354,16 @@ def spconv_bwd_weight(nbr: torch.Tensor, x: View, dout: View, dw: torch.Tensor, 
 
 def bn_row_groups(geom, level: int):
     """Row ranges BatchNorm treats as separate batches at `level`: [(0, A)] or, for a geometry built with group_points,
-    [(0, split), (split, A)] (same rule as csrc/scn_exec.hip::bn_groups)."""
+    [(0, s1), (s1, A)] / [(0, s1), (s1, s2), (s2, A)] (same rule as csrc/scn_exec.hip::bn_groups)."""
     A = geom.num_active[level]
-    s = geom.split[level] if geom.split is not None else 0
-    return [(0, A)] if s <= 0 or s >= A else [(0, s), (s, A)]
+    sp = list(geom.split[level]) if geom.split is not None else []
+    s1 = sp[0] if sp else 0
+    s2 = sp[1] if len(sp) > 1 else 0
+    if s1 <= 0 or s1 >= A:
+        return [(0, A)]
+    if s2 <= s1 or s2 >= A:
+        return [(0, s1), (s1, A)]
+    return [(0, s1), (s1, s2), (s2, A)]
 
 
 def rows_of(v: View, r0: int, r1: int) -> View:
@@ -654,7 +666,7 @@ def _native_forward(ctx, spec, geom, training, feats, flat, P, prog):
     nt = nat.nt
     A, m, C, N = geom.num_active, spec.m, spec.num_classes, geom.n_points
     gd = geom.desc()
-    bufs, arena, stats_ptr = nat.buffers(A, dev, True, 2 if geom.split is not None else 1)
+    bufs, arena, stats_ptr = nat.buffers(A, dev, True, 1 + len(geom.split[0]) if geom.split is not None else 1)
     out_feats = torch.empty(N, m, dtype=torch.float32, device=dev)
     l1 = torch.empty(N, C, dtype=torch.float32, device=dev)
     l2 = torch.empty(N, C if spec.dual_head else 0, dtype=torch.float32, device=dev)

@@ -483,8 +483,16 @@ def test_two_groups_of_scans_in_one_3d_pass_equal_two_calls(native, monkeypatch)
     fb = torch.from_numpy(rng.random((len(cb), 1), dtype=np.float32) + 0.5).cuda()
     g = Geometry3D(torch.from_numpy(both), 7, 4096, "cuda", group_points=len(ca))
     ga = Geometry3D(torch.from_numpy(ca), 7, 4096, "cuda")
-    assert g.split == ga.num_active and all(0 < s < a for s, a in zip(g.split, g.num_active))
+    assert [s[0] for s in g.split] == ga.num_active and all(0 < s[0] < a for s, a in zip(g.split, g.num_active))
     assert Geometry3D(torch.from_numpy(both), 7, 4096, "cuda").split is None
+    # three groups: the boundaries are the row counts of the first and of the first two batches
+    cc = _cloud(23, n=3000, size=130, batch=1)
+    cc[:, 3] += 5
+    three = np.concatenate([both, cc])
+    g3 = Geometry3D(torch.from_numpy(three), 7, 4096, "cuda", group_points=[len(ca), len(both)])
+    assert [s[0] for s in g3.split] == ga.num_active and [s[1] for s in g3.split] == g.num_active
+    with pytest.raises(ValueError):
+        Geometry3D(torch.from_numpy(three), 7, 4096, "cuda", group_points=[len(both), len(ca)])
 
     def gout(shape, seed):
         return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape, dtype=np.float32)).cuda()
@@ -518,3 +526,51 @@ def test_two_groups_of_scans_in_one_3d_pass_equal_two_calls(native, monkeypatch)
     print("two calls vs one grouped pass: worst parameter-gradient difference / tensor max", worst)
     with pytest.raises(ValueError):
         one({"x": [torch.from_numpy(both), torch.cat([fa, fb])], "bn_group_points": len(ca), "geometry_3d": Geometry3D(torch.from_numpy(both), 7, 4096, "cuda")})
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_three_groups_of_scans_in_one_3d_pass_equal_three_calls(native, monkeypatch):
+    """bn_group_points = [N0, N1]: source, target and the VGI batch of a MoPA iteration (train_xmuda_mopa.py:343,427,558) as one
+    sparse tensor: same checks as for two groups, against three calls in that order."""
+    from mopa_amd import sparse3d as s3
+    monkeypatch.setattr(s3, "NATIVE", native)
+    clouds = []
+    for k, (seed, n, nb) in enumerate(((31, 6000, 2), (32, 5000, 2), (33, 4000, 2))):
+        c = _cloud(seed, n=n, size=120, batch=nb)
+        clouds.append(c[np.argsort(c[:, 3], kind="stable")])
+    rng = np.random.Generator(np.random.PCG64(9))
+    feats = [torch.from_numpy(rng.random((len(c), 1), dtype=np.float32) + 0.5).cuda() for c in clouds]
+    merged = []
+    for k, c in enumerate(clouds):
+        c = c.copy()
+        c[:, 3] += 2 * k
+        merged.append(c)
+    merged = np.concatenate(merged)
+    cuts = [len(clouds[0]), len(clouds[0]) + len(clouds[1])]
+
+    def gout(shape, seed):
+        return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape, dtype=np.float32)).cuda()
+
+    sep = _build_3d(7).train()
+    outs = []
+    for k, (c, f) in enumerate(zip(clouds, feats)):
+        o = sep({"x": [torch.from_numpy(c), f]})
+        sum((o[n] * gout(tuple(o[n].shape), 100 * k + i)).sum() for i, n in enumerate(sorted(o))).backward()
+        outs.append({n: v.detach().clone() for n, v in o.items()})
+    one = _build_3d(7).train()
+    o = one({"x": [torch.from_numpy(merged), torch.cat(feats)], "bn_group_points": cuts})
+    sls = (slice(0, cuts[0]), slice(cuts[0], cuts[1]), slice(cuts[1], None))
+    loss = 0
+    for k, sl in enumerate(sls):
+        loss = loss + sum((o[n][sl] * gout(tuple(o[n][sl].shape), 100 * k + i)).sum() for i, n in enumerate(sorted(o)))
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, sl in enumerate(sls):
+        for n in outs[k]:
+            ref, got = outs[k][n], o[n][sl].detach()
+            assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, n)
+    sa, sb = sep.state_dict(), one.state_dict()
+    for n in sa:
+        assert float((sa[n] - sb[n]).abs().max()) <= 1e-5 * (float(sa[n].abs().max()) + 1e-6), n
+    for (n, p), (_, q) in zip(sep.named_parameters(), one.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-4 * (float(p.grad.abs().max()) + 1e-20), n
