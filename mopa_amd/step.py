@@ -130,14 +130,14 @@ class DualStream:
                 t.record_stream(main)
         return preds_2d, preds_3d
 
-    def geometry_ahead(self, model_3d, locs, inputs_ready):
+    def geometry_ahead(self, model_3d, locs, inputs_ready, group_points=None):
         """Voxel geometry of `locs` for a 3D pass that will run on the CURRENT stream, built on the side stream behind
         `inputs_ready` only: its two host syncs then wait for the (short) side-stream queue instead of everything queued on
         the current stream.  Pass the result as ``batch["geometry_3d"]``."""
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.side):
             self.side.wait_event(inputs_ready)
-            geom = model_3d.net_3d.geometry(locs)
+            geom = model_3d.net_3d.geometry(locs, group_points=group_points)   # (group_points: Net3DSeg's "bn_group_points")
             built = torch.cuda.Event()
             built.record()
         cur.wait_event(built)
