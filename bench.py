@@ -935,8 +935,9 @@ def main():
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
         fam_path = os.path.join(ROOT, "profiles", "r3_rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
-        # (the joint step runs the 3D branch on the same scans as `--workload 3d`: its sparse-conv launches move the same bytes)
-        t3_key = {"3d": "3d", "joint": "3d", "kitti": "kitti", "mopa": "mopa"}.get(wl_key)
+        # (every workload has its own PMC passes: the paired steps run both domains' scans as one sparse tensor -- other launches than
+        #  `--workload 3d`'s)
+        t3_key = wl_key
         t3 = os.path.join(ROOT, "profiles", f"r3_{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
         if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
