@@ -595,15 +595,10 @@ def main():
     vgi_stream = torch.cuda.Stream(device=dev) if (mopa and os.environ.get("MOPA_BENCH_VGI_STREAM", "1") != "0") else None
 
     def pair_batch_of(bs, bt):
+        from mopa_amd.step import merge_domains_2d, merge_domains_3d
         Bs = bs["img"].shape[0]
-        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-        p2 = {"img": torch.cat([bs["img"], bt["img"]]), "point_pix_2d": torch.cat([bs["pix"], bt["pix"] + Bs * Hp * Wp]),
-              "img_indices": None, "bn_groups": 2}
-        p3 = None
-        if pair_3d:
-            lt = bt["locs"].clone()
-            lt[:, 3] += Bs   # the target's scans behind the source's
-            p3 = {"x": [torch.cat([bs["locs"], lt]), torch.cat([bs["feats"], bt["feats"]])], "bn_group_points": int(bs["locs"].shape[0])}
+        p2 = merge_domains_2d(bs["img"], bt["img"], bs["pix"], bt["pix"])
+        p3 = merge_domains_3d([(bs["locs"], bs["feats"]), (bt["locs"], bt["feats"])], [Bs, Bs]) if pair_3d else None
         return p2, p3
 
     pair2d = pair_batch_of(batches[0], batches[1]) if pair_mode else None
@@ -654,10 +649,11 @@ def main():
                 p3 = p2d[1]
                 locs3, feats3, cuts = p3["x"][0], p3["x"][1], p3["bn_group_points"]
                 if vin is not None and pair_3d_three:   # MoPA: the VGI batch as a third group of the same pass (scan indices behind)
-                    lv = vin[0]["x"][0].clone()
-                    lv[:, 3] += 2 * bs["img"].shape[0]
-                    cuts = [cuts, int(locs3.shape[0])]
-                    locs3, feats3 = torch.cat([locs3, lv]), torch.cat([feats3, vin[0]["x"][1]])
+                    from mopa_amd.step import merge_domains_3d
+                    nbs = bs["img"].shape[0]
+                    m3 = merge_domains_3d([(bs["locs"], bs["feats"]), (bt["locs"], bt["feats"]), (vin[0]["x"][0], vin[0]["x"][1])],
+                                          [nbs, nbs, nbs])
+                    (locs3, feats3), cuts = m3["x"], m3["bn_group_points"]
                 o3m = model3d({"x": [locs3, feats3], "bn_group_points": cuts,
                                "geometry_3d": model3d.net_3d.geometry(locs3, group_points=cuts)})
                 n3 = p3["bn_group_points"]

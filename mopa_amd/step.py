@@ -33,6 +33,39 @@ def global_mean_weight(n_local: int, group=None) -> float:
     return float(n_local) * dist.get_world_size(group) / total if total > 0 else 1.0
 
 
+def merge_domains_2d(img_s, img_t, pix_s, pix_t):
+    """The source and the target batch of one iteration as ONE `Net2DSeg` batch (`bn_groups = 2`: BatchNorm statistics, running
+    updates and dropout masks per domain in the reference's call order, train_xmuda_mopa.py:342,426; every convolution on both).
+    img_*: (B,3,H,W) of equal size; pix_*: `Net2DSeg.pack_indices` of each domain's img_indices (int32 rows of the /16-padded
+    feature map).  -> data_batch for `model_2d(...)`; its outputs hold the source's points / images first:
+    `out["seg_logit"][:pix_s.numel()]`, `out["seg_logit_all"][:img_s.shape[0]]`."""
+    if img_s.shape[1:] != img_t.shape[1:] or img_s.shape[0] != img_t.shape[0]:
+        raise ValueError(f"the two domains need equal batch and image sizes, got {tuple(img_s.shape)} and {tuple(img_t.shape)}")
+    B, _, H, W = img_s.shape
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    return {"img": torch.cat([img_s, img_t]), "point_pix_2d": torch.cat([pix_s, pix_t + B * Hp * Wp]), "img_indices": None,
+            "bn_groups": 2}
+
+
+def merge_domains_3d(batches, scans_per_batch):
+    """Two or three batches of scans (source, target[, the VGI batch]) as ONE `Net3DSeg` batch: `batches` = [(locs (N_k,4) int64
+    [x,y,z,scan], feats (N_k,C)), ...] with scan indices 0 .. scans_per_batch[k]-1 each; the k-th batch's scan indices are moved
+    behind the earlier ones' and `bn_group_points` marks the boundaries (BatchNorm per batch on row ranges, in order).
+    -> data_batch for `model_3d(...)`; outputs are per point in the order given (`out["seg_logit"][:N_0]`, `[N_0:N_0+N_1]`, ...)."""
+    if not 2 <= len(batches) <= 3 or len(scans_per_batch) != len(batches):
+        raise ValueError("merge_domains_3d takes two or three batches and one scan count per batch")
+    locs, feats, cuts, first = [], [], [], 0
+    for (lc, ft), nb in zip(batches, scans_per_batch):
+        if first:
+            lc = lc.clone()
+            lc[:, 3] += first
+        locs.append(lc)
+        feats.append(ft)
+        first += int(nb)
+        cuts.append(int(lc.shape[0]) + (cuts[-1] if cuts else 0))
+    return {"x": [torch.cat(locs), torch.cat(feats)], "bn_group_points": cuts[0] if len(cuts) == 2 else cuts[:-1]}
+
+
 def freeze_host_heap() -> int:
     """Call once after the models, optimizers and the first iterations exist (the trainer: after building everything at
     ``train_xmuda_mopa.py:135-170``, before the iteration loop).  ``import torch`` and the model graph leave ~2 M tracked

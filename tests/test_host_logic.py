@@ -205,3 +205,35 @@ def test_paired_batch_point_rows_equal_the_concatenated_calls():
     both = Net2DSeg.pack_indices(idx_s + idx_t, H, W, "cpu")
     assert torch.equal(both, torch.cat([ps, pt + Bs * Hp * Wp]))
     assert both.dtype == torch.int32 and int(both.max()) < (Bs + Bt) * Hp * Wp
+
+
+def test_merge_domains_helpers():
+    """mopa_amd.step.merge_domains_2d / _3d build the one-pass batches of bench.py's paired step: point rows of the target shifted
+    behind the source's images, scan indices of later batches behind the earlier ones', group boundaries in points."""
+    from mopa_amd.models.xmuda_arch import Net2DSeg
+    from mopa_amd.step import merge_domains_2d, merge_domains_3d
+    rng = np.random.Generator(np.random.PCG64(4))
+    H, W, B = 30, 45, 2
+    idx_s = [np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], 1) for n in (7, 3)]
+    idx_t = [np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], 1) for n in (5, 9)]
+    img_s, img_t = torch.zeros(B, 3, H, W), torch.ones(B, 3, H, W)
+    m2 = merge_domains_2d(img_s, img_t, Net2DSeg.pack_indices(idx_s, H, W, "cpu"), Net2DSeg.pack_indices(idx_t, H, W, "cpu"))
+    assert m2["bn_groups"] == 2 and m2["img"].shape[0] == 2 * B and float(m2["img"][B:].min()) == 1.0
+    assert torch.equal(m2["point_pix_2d"], Net2DSeg.pack_indices(idx_s + idx_t, H, W, "cpu"))
+    with pytest.raises(ValueError):
+        merge_domains_2d(img_s, img_t[:1], m2["point_pix_2d"], m2["point_pix_2d"])
+
+    def cloud(n, nb):
+        c = torch.from_numpy(rng.integers(0, 50, (n, 4)))
+        c[:, 3] = torch.sort(torch.from_numpy(rng.integers(0, nb, n)))[0]
+        return c, torch.rand(n, 1)
+
+    a, b, c = cloud(11, 2), cloud(7, 2), cloud(5, 3)
+    m = merge_domains_3d([a, b], [2, 2])
+    assert m["bn_group_points"] == 11 and m["x"][0].shape == (18, 4) and m["x"][1].shape == (18, 1)
+    assert torch.equal(m["x"][0][:11], a[0]) and torch.equal(m["x"][0][11:, :3], b[0][:, :3]) and torch.equal(m["x"][0][11:, 3], b[0][:, 3] + 2)
+    assert torch.equal(b[0][:, 3], torch.sort(b[0][:, 3])[0]) and int(b[0][:, 3].max()) <= 1   # the inputs are not modified
+    m3 = merge_domains_3d([a, b, c], [2, 2, 3])
+    assert m3["bn_group_points"] == [11, 18] and int(m3["x"][0][18:, 3].min()) >= 4
+    with pytest.raises(ValueError):
+        merge_domains_3d([a], [2])
