@@ -36,7 +36,12 @@ enum { GL_A = 0, GL_NBR, GL_NBR_GS, GL_CH, GL_CH_GS, GL_UP, GL_UP_GS, GL_SPLIT }
 // io_host     int64: see IO_* below (doubles travel as their bit patterns)
 enum { IO_TRAINING = 0, IO_EPOCH, IO_FEATS, IO_CIN, IO_X0BUF, IO_X0COL, IO_OUTBUF, IO_OUTCOL, IO_M, IO_NCLS, IO_W1, IO_B1, IO_W2, IO_B2,
        IO_OFEATS, IO_L1, IO_L2, IO_STATS, IO_MOMENTUM, IO_EPS, IO_LEAK, IO_DFEATS_OUT, IO_DL1, IO_DL2, IO_DFEATS_IN, IO_DW1, IO_DB1,
-       IO_DW2, IO_DB2, IO_HEADS_ACC, IO_N };
+       IO_DW2, IO_DB2, IO_HEADS_ACC,
+       // backward only, all optional (0 = the weight gradients run on `stream` like everything else): a second stream for the weight
+       // gradients (they depend on a layer's input and output gradient only, nothing in the pass waits for them), its own scratch,
+       // and two hipEvent_t the caller created: "output gradient ready" (recorded on `stream` per convolution) and "weight gradients
+       // done" (recorded on the second stream at the end; `stream` waits for it before the call returns its work to the caller)
+       IO_WSTREAM, IO_WS2, IO_WS2_BYTES, IO_EV_READY, IO_EV_DONE, IO_N };
 // plan_host   int32 [n_steps][PL_W] (backward): step kind, op index, where the output gradient is read, where the input gradient goes
 enum { PL_KIND = 0, PL_OP, PL_DYBUF, PL_DYCOL, PL_DYC, PL_DXBUF, PL_DXCOL, PL_DXC, PL_ACC, PL_SKIPDX, PL_W };
 // grads_host  int64 [n_ops][3]: gradient destinations (BatchNorm: dgamma, dbeta | convolution: dweight), accumulate flag
@@ -253,6 +258,11 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
   const float* stats = reinterpret_cast<const float*>(io[IO_STATS]);
   const int NG = n_bn_groups(geom_host);
   const int M = (int)io[IO_M], NC = (int)io[IO_NCLS];
+  hipStream_t wst = (hipStream_t)io[IO_WSTREAM];
+  hipEvent_t ev_ready = (hipEvent_t)io[IO_EV_READY], ev_done = (hipEvent_t)io[IO_EV_DONE];
+  void* ws2 = (void*)io[IO_WS2];
+  const size_t ws2_bytes = (size_t)io[IO_WS2_BYTES];
+  const bool side = wst && wst != st && ev_ready && ev_done && ws2;
   int rc = refresh_forms(prog_host, n_ops, params_host, forms_host, geom_host, bufs_host, gbufs_host, plan_host, n_steps, io[IO_EPOCH], 1, st);
   if (rc) return rc;
   {
@@ -279,21 +289,28 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
         rc = mopa_bnrelu_rows_bwd(dy.p + (int64_t)r0[k] * dy.ld, dy.ld, x.p + (int64_t)r0[k] * x.ld, x.ld, dx.p + (int64_t)r0[k] * dx.ld, dx.ld,
                                   r1[k] - r0[k], x.C, stats + (int64_t)NG * o[OP_ABUF] + k * 4 * x.C, leak, training, (float*)g[0],
                                   (float*)g[1], (int)g[2] || k > 0, pl[PL_ACC], ws, ws_bytes, st);
-      if (rc) return rc;
+      if (rc) break;
       continue;
     }
     const int ck = o[OP_CKIND], l = o[OP_LSRC] < o[OP_LDST] ? o[OP_LSRC] : o[OP_LDST];
     const Table t = table_of(geom_host, ck, l, false);
-    rc = mopa_spconv_bwd_weight(t.nbr, t.K, t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, (float*)g[0], (int)g[2], ws, ws_bytes, st);
-    if (rc) return rc;
+    if (side) {   // dy is complete at this point of `stream`; nothing later in the pass writes it or the layer's input again
+      if (hipEventRecord(ev_ready, st) != hipSuccess || hipStreamWaitEvent(wst, ev_ready, 0) != hipSuccess) return MOPA_ERR_LAUNCH;
+      rc = mopa_spconv_bwd_weight(t.nbr, t.K, t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, (float*)g[0], (int)g[2], ws2, ws2_bytes, wst);
+    } else {
+      rc = mopa_spconv_bwd_weight(t.nbr, t.K, t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, (float*)g[0], (int)g[2], ws, ws_bytes, st);
+    }
+    if (rc) break;
     if (pl[PL_SKIPDX]) continue;
     // backward-data: the same kernel on the reversed rules with the per-offset transposed weight (submanifold: the table is its own
     // reverse with mirrored offsets; stride-2 convolution <-> deconvolution swap tables)
     const Table tr = table_of(geom_host, ck, l, true);
     const int ntw = wanted_ntw(tr, dy.C, dx.C, dy.ld);
     rc = run_conv(tr, dy, form_ptr(params_host, forms_host, op, 1, ntw), ntw, dx, ck == C_SUBM ? 1 : 0, geom_host, ws, ws_bytes, st);
-    if (rc) return rc;
+    if (rc) break;
   }
+  if (side && (hipEventRecord(ev_done, wst) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess)) return MOPA_ERR_LAUNCH;
+  if (rc) return rc;
   if (io[IO_DFEATS_IN]) {
     const View dx0 = view_of(gbufs_host, geom_host, (int)io[IO_X0BUF], (int)io[IO_X0COL], (int)io[IO_CIN], 0);
     rc = mopa_input_layer_bwd(dx0.p, dx0.ld, (const int32_t*)geom_host[G_PROW], (const int32_t*)geom_host[G_RSTART], (int)geom_host[G_NPTS],

@@ -592,7 +592,30 @@ def program_for(spec) -> Program:
 NATIVE = os.environ.get("MOPA_SCN_NATIVE", "1") != "0"   # A/B switch: the Python walk of the layer program (round 1-2)
 _IO = dict(TRAINING=0, EPOCH=1, FEATS=2, CIN=3, X0BUF=4, X0COL=5, OUTBUF=6, OUTCOL=7, M=8, NCLS=9, W1=10, B1=11, W2=12, B2=13, OFEATS=14,
            L1=15, L2=16, STATS=17, MOMENTUM=18, EPS=19, LEAK=20, DFEATS_OUT=21, DL1=22, DL2=23, DFEATS_IN=24, DW1=25, DB1=26, DW2=27,
-           DB2=28, HEADS_ACC=29, N=30)
+           DB2=28, HEADS_ACC=29, WSTREAM=30, WS2=31, WS2_BYTES=32, EV_READY=33, EV_DONE=34, N=35)
+
+# The sparse weight gradients of the native backward pass on a second stream (csrc/scn_exec.hip, IO_WSTREAM): they need a layer's
+# input and output gradient only and nothing in the pass waits for them; the backward-data / BatchNorm chain they ran in front of
+# is a sequence of short launches that leaves most of the chip idle.  MOPA_SCN_WGRAD_STREAM=0: everything on the caller's stream.
+SCN_WGRAD_STREAM = os.environ.get("MOPA_SCN_WGRAD_STREAM", "1") != "0"
+_wgrad3 = {}   # (device index, consumer stream) -> (torch stream, "ready" event, "done" event)
+
+
+def _wgrad3_side(dev):
+    if not SCN_WGRAD_STREAM:
+        return None
+    from . import dense2d   # (same rule as the 2D branch: not when several ranks may share this device)
+    if os.environ.get("MOPA_SCN_WGRAD_STREAM") != "1" and dense2d._shared_device_group():
+        return None
+    key = (torch.device(dev).index, stream())
+    ent = _wgrad3.get(key)
+    if ent is None:
+        st = torch.cuda.Stream(device=dev)
+        evs = (torch.cuda.Event(), torch.cuda.Event())
+        for e in evs:
+            e.record(st)    # (creates the hipEvent_t: torch makes it at the first record)
+        ent = _wgrad3[key] = (st, evs[0], evs[1])
+    return ent
 
 
 def _f64_bits(x: float) -> int:
@@ -737,6 +760,13 @@ def _native_backward(ctx, dfeats, dl1, dl2):
         plan = plan.copy()
         plan[nt["stem_step"], 9] = 1      # no gradient w.r.t. the input features: the stem's backward-data is skipped
     ws = _ws(wsb, dev)
+    side = _wgrad3_side(dev)
+    if side is not None:
+        wst, ev_ready, ev_done = side
+        with torch.cuda.stream(wst):
+            ws2 = _ws(wsb, dev)    # the second stream's own scratch (keyed by stream)
+        io[_IO["WSTREAM"]], io[_IO["WS2"]], io[_IO["WS2_BYTES"]] = wst.cuda_stream, ws2.data_ptr(), ws2.numel()
+        io[_IO["EV_READY"]], io[_IO["EV_DONE"]] = ev_ready.cuda_event, ev_done.cuda_event
     call("mopa_scn_backward", prog_t.ctypes.data, len(prog_t), plan.ctypes.data, len(plan), nat.params.ctypes.data, nat.forms.ctypes.data,
          grads.ctypes.data, geom.desc().ctypes.data, bufs.ctypes.data, gbufs.ctypes.data, io.ctypes.data, ptr(ws), ws.numel(), stream())
     return (None, None, None, dfeat_in) + sink.returned()
