@@ -596,8 +596,11 @@ _IO = dict(TRAINING=0, EPOCH=1, FEATS=2, CIN=3, X0BUF=4, X0COL=5, OUTBUF=6, OUTC
 
 # The sparse weight gradients of the native backward pass on a second stream (csrc/scn_exec.hip, IO_WSTREAM): they need a layer's
 # input and output gradient only and nothing in the pass waits for them; the backward-data / BatchNorm chain they ran in front of
-# is a sequence of short launches that leaves most of the chip idle.  MOPA_SCN_WGRAD_STREAM=0: everything on the caller's stream.
-SCN_WGRAD_STREAM = os.environ.get("MOPA_SCN_WGRAD_STREAM", "1") != "0"
+# is a sequence of short launches that leaves most of the chip idle.  MOPA_SCN_WGRAD_STREAM=1 switches it on: 3D-only training
+# 1423 -> 1495 scans/s, bit-identical results, neutral inside the joint steps (the chip is full there).  OFF by default because
+# every kernel of the pass then shares the chip with a weight-gradient kernel: the sparse-conv family's launches take 51 instead
+# of 45 us each (rocprofv3), i.e. the per-kernel roofline figure this repository tracks gets WORSE while the step gets faster.
+SCN_WGRAD_STREAM = os.environ.get("MOPA_SCN_WGRAD_STREAM", "0") == "1"
 _wgrad3 = {}   # (device index, consumer stream) -> (torch stream, "ready" event, "done" event)
 
 
@@ -605,7 +608,7 @@ def _wgrad3_side(dev):
     if not SCN_WGRAD_STREAM:
         return None
     from . import dense2d   # (same rule as the 2D branch: not when several ranks may share this device)
-    if os.environ.get("MOPA_SCN_WGRAD_STREAM") != "1" and dense2d._shared_device_group():
+    if dense2d._shared_device_group() and os.environ.get("MOPA_SCN_WGRAD_STREAM_SHARED") != "1":
         return None
     key = (torch.device(dev).index, stream())
     ent = _wgrad3.get(key)

@@ -311,13 +311,16 @@ def test_net3dseg_equals_dense_network():
                                    (0.9 * sd0[name + ".running_var"].double() + 0.1 * var * n / max(n - 1, 1)).numpy(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("residual,needs_dfeats", [(False, False), (False, True), (True, True)])
-def test_native_executor_is_bit_identical_to_the_python_walk(residual, needs_dfeats):
+@pytest.mark.parametrize("residual,needs_dfeats,wstream", [(False, False, False), (False, True, False), (True, True, False),
+                                                          (False, False, True), (True, True, True)])
+def test_native_executor_is_bit_identical_to_the_python_walk(residual, needs_dfeats, wstream, monkeypatch):
     """One C-ABI call per pass (csrc/scn_exec.hip) runs the same kernels in the same order as the per-layer walk from Python
     (kept for synchronised BatchNorm, MOPA_SCN_NATIVE=0): outputs, every parameter gradient, the input gradient and the running
-    statistics are equal bit for bit -- two training steps, so the second pass re-uses / refreshes the derived weight forms."""
+    statistics are equal bit for bit -- two training steps, so the second pass re-uses / refreshes the derived weight forms.
+    wstream: the executor's weight gradients on a second stream (MOPA_SCN_WGRAD_STREAM=1; the walk stays on one stream)."""
     from mopa_amd import sparse3d as s3
     from mopa_amd.optim import FlatAdam
+    monkeypatch.setattr(s3, "SCN_WGRAD_STREAM", wstream)
     c = _cloud(17, n=9000, size=150)
     rng = np.random.Generator(np.random.PCG64(6))
     feats = torch.from_numpy(rng.random((c.shape[0], 1), dtype=np.float32) + 0.5)
