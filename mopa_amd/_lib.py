@@ -166,10 +166,14 @@ def ptr(t, col: int = 0):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
-    """hipStream_t of torch's current stream on the current device (fast path: no Stream object, ~0.3 us)."""
+    """hipStream_t of torch's current stream on the current device (fast path: no Stream object, no lazy-init check: ~0.3 us;
+    a 2D forward + backward asks ~740 times)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_raw_device() if _raw_device is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

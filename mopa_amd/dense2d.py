@@ -194,7 +194,7 @@ def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
     128->64 152x240, 2.0x at 128^2 76x120, 2.7x at 256^2 38x60, 3.5x at 512^2 19x30; F(2x2) -- 2.25x fewer multiplies, V / M =
     4x the activations, ~2e-6 -- 0.8x / 0.9x / 1.3x / 1.8x / 2.4x on the same shapes: it remains for maps below 8 pixels
     (MOPA_WINOGRAD_F4=0 forces it where it is eligible)."""
-    if not (k == 3 and s == 1 and p == 1 and cin % 16 == 0 and cout % 64 == 0 and os.environ.get("MOPA_WINOGRAD", "1") != "0"):
+    if not (WINOGRAD and k == 3 and s == 1 and p == 1 and cin % 16 == 0 and cout % 64 == 0):
         return 0
     if (role in F4_ROLES and min(H, W) >= 8 and B * H * W < F4_MAX_PIXELS
             and (role != "fwd" or B * H * W >= F4_FWD_MIN_PIXELS)):
@@ -206,6 +206,9 @@ def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
 #  transformed operands V / M of one layer are 2.25 x its activations, and the fused kernel addresses one transform point with 32-bit
 #  byte offsets: mopa_wino4_gemm_output refuses T * Cin * 4 >= 2^32)
 F4_MAX_PIXELS = int(os.environ.get("MOPA_WINOGRAD_F4_PIXELS", "3000000"))
+# module-level switches (read once: the algorithm choice is asked ~460 times per forward + backward; tests set the attributes)
+WINOGRAD = os.environ.get("MOPA_WINOGRAD", "1") != "0"
+WINOGRAD_WGRAD = os.environ.get("MOPA_CONV2D_MFMA", "1") != "0" and os.environ.get("MOPA_WINOGRAD_WGRAD", "1") != "0"
 # Which passes use F(4x4): all three (round 2; round 1 shipped "dgrad,wgrad").  In the backward passes its rounding error
 # (~1e-5 relative per layer) is a linear perturbation.  In the FORWARD pass the same error also moves a few ReLU pre-activations
 # across zero, and layers that normalise over few samples amplify such a flip -- measured against the fp64 oracle
@@ -256,7 +259,7 @@ def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
     on the MFMA kernel, then G^T dU G): needs 64-aligned channels on both sides and the MFMA build."""
     F = wino_tile(cin, cout, k, s, p, B, H, W, "wgrad")
     return (F != 0 and cin % 64 == 0 and cout % 64 == 0 and min(cin, cout) >= (64 if F == 4 else 128)
-            and os.environ.get("MOPA_CONV2D_MFMA", "1") != "0" and os.environ.get("MOPA_WINOGRAD_WGRAD", "1") != "0")
+            and WINOGRAD_WGRAD)
 
 
 def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):

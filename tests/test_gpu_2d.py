@@ -680,7 +680,8 @@ def test_source_and_target_batch_in_one_pass_equal_two_calls(winograd, monkeypat
       a few hundred samples per BatchNorm channel in layer4; profiles/f4_gradient_noise.py has the same figures against fp64):
       5 % of each tensor's L2 norm."""
     if not winograd:
-        monkeypatch.setenv("MOPA_WINOGRAD", "0")
+        from mopa_amd import dense2d
+        monkeypatch.setattr(dense2d, "WINOGRAD", False)
     from mopa_amd import synth
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_2d

@@ -121,7 +121,8 @@ def test_conv_algorithm_choice(monkeypatch):
     """dense2d.wino_tile: which algorithm runs a convolution in which pass (the policy behind the measurements in DESIGN.md)."""
     from mopa_amd import dense2d
     monkeypatch.setattr(dense2d, "F4_ROLES", ("dgrad", "wgrad"))
-    monkeypatch.delenv("MOPA_WINOGRAD", raising=False)
+    monkeypatch.setattr(dense2d, "WINOGRAD", True)
+    monkeypatch.setattr(dense2d, "WINOGRAD_WGRAD", True)
     B = 8
     t = dense2d.wino_tile
     # forward: F(2x2) for >= 128 channels up to 76x120, direct otherwise; backward passes: F(4x4) up to full resolution
@@ -143,7 +144,7 @@ def test_conv_algorithm_choice(monkeypatch):
     assert dense2d.wino4_fused(128, 64, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 152, 240)
     assert dense2d.wino4_fused(64, 64, B, 152, 240) and not dense2d.wino4_fused(128, 64, B, 152, 240)   # one K chunk per point: one round suffices
     assert not dense2d.wino4_fused(64, 64, B, 76, 120) and not dense2d.wino4_fused(512, 512, B, 19, 30) and not dense2d.wino4_fused(48, 128, B, 304, 480)
-    monkeypatch.setenv("MOPA_WINOGRAD", "0")
+    monkeypatch.setattr(dense2d, "WINOGRAD", False)   # (MOPA_WINOGRAD=0 at import)
     assert t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 0
 
 
