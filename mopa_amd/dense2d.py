@@ -311,10 +311,15 @@ def wgrad_stream(dev):
     return st
 
 
+_on_events = {}   # side stream -> the event that orders it behind the consumer stream (re-recorded at every hand-over)
+
+
 class _on:
     """`with _on(side, *tensors)`: run the body on `side`, ordered behind everything queued on the current stream so far; the
-    tensors (allocated from the current stream's pool, touched by `side`) are recorded for the caching allocator.  side = None:
-    no-op."""
+    tensors (allocated from the current stream's pool, touched by `side`, and FREED before the streams are joined again) are
+    recorded for the caching allocator.  Tensors that outlive the join need no record: activations and transformed inputs on the
+    tape, parameter gradients -- they are released after Net2DFunction.backward has queued join_wgrad_stream, and whatever
+    re-uses their memory is queued behind that.  side = None: no-op."""
 
     def __init__(self, side, *tensors):
         self.side, self.tensors = side, tensors
@@ -322,7 +327,11 @@ class _on:
     def __enter__(self):
         if self.side is None:
             return
-        self.side.wait_stream(torch.cuda.current_stream())
+        ev = _on_events.get(self.side)
+        if ev is None:
+            ev = _on_events[self.side] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
         for t in self.tensors:
             if torch.is_tensor(t):
                 t.record_stream(self.side)
@@ -377,7 +386,7 @@ class ConvOp:
         # and dout only and nothing downstream of this layer waits for it: it runs on the weight-gradient stream, beside the
         # backward-data chain that the rest of the backward pass is waiting for (Net2DFunction.backward joins the stream).
         ws = wgrad_stream(dev) if wgrad_side else None
-        with _on(ws, x.t, dout.t, dw, db, V):
+        with _on(ws, dout.t):   # (dout is dropped by the caller before the join; x, V, dw, db outlive it)
             if wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W):
                 wino_wgrad(x, dout, self.I, self.O, dw, V, accumulate=acc_params, F=wino_tile(self.I, self.O, k, s, p, x.B, x.H, x.W, "wgrad"))
             else:
@@ -433,7 +442,7 @@ class ConvTOp:
 
     def backward(self, x: Img, dout: Img, dx: Img, dw, db, acc_params: bool = False, wgrad_side: bool = False):
         dev = self.w.device
-        with _on(wgrad_stream(dev) if wgrad_side else None, x.t, dout.t, dw, db):   # see ConvOp.backward
+        with _on(wgrad_stream(dev) if wgrad_side else None, dout.t):   # see ConvOp.backward
             dwl = torch.empty(2, 2, self.I, self.O, dtype=torch.float32, device=dev)
             for ky in range(2):
                 for kx in range(2):
@@ -690,7 +699,7 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             _, x4, c1, g = rec
             dout = gmap.pop(key(c1))
             (dw,), pacc = sink.take(pre + "conv1.weight")
-            with _on(wgrad_stream(dev), x4, dout.t, dw):
+            with _on(wgrad_stream(dev), dout.t):
                 dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
                 wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
                 call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
