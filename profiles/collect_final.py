@@ -2,7 +2,8 @@
 """Copy the artifacts of profiles/make_final.sh (gpurun_out/final/) into the tracked profiles/ files of this round, stamped with the
 commit they were taken at, and write profiles/<round>_rocprof_family.json: the rocprofv3 average launch duration of the kernel
 families bench.py's `roofline` objects are about (bench.py prints `frac_rocprof` from it beside its own HIP-event figure).
-Usage (repo root, after `gpurun -- bash profiles/make_final.sh`): python profiles/collect_final.py [round=r3]"""
+Usage (repo root, after `gpurun -- bash profiles/make_final.sh`): python profiles/collect_final.py [round=r3] [lines]
+(`lines`: after refresh_lines.sh -- re-embed the bench lines, keep the commit stamp of the traces)"""
 import collections, csv, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.abspath(__file__))
 F = os.path.join(R, "..", "gpurun_out", "final")
@@ -24,6 +25,10 @@ def git(*a):
 
 
 commit = git("rev-parse", "--short", "HEAD") + ("+dirty" if git("status", "--porcelain", "--", "mopa_amd", "bench.py") else "")
+if len(sys.argv) > 2 and sys.argv[2] == "lines":   # only the bench lines were re-taken (refresh_lines.sh): the traces keep their stamp
+    prev = os.path.join(R, f"{RND}_rocprof_family.json")
+    if os.path.exists(prev):
+        commit = json.load(open(prev)).get("commit", commit)
 fam = {"commit": commit, "note": "rocprofv3 --kernel-trace --stats of the bench command (profiles/make_final.sh); avg_us = total duration / calls over the family"}
 for w in ("3d", "joint", "kitti", "mopa"):
     if not os.path.exists(os.path.join(F, f"bench_{w}.json")):
