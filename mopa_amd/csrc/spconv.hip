@@ -384,7 +384,7 @@ static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
   // 4 waves per (tile, column group): column groups of 2 tiles when they divide Cout, else 3, else 1 -- and 1 on the
   // shortest levels, where the wider groups would leave fewer than ~3 blocks per CU
   int w = nt % 2 == 0 ? 2 : nt % 3 == 0 ? 3 : 1;
-  if (tiles * (nt / w) < 768) w = 1;
+  if (tiles * (nt / w) < 768) w = 1;   // (level 5 with 32- / 48-column groups instead: 35.3 -> 34.5 / 51.8 us -- not kept)
   if (force_path == 4 || tiles * (nt / w) >= 256) {
     *ntw = w;
     return SP_T4;
@@ -805,6 +805,15 @@ static int launch_pipe(const int* gs, const int* go, const int* gi, const int* g
 //     accumulator read-add-write and 4*NKU*NTW MFMAs per unit;
 //   * wide outputs are cut into column groups (grid.y) so four accumulators fit 2-4 blocks per CU.
 // The block stages the tile's metadata once (shared); everything else is as in k_spconv_pipe.
+// In-kernel cycle counters (-DT4_PROFILE; not in the shipped library): wave 0 of the block at the middle of the grid accumulates the
+// cycles of the phases of its pass into g_t4_prof (the launcher synchronises and prints them) -- prologue (zeroing, metadata,
+// first loads), per unit: accumulator reads + MFMA issue | issue of the next unit's loads | accumulator write-back, epilogue.
+#ifdef T4_PROFILE
+__device__ long long g_t4_prof[8];
+#define T4_CLK() (prof_on ? (long long)__builtin_readcyclecounter() : 0ll)
+#else
+#define T4_CLK() 0ll
+#endif
 #define T4_PAD 4  // accumulator row padding (floats): 0 fits a 4th block per CU at 32 columns (level 1 -6 %) but costs 3-4 % on the MFMA-heavy levels
 template <int NTW, int NKU, int D, bool PART, int NWV>  // NWV waves per tile: 4, or 1 for the 16-column layers of the long levels
 __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
@@ -832,6 +841,10 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
   const int NU = (nkc + NKU - 1) / NKU;  // units per group
   const unsigned ld4 = (unsigned)ld_in >> 2;
   float* acc = reinterpret_cast<float*>(smem + wv * ACCB);
+#ifdef T4_PROFILE
+  const bool prof_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && wv == 0;
+  long long p_t0 = T4_CLK(), p_mma = 0, p_iss = 0, p_wb = 0, p_units = 0, p_first = 0;
+#endif
   for (int i = lane; i < 65 * LD / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // uniform bases (SGPR) + 32-bit per-lane byte offsets: the loads use the saddr + voffset form, no 64-bit VALU adds.
   // Byte offsets of input rows stay below 2^32 (checked by the launcher: 8 * num_out * ld_in * 4 < 2^32).
@@ -892,9 +905,15 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
       T4_ISSUE(s);
       __builtin_amdgcn_sched_barrier(0);  // keep the ring in issue order: the loop's counted vmcnt relies on it
     }
+#ifdef T4_PROFILE
+    if (!p_first) p_first = T4_CLK();
+#endif
     for (int u = 0; u < U; u += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {
+#ifdef T4_PROFILE
+        const long long c0 = T4_CLK();
+#endif
         const unsigned ol[4] = {mo_n.x & 0xffffu, mo_n.x >> 16, mo_n.y & 0xffffu, mo_n.y >> 16};
         BT v[4];  // the 4 rows of a lane are distinct output rows (or the sink): read all, then write all
 #pragma unroll
@@ -916,7 +935,13 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
         }
         if (++cku == NU) { cku = 0; cgp = cgp + NWV < ng ? cgp + NWV : gdead; }
         mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);
+#ifdef T4_PROFILE
+        const long long c1 = T4_CLK();
+#endif
         T4_ISSUE(s);
+#ifdef T4_PROFILE
+        const long long c2 = T4_CLK();
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float* vf = reinterpret_cast<float*>(&v[j]);
@@ -924,10 +949,17 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
           for (int t = 0; t < NTW; ++t) vf[t] += d[t][j];
           *reinterpret_cast<BT*>(acc_lane + ol[j]) = v[j];
         }
+#ifdef T4_PROFILE
+        const long long c3 = T4_CLK();
+        p_mma += c1 - c0; p_iss += c2 - c1; p_wb += c3 - c2; p_units += 1;
+#endif
       }
     }
 #undef T4_ISSUE
   }
+#ifdef T4_PROFILE
+  const long long p_t1 = T4_CLK();
+#endif
   __syncthreads();
   // ordered sum of the four partial accumulators; each output element is written exactly once
   constexpr int V = CP / 4;
@@ -944,6 +976,13 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
       *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + cg * CP + c4 * 4) = sum;
     }
   }
+#ifdef T4_PROFILE
+  if (prof_on && lane == 0) {
+    const long long p_t2 = T4_CLK();
+    g_t4_prof[0] = p_first - p_t0; g_t4_prof[1] = p_mma; g_t4_prof[2] = p_iss; g_t4_prof[3] = p_wb; g_t4_prof[4] = p_t2 - p_t1;
+    g_t4_prof[5] = p_units; g_t4_prof[6] = p_t2 - p_t0; g_t4_prof[7] = ge - gb;
+  }
+#endif
 }
 
 template <int NTW, int NKU, int D, int NWV = 4>
@@ -968,6 +1007,19 @@ static int launch_t4(const int* gs, const int* go, const int* gi, const int* gou
   }
   if (part) T4_GO(true) else T4_GO(false)
 #undef T4_GO
+#ifdef T4_PROFILE
+  {
+    long long h[8];
+    hipStreamSynchronize(st);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_t4_prof), sizeof(h));
+    static int printed = 0;
+    if (printed++ % 33 == 0)   // (the bench repeats each launch 33 times)
+      printf("[t4 profile] K %d rows %d cin %d cout %d NTW %d NKU %d D %d NWV %d grid %u x %u | middle block wave 0: groups %lld units %lld | cycles: prologue %lld, "
+             "per unit: acc read + MFMA issue %.0f | next loads issue %.0f | write-back %.0f, epilogue %lld, total %lld\n",
+             K, A_out, cin, cout, NTW, NKU, D, NWV, grid.x, grid.y, h[7], h[5], h[0], h[5] ? (double)h[1] / h[5] : 0.0, h[5] ? (double)h[2] / h[5] : 0.0,
+             h[5] ? (double)h[3] / h[5] : 0.0, h[4], h[6]);
+  }
+#endif
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
