@@ -849,7 +849,21 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
   // uniform bases (SGPR) + 32-bit per-lane byte offsets: the loads use the saddr + voffset form, no 64-bit VALU adds.
   // Byte offsets of input rows stay below 2^32 (checked by the launcher: 8 * num_out * ld_in * 4 < 2^32).
   const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4;
+  #ifdef T4_DUMMYA   // timing probe only (wrong results): every gather reads input row 0 -> no gather traffic beyond one row
+#define T4_AROW(x) (a_off)
+#else
+#define T4_AROW(x) (x)
+#endif
+#ifdef T4_LDSB     // timing probe only (wrong results): the weight fragments come out of LDS (whatever is there) instead of global memory
+#define T4_BLOAD(gp, lo) (*reinterpret_cast<const float4*>(smem + ((lo) & 0x3ff0)))
+#else
+#define T4_BLOAD(gp, lo) (*reinterpret_cast<const float4*>(gp))
+#endif
+#ifdef T4_DUMMYB   // timing probe only (wrong results): every lane of a weight load reads the same 16 bytes -> no weight traffic through L1
+  const unsigned b_off = 0u;
+#else
   const unsigned b_off = (unsigned)(lane * NTW * 16);
+#endif
   const char* __restrict__ in_b = reinterpret_cast<const char*>(in);
   const unsigned a_off = (unsigned)(q * 16);
   char* acc_lane = reinterpret_cast<char*>(acc) + r * NTW * 4;
@@ -889,12 +903,12 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
 #define T4_ISSUE(S)                                                                                        \
   {                                                                                                        \
     const char* wp_ = wcg + __builtin_amdgcn_readfirstlane(wo_n);                                          \
-    const unsigned arow_ = io_n * 16u + a_off;                                                             \
+    const unsigned arow_ = T4_AROW(io_n * 16u + a_off);                                                    \
     _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                                      \
       const int kc_ = PART ? min(iku * NKU + j, nkc - 1) : iku * NKU + j;                                  \
       A[S][j] = *reinterpret_cast<const float4*>(in_b + (arow_ + (unsigned)(kc_ * 64)));                   \
       _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                   \
-        B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + (b_off + v_ * 16)); \
+        B[S][j][v_] = T4_BLOAD(wp_ + (size_t)kc_ * (16 * CP * 4) + (b_off + v_ * 16), (kc_ * NTW + v_) * 1024 + lane * 16); \
     }                                                                                                      \
     if (++iku == NU) { iku = 0; ig = ig + NWV < ng ? ig + NWV : gdead; }                                       \
     io_n = m_in[ig * 16 + r];                                                                              \
