@@ -854,6 +854,11 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
 #else
 #define T4_AROW(x) (x)
 #endif
+#ifdef T4_NOMFMA   // timing probe only (wrong results): the operands are consumed by one VALU add each instead of an MFMA
+#define T4_MFMA(a, b, c) ((c) + (a) * (b))
+#else
+#define T4_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
 #ifdef T4_LDSB     // timing probe only (wrong results): the weight fragments come out of LDS (whatever is there) instead of global memory
 #define T4_BLOAD(gp, lo) (*reinterpret_cast<const float4*>(smem + ((lo) & 0x3ff0)))
 #else
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(64 * NWV) void k_spconv_t4(const int* __restrict__ 
           for (int s2 = 0; s2 < 4; ++s2) {
             const float* bw = reinterpret_cast<const float*>(&B[s][j][0]) + s2 * NTW;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) d[t] = T4_MFMA(av[s2], bw[t], d[t]);
           }
         }
         if (++cku == NU) { cku = 0; cgp = cgp + NWV < ng ? cgp + NWV : gdead; }
