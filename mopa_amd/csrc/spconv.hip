@@ -14,6 +14,9 @@
 // Data layout: features row-major [rows][ld] fp32 (ld >= C lets a layer read/write a channel slice of a wider
 // JoinTable buffer); weights [K][Cin][Cout] fp32.
 #include "common.h"
+#ifdef MOPA_EXP_RING   // round-4 experiment (profiles/experiments/spconv_ring.hip, build_ring.sh): not in the shipped library
+#include "spconv_ring.h"
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -360,13 +363,19 @@ MOPA_API int mopa_rulebook_groups_fill_batched(const int64_t* desc_host, int32_t
 
 // Which kernel mopa_spconv_fwd_grouped runs for a shape (cin / cout are those of the convolution to run, i.e. swapped
 // for backward-data) and the column-group width NTW its packed weights need (w_flip bit 1).  0 = unpacked weights.
-enum { SP_BLK = 0, SP_PIPE = 1, SP_T4 = 2 };
+enum { SP_BLK = 0, SP_PIPE = 1, SP_T4 = 2, SP_RING = 3 };
 static int packed_plan(int K, int64_t num_out, int cin, int cout, int* ntw) {
   static const int force_path = getenv("MOPA_SPCONV_PATH") ? atoi(getenv("MOPA_SPCONV_PATH")) : 0;  // tuning only
   *ntw = 0;
   if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || force_path == 2) return SP_BLK;
   const int64_t tiles = cdiv64(num_out, 64);
   const int nt = cout / 16;
+#ifdef MOPA_EXP_RING
+  if (force_path == 0) {   // persistent ring kernel, MOPA_SPCONV_RING=1|2
+    const int rw = mopa_ring_plan(K, num_out, cin, cout);
+    if (rw > 0) { *ntw = rw; return SP_RING; }
+  }
+#endif
   // 8-offset down/up tables: few groups per tile -> one wave per tile on the long levels (dispatch below), four on the short
   if (K != 27 && force_path != 4 && force_path != 0) return SP_BLK;
   if (force_path == 1) {
@@ -1157,6 +1166,10 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
     // the pipelined kernels address input rows with 32-bit byte offsets (an input has at most 8x the output's rows)
     if ((int64_t)num_out * 8 * ld_in * 4 >= (1ll << 32)) return MOPA_ERR_ARG;
     const int nkc = cin / 16;
+#ifdef MOPA_EXP_RING
+    if (path == SP_RING)
+      return mopa_ring_launch(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, pntw, st);
+#endif
     if (path == SP_PIPE && cout == 16 && nkc == 2)   // 32 -> 16: one wave per tile with whole-Cin units (40 vs 42 us)
       return launch_t4<1, 2, 2, 1>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st);
     if (path == SP_PIPE) {

@@ -32,12 +32,14 @@ def timed(fn, reps):
 def main():
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    b = synth.make_batch(8, H=16, W=16)
+    scans = int(sys.argv[3]) if len(sys.argv) > 3 else 8     # 16 = the joint step's merged source + target batch
+    b = synth.make_batch(scans, H=16, W=16)
     g = s3.Geometry3D(b["x"][0], L, 4096, "cuda")
     torch.manual_seed(0)
     m = 16
     print(f"{'level':>5} {'table':>6} {'rows':>8} {'rules':>9} {'cin':>4} {'cout':>4} {'wave us':>9} {'grouped us':>10} "
-          f"{'t40 us':>7} {'frac':>6} {'TF/s':>6} same")
+          f"{'t40 us':>7} {'frac':>6} {'TF/s':>6} same  max|diff|  checksum(grouped)")
+    tot_t, tot_b = 0.0, 0.0
     for l in range(L):
         C = m * (l + 1)
         cases = [("subm", g.nbr27[l], C, C), ("subm", g.nbr27[l], 2 * C, C)]
@@ -74,8 +76,13 @@ def main():
             err = float((o1.t - o2.t).abs().max())
             alg = rules * cin * 4 + Ao * cout * 4 + rules * 8 + K * cin * cout * 4     # SURVEY 8d algorithmic bytes
             t40 = alg / 3.2e6                                                           # us at 40 % of 8 TB/s
+            bits = o2.t.contiguous().view(torch.int32).to(torch.int64)
+            chk = int((bits * (torch.arange(bits.numel(), device="cuda").view_as(bits) % 8191 + 1)).sum().item()) & 0xffffffffffff
+            tot_t += tg
+            tot_b += alg
             print(f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {t40:>7.1f} {alg / tg / 8e6:>6.3f} "
-                  f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e}", flush=True)
+                  f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e} {chk:012x}", flush=True)
+    print(f"forward family: {tot_t:.1f} us for {tot_b / 1e6:.1f} MB algorithmic = {tot_b / tot_t / 8e6:.3f} of 8 TB/s")
 
 
 if __name__ == "__main__":

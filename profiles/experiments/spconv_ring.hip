@@ -1,0 +1,486 @@
+// Persistent sparse convolution on the grouped rulebook: ONE workgroup per CU, T teams of four waves + one loader wave.
+//
+// Same contract and the same arithmetic as k_spconv_t4 (spconv.hip): a team owns a 64-row output tile, wave w of the team
+// takes the tile's MFMA groups w, w + 4, ... into a private LDS accumulator, the four accumulators are summed in wave
+// order -- so the results are bit-identical to k_spconv_t4 run with the same unit width.  What changes is how the
+// operands reach the matrix pipe and what a tile costs around its MFMAs (profiles/r3_t4_cycle_counters.md):
+//   * WEIGHTS come from LDS.  In k_spconv_t4 every MFMA needs 256 fresh weight bytes through the vector-memory return
+//     path (one dwordx4 load per 4 MFMAs, 16 cycles of the CU's 64 B/clk path each) -- two thirds of its loads.  Here a
+//     dedicated loader wave streams the column slice W[o][:, cg] of one filter offset after the other into a ring of R
+//     LDS slots by LDS-DMA (global_load_lds_dwordx4, lane-linear 1-KB pieces in MFMA-fragment order), and ALL teams of
+//     the workgroup read their B fragments from it with ds_read_b128 (a separate 256 B/clk pipe).  A slice is fetched
+//     once per workgroup and round instead of once per MFMA group.  The waves walk the offsets 0 .. K-1 of their tiles
+//     in rulebook order, so a ring of R consecutive offsets serves all of them; a slot is handed over with two words in
+//     LDS (ready: the loader after its counted vmcnt; done: every consumer wave once it is past the offset) -- no
+//     workgroup barrier anywhere in the steady state.
+//   * NO COLD PROLOGUE PER TILE.  The workgroup is persistent: a block walks its tiles round by round (static
+//     assignment: batch = round * blocks + block, tile = batch * T + team); the accumulators are zeroed by the ordered
+//     sum that empties them; per-wave metadata needs no barrier (a wave stages only its own groups); the two team
+//     hand-offs per tile (everyone done accumulating / everyone done summing) are spin-waits on LDS counters.
+//
+// LDS: ring R x (Cin x 16 NTW x 4 B) | 4T accumulators of 65 x (16 NTW + 4) floats | 4T metadata blocks | flags.
+#include "spconv_ring.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RG_MSW 20                        // groups a wave stages per chunk (80 groups of a tile per chunk; p99 is 57)
+#define RG_MS1 (RG_MSW + 1)              // + the dead group: ring look-ahead and padding rules go to the sink row
+#define RG_METAB ((RG_MS1 * 100 + 15) / 16 * 16)
+#define RG_PAD 4
+#define RG_FLAGS 64                      // ready[16] | pos[16] | arrive[8] | arrive2[8] | spare
+#define RG_MAXR 16
+#ifndef RG_D
+#define RG_D(NKU) ((NKU) <= 2 ? 6 : (NKU) <= 4 ? 4 : 3)
+#endif
+#define RG_NLMAX 3                        // loader waves per workgroup (launch bound; the launcher picks 1 .. 3)
+
+template <int N> struct RgVec;
+template <> struct RgVec<1> { typedef float T; };
+template <> struct RgVec<2> { typedef float2 T; };
+
+__device__ __forceinline__ unsigned rg_ld(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// wait until *p >= target (monotonic counters; LDS, so another wave's update becomes visible without any fence)
+// The spin is bounded (~30 ms): a protocol error then shows up as wrong results in the parity tests instead of a hung GPU.
+#define RG_SPIN_CAP (1 << 20)
+__device__ __forceinline__ void rg_spin_ge(const unsigned* p, unsigned target) {
+  asm volatile("" ::: "memory");
+  for (int it = 0; it < RG_SPIN_CAP && (int)(__builtin_amdgcn_readfirstlane(rg_ld(p)) - target) < 0; ++it) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+// true when the first n words at p (one per consumer wave: the ring sequence numbers it has released) are all >= target
+__device__ __forceinline__ bool rg_all_ge(const unsigned* p, int n, unsigned target, int lane) {
+  asm volatile("" ::: "memory");
+  const unsigned v = rg_ld(p + (lane < n ? lane : 0));
+  const bool r = __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
+  asm volatile("" ::: "memory");
+  return r;
+}
+__device__ __forceinline__ void rg_add1(unsigned* p, int lane) {
+  asm volatile("" ::: "memory");   // the LDS pipe executes a wave's instructions in order: everything this wave read or wrote before is done first
+  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rg_wait_vmcnt(int n) {   // all but the n youngest vector-memory operations of this wave are done
+#define RG_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define RG_W8(A, B, C, D, E, F, G, H) RG_W(A) RG_W(B) RG_W(C) RG_W(D) RG_W(E) RG_W(F) RG_W(G) RG_W(H)
+  switch (n) {
+    RG_W8(1, 2, 3, 4, 5, 6, 7, 8) RG_W8(9, 10, 11, 12, 13, 14, 15, 16) RG_W8(17, 18, 19, 20, 21, 22, 23, 24)
+    RG_W8(25, 26, 27, 28, 29, 30, 31, 32) RG_W8(33, 34, 35, 36, 37, 38, 39, 40) RG_W8(41, 42, 43, 44, 45, 46, 47, 48)
+    RG_W8(49, 50, 51, 52, 53, 54, 55, 56) RG_W(57) RG_W(58) RG_W(59) RG_W(60)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef RG_W8
+#undef RG_W
+}
+
+// In-kernel cycle counters (-DRG_PROFILE; not in the shipped library): consumer wave 0 of the block in the middle of the grid sums
+// the cycles of the phases of its rounds into g_rg_prof (the launcher synchronises and prints them).
+#ifdef RG_PROFILE
+__device__ long long g_rg_prof[16];
+#define RG_CLK() (prof_on ? (long long)__builtin_readcyclecounter() : 0ll)
+#define RG_ACC(i, v) if (prof_on) p_acc[i] += (v)
+#else
+#define RG_CLK() 0ll
+#define RG_ACC(i, v)
+#endif
+
+template <int NTW, int NKU, bool PART, int T>
+__global__ __launch_bounds__(64 * (4 * T + RG_NLMAX)) void k_spconv_ring(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+                                                                const int* __restrict__ grp_in, const int* __restrict__ grp_out,
+                                                                int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
+                                                                const float* __restrict__ Wp, int w_flip, float* __restrict__ out,
+                                                                int ld_out, int ntiles, int ncg, int R, int NL) {
+  // D units of row gathers in flight per wave: with 8-12 consumer waves per CU two units are ~64 KB in flight per CU, too few to
+  // cover the ~5 us a gather takes behind a full vector-memory queue
+  constexpr int D = RG_D(NKU), CP = NTW * 16, LD = CP + RG_PAD, ACCB = 65 * LD * 4, NW = 4 * T;
+  static_assert(ACCB < 65536 && ACCB % 16 == 0, "metadata packing");
+  typedef typename RgVec<NTW>::T BT;
+  extern __shared__ float4 smem4[];
+  char* smem = reinterpret_cast<char*>(smem4);
+  const int nkc = cin >> 4;
+  const int NU = (nkc + NKU - 1) / NKU;
+  const unsigned SLOT = (unsigned)(nkc * NTW) * 1024u;
+  char* ring = smem;
+  char* accs = smem + (size_t)R * SLOT;
+  char* metas = accs + NW * ACCB;
+  unsigned* flags = reinterpret_cast<unsigned*>(metas + NW * RG_METAB);
+  unsigned *f_ready = flags, *f_pos = flags + 16, *f_arr = flags + 32, *f_arr2 = flags + 40;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = blockIdx.x % ncg, bidx = blockIdx.x / ncg, nblk = gridDim.x / ncg;
+  const int nbatch = (ntiles + T - 1) / T;
+  const int rounds = (nbatch + nblk - 1) / nblk;   // the same for every block: a block without a batch in the last round walks it empty
+  if (tid < RG_FLAGS) flags[tid] = 0u;
+  if (wave < NW) {
+    float4* a4 = reinterpret_cast<float4*>(accs + wave * ACCB);
+    for (int i = lane; i < 65 * LD / 4; i += 64) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  if (wave >= NW) {
+    // ---------------------------------------------------------------- loaders: the weight ring (loader l moves pieces l, l + NL, ...)
+    const int lw = wave - NW;
+    __builtin_amdgcn_s_setprio(3);   // a few instructions per slice that every consumer waits for: never queue them behind MFMA chains
+    typedef const __attribute__((address_space(1))) char* gptr_t;
+    gptr_t wcg = (gptr_t)(reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4);
+    const unsigned lds_ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
+    const int pieces_all = nkc * NTW;
+    const int pieces = (pieces_all - lw + NL - 1) / NL;   // of every slice, this loader's share
+    const unsigned lane_off = (unsigned)(lane * NTW * 16);
+    // Two cursors over the ring sequence (number = round * K + offset): `iss` = next slice to fetch, `pub` = oldest slice fetched but
+    // not yet handed over.  Up to Q slices stay in flight (one wait per slice would pace the ring at one DMA latency per offset:
+    // measured, 2,000 cycles per offset transition of every consumer); a slice is handed over behind a counted vmcnt that leaves
+    // the younger ones in flight.  Fetching has priority; handing over happens when nothing can be fetched.
+#ifdef RG_NOLOAD   // timing probe only (wrong results; with RG_NOWAIT): no weight stream at all
+    return;
+#endif
+    const unsigned total = (unsigned)(rounds * K);
+    int Q = 60 / (pieces > 0 ? pieces : 1);
+    if (Q > R - 1) Q = R - 1;
+    if (Q < 1) Q = 1;
+    unsigned iss = 0, iss_slot = 0, iss_o = 0, pub = 0, pub_slot = 0, pub_use = 0;
+    int idle = 0;
+#ifdef RG_PROFILE
+    const bool prof_on = blockIdx.x == gridDim.x / 2 && lw == 0;
+    long long p_acc[4] = {0, 0, 0, 0};
+    const long long p_l0 = RG_CLK();
+#endif
+    while (pub < total) {
+      [[maybe_unused]] const long long p_c0 = RG_CLK();
+      bool can = iss < total && (int)(iss - pub) < Q;
+      if (can && iss >= (unsigned)R) can = rg_all_ge(f_pos, NW, iss - (unsigned)R + 1u, lane);   // every consumer is past the slice that lived there
+      if (can) {
+        gptr_t slice = wcg + (size_t)(w_flip ? K - 1 - (int)iss_o : (int)iss_o) * SLOT;
+        const unsigned dst = lds_ring + iss_slot * SLOT;
+        for (int p = lw; p < pieces_all; p += NL) {   // piece (kc, v): the v-th float4 of every lane's B operands of chunk kc, lane-linear in LDS
+          const int kc = p / NTW, v = p - kc * NTW;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slice + (unsigned)(kc * NTW) * 1024u + lane_off + v * 16),
+                                           (__attribute__((address_space(3))) void*)(uintptr_t)(dst + (unsigned)p * 1024u), 16, 0, 0);
+        }
+        ++iss;
+        if (++iss_slot == (unsigned)R) iss_slot = 0;
+        if (++iss_o == (unsigned)K) iss_o = 0;
+        idle = 0;
+        RG_ACC(0, RG_CLK() - p_c0);
+      } else if (iss > pub) {
+        rg_wait_vmcnt((int)(iss - pub - 1u) * pieces);   // this loader's part of the oldest slice in flight has landed
+        rg_add1(f_ready + pub_slot, lane);               // (complete once all NL loaders have added theirs)
+        ++pub;
+        if (++pub_slot == (unsigned)R) { pub_slot = 0; ++pub_use; }
+        RG_ACC(1, RG_CLK() - p_c0);
+      } else {
+        if (++idle > RG_SPIN_CAP) break;   // (bounded like every spin of this kernel)
+        __builtin_amdgcn_s_sleep(2);
+        RG_ACC(2, RG_CLK() - p_c0);
+      }
+    }
+#ifdef RG_PROFILE
+    if (prof_on && lane == 0) {
+      g_rg_prof[10] = p_acc[0]; g_rg_prof[11] = p_acc[1]; g_rg_prof[12] = p_acc[2]; g_rg_prof[13] = RG_CLK() - p_l0;
+    }
+#endif
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int team = wave >> 2, wv = wave & 3, r = lane & 15, q = lane >> 4;
+  char* acc_c = accs + wave * ACCB;
+  const char* tacc = accs + team * 4 * ACCB;
+  unsigned* m_in = reinterpret_cast<unsigned*>(metas + wave * RG_METAB);                         // [MS1][16] input row * (ld_in / 4)
+  unsigned short* m_out = reinterpret_cast<unsigned short*>(metas + wave * RG_METAB + RG_MS1 * 64);  // [MS1][16] accumulator row byte offset
+  int* m_o = reinterpret_cast<int*>(metas + wave * RG_METAB + RG_MS1 * 96);                      // [MS1] filter offset (-1: dead)
+  const int G = grp_start[ntiles];
+  const unsigned ld4 = (unsigned)ld_in >> 2;
+  const char* __restrict__ in_b = reinterpret_cast<const char*>(in);
+  const unsigned a_off = (unsigned)(q * 16);
+  char* acc_lane = acc_c + r * NTW * 4;
+  const unsigned b_lane = (unsigned)(lane * 16);
+  float4 A[D][NKU];
+#ifdef RG_PROFILE
+  const bool prof_on = blockIdx.x == gridDim.x / 2 && wave == 0;
+  long long p_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long p_t00 = RG_CLK();
+#endif
+
+  for (int rd = 0; rd < rounds; ++rd) {
+    [[maybe_unused]] const long long p_t0 = RG_CLK();
+    const int tile = (rd * nblk + bidx) * T + team;
+    int gb = 0, ge = 0;
+    if (tile < ntiles) { gb = grp_start[tile]; ge = grp_start[tile + 1]; }
+    const int ng = ge - gb;
+    const int nmine = ng > wv ? (ng - wv + 3) >> 2 : 0;   // this wave: groups wv, wv + 4, ... of the tile
+    const unsigned seq0 = (unsigned)(rd * K);
+    int cur_o = -1;
+    const char* bbase = ring;
+    bool need_arr2 = rd > 0;
+
+    for (int c0 = 0; c0 < nmine; c0 += RG_MSW) {
+      const int nch = min(RG_MSW, nmine - c0);
+      // metadata of this wave's groups c0 .. c0 + nch - 1 (wave-private: program order is all the ordering it needs)
+      for (int e = lane * 4; e < RG_MS1 * 16; e += 256) {
+        const int i = e >> 4;
+        const bool dead = i >= nch;
+        const int g = min(gb + wv + 4 * (c0 + i), G - 1);
+        const int src = g * 16 + (e & 15);
+        const int4 vi = *reinterpret_cast<const int4*>(grp_in + src);
+        const int4 vo = *reinterpret_cast<const int4*>(grp_out + src);
+        uint4 wi;
+        wi.x = dead ? 0u : (unsigned)max(vi.x, 0) * ld4; wi.y = dead ? 0u : (unsigned)max(vi.y, 0) * ld4;
+        wi.z = dead ? 0u : (unsigned)max(vi.z, 0) * ld4; wi.w = dead ? 0u : (unsigned)max(vi.w, 0) * ld4;
+        const unsigned o0 = (unsigned)((dead || vo.x < 0) ? 64 : vo.x) * (LD * 4), o1 = (unsigned)((dead || vo.y < 0) ? 64 : vo.y) * (LD * 4);
+        const unsigned o2 = (unsigned)((dead || vo.z < 0) ? 64 : vo.z) * (LD * 4), o3 = (unsigned)((dead || vo.w < 0) ? 64 : vo.w) * (LD * 4);
+        *reinterpret_cast<uint4*>(m_in + e) = wi;
+        *reinterpret_cast<uint2*>(m_out + e) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+      }
+      if (lane < RG_MS1) {
+        const int g = min(gb + wv + 4 * (c0 + lane), G - 1);
+        m_o[lane] = lane < nch ? grp_o[g] : -1;
+      }
+      asm volatile("" ::: "memory");
+      [[maybe_unused]] const long long p_t1 = RG_CLK();
+      RG_ACC(0, p_t1 - p_t0);   // (chunks after the first count from the round start too: rare)
+
+      const int U = nch * NU;
+      int ig = 0, iku = 0, cgp = 0, cku = 0;
+      unsigned io_n = m_in[r];
+      uint2 mo_n = *reinterpret_cast<const uint2*>(m_out + q * 4);
+#define RG_ISSUE(S)                                                                                 \
+  {                                                                                                 \
+    const unsigned arow_ = io_n * 16u + a_off;                                                      \
+    _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                               \
+      const int kc_ = PART ? min(iku * NKU + j, nkc - 1) : iku * NKU + j;                           \
+      A[S][j] = *reinterpret_cast<const float4*>(in_b + (arow_ + (unsigned)(kc_ * 64)));            \
+    }                                                                                               \
+    if (++iku == NU) { iku = 0; ig = ig + 1 < nch ? ig + 1 : RG_MSW; }                              \
+    io_n = m_in[ig * 16 + r];                                                                       \
+  }
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        RG_ISSUE(s);
+        __builtin_amdgcn_sched_barrier(0);   // keep the ring in issue order: the loop's counted vmcnt relies on it
+      }
+      if (need_arr2) {   // my accumulator's rows are zeroed by my team mates' ordered sums of the previous round
+        rg_spin_ge(f_arr2 + team, 4u * (unsigned)rd);
+        need_arr2 = false;
+      }
+      [[maybe_unused]] const long long p_t2 = RG_CLK();
+      RG_ACC(1, p_t2 - p_t1);
+      RG_ACC(6, U);
+      for (int u = 0; u < U; u += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          if (u + s >= U) { RG_ISSUE(s); continue; }   // past the chunk's last unit: keep the ring's load order, skip the arithmetic
+          if (cku == 0) {
+            const int o = __builtin_amdgcn_readfirstlane(m_o[cgp]);
+            if (o >= 0 && o != cur_o) {   // next filter offset: release the slots behind it, wait for its slice
+              [[maybe_unused]] const long long p_w0 = RG_CLK();
+              const unsigned n = seq0 + (unsigned)o;
+              asm volatile("" ::: "memory");   // (the LDS pipe runs a wave's instructions in order: the B reads of the offsets behind are done)
+              if (lane == 0) __hip_atomic_store(f_pos + wave, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const unsigned use = n / (unsigned)R;
+              const unsigned sig_slot = n - use * (unsigned)R;
+#ifndef RG_NOWAIT   // timing probe only (wrong results): the consumers never wait for a slice -- the ceiling if the weight stream kept up
+              rg_spin_ge(f_ready + sig_slot, (unsigned)NL * (use + 1u));
+#endif
+              bbase = ring + sig_slot * SLOT;
+              cur_o = o;
+              RG_ACC(5, RG_CLK() - p_w0);
+              RG_ACC(7, 1);
+            }
+          }
+          const unsigned ol[4] = {mo_n.x & 0xffffu, mo_n.x >> 16, mo_n.y & 0xffffu, mo_n.y >> 16};
+          float4 B[NKU][NTW];
+#pragma unroll
+          for (int j = 0; j < NKU; ++j) {
+            const int kc_ = PART ? min(cku * NKU + j, nkc - 1) : cku * NKU + j;
+#pragma unroll
+            for (int v = 0; v < NTW; ++v)
+              B[j][v] = *reinterpret_cast<const float4*>(bbase + ((unsigned)(kc_ * NTW + v) * 1024u + b_lane));
+          }
+          BT v[4];   // the 4 rows of a lane are distinct output rows (or the sink): read all, then write all
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const BT*>(acc_lane + ol[j]);
+          f32x4 d[NTW];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < NKU; ++j) {
+            const bool live = !PART || cku * NKU + j < nkc;
+            const float av[4] = {live ? A[s][j].x : 0.f, live ? A[s][j].y : 0.f, live ? A[s][j].z : 0.f, live ? A[s][j].w : 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              const float* bw = reinterpret_cast<const float*>(&B[j][0]) + s2 * NTW;
+#pragma unroll
+              for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0);
+            }
+          }
+          if (++cku == NU) { cku = 0; cgp = cgp + 1 < nch ? cgp + 1 : RG_MSW; }
+          mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);
+          RG_ISSUE(s);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float* vf = reinterpret_cast<float*>(&v[j]);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) vf[t] += d[t][j];
+            *reinterpret_cast<BT*>(acc_lane + ol[j]) = v[j];
+          }
+        }
+      }
+#undef RG_ISSUE
+      RG_ACC(2, RG_CLK() - p_t2);
+    }
+    [[maybe_unused]] const long long p_t3 = RG_CLK();
+    // release the rest of this round's ring sequence (offsets this wave has no group at included)
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(f_pos + wave, seq0 + (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // team hand-off 1: all four accumulators of the tile are complete
+    rg_add1(f_arr + team, lane);
+    rg_spin_ge(f_arr + team, 4u * (unsigned)(rd + 1));
+    [[maybe_unused]] const long long p_t4 = RG_CLK();
+    RG_ACC(3, p_t4 - p_t3);
+    // ordered sum of rows 16 wv .. 16 wv + 15 of the four accumulators (wave order: as k_spconv_t4), written once, zeroed
+    {
+      constexpr int V = CP / 4;
+      const int row0 = tile * 64;
+#pragma unroll
+      for (int i = lane; i < 16 * V; i += 64) {
+        const int rr = 16 * wv + i / V, c4 = i % V;
+        const char* p0 = tacc + (rr * LD + c4 * 4) * 4;
+        float4 sum = *reinterpret_cast<const float4*>(p0);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+          const float4 p = *reinterpret_cast<const float4*>(p0 + w2 * ACCB);
+          sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+        }
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) *reinterpret_cast<float4*>(const_cast<char*>(p0) + w2 * ACCB) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile < ntiles && row0 + rr < A_out)
+          *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + cg * CP + c4 * 4) = sum;
+      }
+    }
+    // team hand-off 2: the accumulators are empty again
+    rg_add1(f_arr2 + team, lane);
+    RG_ACC(4, RG_CLK() - p_t4);
+  }
+#ifdef RG_PROFILE
+  if (prof_on && lane == 0) {
+    for (int i = 0; i < 8; ++i) g_rg_prof[i] = p_acc[i];
+    g_rg_prof[8] = RG_CLK() - p_t00;
+    g_rg_prof[9] = rounds;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+static int rg_env(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+static size_t rg_lds_bytes(int ntw, int T, int R, int cin) {
+  const int LD = ntw * 16 + RG_PAD;
+  return (size_t)R * cin * ntw * 64 + (size_t)4 * T * (65 * LD * 4 + RG_METAB) + RG_FLAGS * 4;
+}
+static int rg_teams(int ntw) { return ntw == 2 ? 2 : 3; }
+// ring slots for a shape: as many of the K offsets as fit beside the accumulators (at least 3: one being read, one landed, one in flight)
+static int rg_slots(int ntw, int K, int cin) {
+  const int T = rg_teams(ntw);
+  int R = K < RG_MAXR ? K : RG_MAXR;
+  static const int cap = rg_env("MOPA_RING_R", 0);   // tuning only
+  if (cap > 0 && R > cap) R = cap;
+  while (R >= 3 && rg_lds_bytes(ntw, T, R, cin) > 160 * 1024) --R;
+  return R;
+}
+
+int mopa_ring_plan(int K, int64_t num_out, int cin, int cout) {
+  static const int enable = rg_env("MOPA_SPCONV_RING", 0);   // 0 = off, 1 = every shape it supports, 2 = 27-offset tables only
+  if (!enable) return 0;
+  if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || K > 27) return 0;
+  if (enable == 2 && K != 27) return 0;
+  static const int force_ntw = rg_env("MOPA_RING_NTW", 0);   // tuning only
+  static const int min_tiles = rg_env("MOPA_RING_MIN_TILES", 0);
+  if (cdiv64(num_out, 64) < min_tiles) return 0;
+  int ntw = (cout % 32 == 0 && cin <= 128) ? 2 : 1;
+  if (force_ntw == 1 || (force_ntw == 2 && cout % 32 == 0)) ntw = force_ntw;
+  if (ntw == 2 && rg_slots(2, K, cin) < 3) ntw = 1;
+  if (rg_slots(ntw, K, cin) < 3) return 0;
+  return ntw;
+}
+
+template <int NTW, int NKU, bool PART>
+static int rg_go(const int* gs, const int* go, const int* gi, const int* gout, int K, int num_out, const float* in, int ld_in, int cin,
+                 const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
+  constexpr int T = NTW == 2 ? 2 : 3;
+  const int R = rg_slots(NTW, K, cin);
+  if (R < 3) return MOPA_ERR_ARG;
+  const size_t lds = rg_lds_bytes(NTW, T, R, cin);
+  auto kern = k_spconv_ring<NTW, NKU, PART, T>;
+  static std::atomic<int> attr_lds{0};   // caches an idempotent attribute call, no result depends on it
+  if ((int)lds > attr_lds.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MOPA_ERR_LAUNCH;
+    attr_lds.store(160 * 1024, std::memory_order_release);
+  }
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int ntiles = (int)cdiv64(num_out, 64), ncg = cout / (NTW * 16);
+  const int nbatch = (ntiles + T - 1) / T;
+  int nblk = cus / ncg;
+  if (nblk < 1) nblk = 1;
+  if (nblk > nbatch) nblk = nbatch;
+  static const int nl_env = rg_env("MOPA_RING_NL", 0);   // tuning only
+  int NL = nl_env > 0 ? nl_env : 2;
+  if (NL > RG_NLMAX) NL = RG_NLMAX;
+  if (NL > (cin / 16) * NTW) NL = (cin / 16) * NTW;
+  kern<<<nblk * ncg, 64 * (4 * T + NL), lds, st>>>(gs, go, gi, gout, K, num_out, in, ld_in, cin, Wp, w_flip, out, ld_out, ntiles, ncg, R, NL);
+#ifdef RG_PROFILE
+  {
+    long long h[16];
+    hipStreamSynchronize(st);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rg_prof), sizeof(h));
+    static int printed = 0;
+    if (printed++ % 13 == 0 && h[9] > 0)   // (the bench repeats each launch 3 + reps times)
+      printf("[ring profile] K %d rows %d cin %d cout %d NTW %d NKU %d T %d R %d NL %d grid %d | middle block, consumer wave 0, per round of %lld: units %.1f, "
+             "transitions %.1f | cycles: metadata %.0f, first loads + wait for empty accumulators %.0f, main loop %.0f (of it waiting at offset "
+             "transitions %.0f), release + wait for the team %.0f, ordered sum %.0f | total %lld\n",
+             K, num_out, cin, cout, NTW, NKU, T, R, NL, nblk * ncg, h[9], (double)h[6] / h[9], (double)h[7] / h[9], (double)h[0] / h[9], (double)h[1] / h[9],
+             (double)h[2] / h[9], (double)h[5] / h[9], (double)h[3] / h[9], (double)h[4] / h[9], h[8]);
+    if (printed % 13 == 1 && h[9] > 0)
+      printf("[ring profile]   loader, per round: fetching %.0f, handing over %.0f, idle (ring full) %.0f | total %lld\n", (double)h[10] / h[9],
+             (double)h[11] / h[9], (double)h[12] / h[9], h[13]);
+  }
+#endif
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
+int mopa_ring_launch(const int* gs, const int* go, const int* gi, const int* gout, int K, int num_out, const float* in, int ld_in,
+                     int cin, const float* Wp, int cout, int w_flip, float* out, int ld_out, int ntw, hipStream_t st) {
+  const int nkc = cin / 16;
+#define RG(N, KU, P) return rg_go<N, KU, P>(gs, go, gi, gout, K, num_out, in, ld_in, cin, Wp, cout, w_flip, out, ld_out, st)
+  // unit = group x NKU chunks: the same unit widths as k_spconv_t4 picks for this column-group width (bit-identical sums)
+  if (ntw == 1) {
+    if (nkc == 1) RG(1, 1, false);
+    if (nkc == 2) RG(1, 2, false);
+    if (nkc % 5 == 0) RG(1, 5, false);
+    if (nkc % 7 == 0) RG(1, 7, false);
+    if (nkc % 3 == 0) RG(1, 3, false);
+    if (nkc % 4 == 0) RG(1, 4, false);
+    RG(1, 4, true);
+  }
+  if (ntw == 2) {
+    if (nkc == 1) RG(2, 1, false);
+    if (nkc == 2) RG(2, 2, false);
+    if (nkc % 5 == 0) RG(2, 5, false);
+    if (nkc % 3 == 0) RG(2, 3, false);
+    if (nkc % 4 == 0) RG(2, 4, false);
+    RG(2, 4, true);
+  }
+#undef RG
+  return MOPA_ERR_ARG;
+}
