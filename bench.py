@@ -601,6 +601,7 @@ def main():
         p3 = merge_domains_3d([(bs["locs"], bs["feats"]), (bt["locs"], bt["feats"])], [Bs, Bs]) if pair_3d else None
         return p2, p3
 
+    mode = {"pair": pair_mode}   # (mutable: the two-calls-per-domain figure after the timed region switches it off)
     pair2d = pair_batch_of(batches[0], batches[1]) if pair_mode else None
     if pair_mode and pair2d[1] is not None:   # rule counts of the joint geometry for the algorithmic-bytes model (as above)
         g = Geometry3D(pair2d[1]["x"][0], 7, 4096, dev, group_points=pair2d[1]["bn_group_points"])
@@ -745,7 +746,7 @@ def main():
             for o in opts:
                 o.zero_grad()
         work3 = None
-        if joint and host_fed and pair_mode:
+        if joint and host_fed and mode["pair"]:
             d0, e0 = stage(host_batches[0])
             d1, e1 = stage(host_batches[1])
             torch.cuda.current_stream(dev).wait_event(e0)
@@ -758,7 +759,7 @@ def main():
             pa = half(d0, lam_src, True, ready=e0)
             torch.cuda.current_stream(dev).wait_event(e1)
             parts = pa + half(d1, lam_trg, False, ready=e1)
-        elif joint and pair_mode:
+        elif joint and mode["pair"]:
             parts = pair(batches[0], batches[1], pair2d)
             if multi and overlap_3d:
                 with torch.cuda.stream(dual.side):
@@ -912,6 +913,69 @@ def main():
             el_h = t.item()
         host_value = (world * scans_per_step * n_host / el_h, n_host)
 
+    def timed_extra(n, **kw):
+        """n further steps after two untimed ones, max over ranks -> scans/s (figures beside `value`, never `value`)."""
+        for i in range(2):
+            paced_step(i, **kw)
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        t_ = time.perf_counter()
+        for i in range(n):
+            paced_step(i, **kw)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t_
+        if multi:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return world * scans_per_step * n / el
+
+    # ---- the reference's loop as written: model(source) then model(target), two passes per network and iteration
+    # (train_xmuda_mopa.py:342-343,426-427).  `value` merges them (bn_groups / bn_group_points: an extension of the data_batch contract,
+    # INTEGRATION.md); this is the same step without the extension, a few steps after the timed region, reported beside `value`.
+    two_call_value = None
+    if joint and pair_mode and decoupled and os.environ.get("MOPA_BENCH_TWO_CALLS", "1") != "0":
+        n_two = max(2, min(args.steps, 8))
+        mode["pair"] = False
+        two_call_value = (timed_extra(n_two), n_two)
+        mode["pair"] = pair_mode
+
+    # ---- the sparse-conv roofline figure of THIS run (joint workloads): the merged 3D pass (both domains' scans as one sparse tensor,
+    # exactly the launches of the timed step) forward + backward with the 2D branch idle, the layer program walked from Python so that
+    # every sparse-conv launch sits in a HIP-event bracket on its stream.  Inside the timed step the family shares the chip and a
+    # lower-priority stream with the 2D GEMMs: a bracket there is mostly queue wait (kept as frac_event_bracket_with_queue_wait).
+    ks_alone = None
+    if joint and rank == 0 and pair_mode and pair2d[1] is not None and os.environ.get("MOPA_BENCH_SPARSE_ALONE", "1") != "0":
+        p3 = pair2d[1]
+        lab3 = torch.cat([batches[0]["label"], batches[1]["label"]])
+        ks_main_records = timer.records
+        timer.records = []
+        sparse3d_mod.NATIVE = False
+
+        def step3d_alone():
+            opts[0].zero_grad()
+            g3 = model3d.net_3d.geometry(p3["x"][0], group_points=p3["bn_group_points"])
+            o = model3d({"x": p3["x"], "bn_group_points": p3["bn_group_points"], "geometry_3d": g3})
+            l = seg_ce(o["seg_logit"], lab3, cw) + seg_ce(o["seg_logit2"], lab3, cw)
+            l.backward()
+
+        for _ in range(2):
+            step3d_alone()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        n_alone = 5
+        for _ in range(n_alone):
+            step3d_alone()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        ks_alone = timer.summary()
+        if ks_alone:
+            ks_alone["steps"] = n_alone
+        timer.records = ks_main_records
+        sparse3d_mod.NATIVE = native_default
+        opts[0].zero_grad()
+
     if rank == 0:
         ks = timer.summary()
         sp = None
@@ -929,19 +993,26 @@ def main():
         # PMC traffic and rocprofv3 launch durations come from COMMITTED files (counters need rocprofv3 around the process): the
         # files carry the commit they were taken at (profiles/collect_final.py), the line says so
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
-        fam_path = os.path.join(ROOT, "profiles", "r3_rocprof_family.json")
+        def _prof(name):   # committed profile summaries: this round's if present, else the previous round's
+            for rnd in ("r4", "r3"):
+                q = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+                if os.path.exists(q):
+                    return q
+            return os.path.join(ROOT, "profiles", f"r4_{name}")
+
+        fam_path = _prof("rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
         # (every workload has its own PMC passes: the paired steps run both domains' scans as one sparse tensor -- other launches than
         #  `--workload 3d`'s)
         t3_key = wl_key
-        t3 = os.path.join(ROOT, "profiles", f"r3_{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
+        t3 = _prof(f"{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
         if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
             fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
-                sp["traffic_source"] = ("profiles/r3_%s_hbm_traffic.json at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                        "`bench.py --workload %s`, per launch)" % (t3_key, d3.get("_commit", "?"), t3_key))
+                sp["traffic_source"] = ("%s at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "`bench.py --workload %s`, per launch)" % (os.path.relpath(t3, ROOT), d3.get("_commit", "?"), t3_key))
         if sp and joint:
             # inside the joint step the family shares the chip and its (lower-priority) side stream with the 2D GEMMs: an event
             # bracket there is mostly queue wait, not kernel time.  `frac` is therefore NOT reported from it; see frac_rocprof (kernel
@@ -949,8 +1020,22 @@ def main():
             sp["frac_event_bracket_with_queue_wait"] = sp.pop("frac")
             sp["achieved_event_bracket_with_queue_wait"] = sp.pop("achieved")
             sp["frac"], sp["achieved"] = None, None
-            sp["note"] = ("the 3D branch runs on a second stream beside the 2D branch: HIP-event brackets on it include queue wait; frac / achieved "
-                          "are taken from rocprofv3 kernel durations (frac_rocprof) -- `--workload 3d` measures the family on its own")
+            sp["avg_launch_us_event_bracket_with_queue_wait"] = sp.pop("avg_launch_us")
+            if ks_alone:   # measured in THIS run: the same launches with the 2D branch idle
+                sp["frac"], sp["achieved"] = round(ks_alone["gbs"] / HBM_PEAK_GBS, 4), round(ks_alone["gbs"], 1)
+                sp["avg_launch_us"] = round(ks_alone["avg_us"], 2)
+                sp["mfma_tflops"] = round(ks_alone["tflops"], 2)
+                sp["launches_per_step"] = ks_alone["launches"] // ks_alone["steps"]
+                sp["algorithmic_bytes_per_launch"] = round(ks_alone["bytes_per_launch"])
+                sp["mixed_roofline"] = {"ideal_us_per_launch": round(ks_alone["ideal_us_per_launch"], 2),
+                                        "mfma_bound_launches_per_step": ks_alone["mfma_bound_launches"] // ks_alone["steps"],
+                                        "frac_event_bracket": round(ks_alone["ideal_us_per_launch"] / ks_alone["avg_us"], 4)}
+                sp["frac_measured_in"] = (f"this run, after the timed region: {ks_alone['steps']} forward + backward passes of the merged 3D batch "
+                                          "(source + target scans as one sparse tensor: the launches of the timed step) with the 2D branch idle, "
+                                          "every launch of the family in a HIP-event bracket on its stream")
+            sp["note"] = ("inside the timed step the 3D branch runs on a second stream beside the 2D branch: HIP-event brackets there include queue "
+                          "wait (frac_event_bracket_with_queue_wait); frac / achieved are measured in this run with the 2D branch idle; frac_rocprof = "
+                          "rocprofv3 kernel durations of this command from the committed profile")
         def _fresh(rf_, launches_per_step):
             """A committed rocprofv3 figure belongs to this code only if the family is launched as often per step as when it was taken
             (e.g. one 2D pass per iteration instead of two halves the launch count and doubles the launch size)."""
@@ -959,18 +1044,18 @@ def main():
 
         rf = famj.get(wl_key, {}).get("sparse_conv")
         if sp and rf and not _fresh(rf, sp["launches_per_step"]):
-            sp["rocprof_note"] = "profiles/r3_rocprof_family.json was taken with another launch count per step: not used"
+            sp["rocprof_note"] = f"{os.path.relpath(fam_path, ROOT)} was taken with another launch count per step: not used"
             rf = None
         if sp and rf:
             gbs = sp["algorithmic_bytes_per_launch"] / (rf["avg_us"] * 1e-6) / 1e9
             sp["frac_rocprof"], sp["avg_launch_us_rocprof"], sp["rocprof_commit"] = round(gbs / HBM_PEAK_GBS, 4), rf["avg_us"], famj.get("commit")
             sp["mixed_roofline"]["frac_rocprof"] = round(sp["mixed_roofline"]["ideal_us_per_launch"] / rf["avg_us"], 4)
-            if sp.get("frac") is None:
-                sp["frac"], sp["achieved"] = sp["frac_rocprof"], round(gbs, 1)
+            # (a committed figure is never `frac`: the file cannot know whether the kernels changed since -- ADVICE r3)
+            sp["rocprof_source"] = os.path.relpath(fam_path, ROOT)
         roof = sp
         k2 = timer2d.summary() if joint else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r3_{wl_key}_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tpath = _prof(f"{wl_key}_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         tj = {}
         if joint and os.path.exists(tpath):                                      # of this same command (profiles/traffic.py)
             tj = json.load(open(tpath))
@@ -980,7 +1065,7 @@ def main():
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": f"profiles/r3_{wl_key}_hbm_traffic.json at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
+                    "traffic_source": f"{os.path.relpath(tpath, ROOT)} at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
                     "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
@@ -995,7 +1080,7 @@ def main():
                                             ("weight-gradient stream + " if dense2d_streams() else "") + "3D side stream"}
             rd = famj.get(wl_key, {}).get("dense_mfma")
             if rd and not _fresh(rd, roof["launches_per_step"]):
-                roof["rocprof_note"] = "profiles/r3_rocprof_family.json was taken with another launch count per step: not used"
+                roof["rocprof_note"] = f"{os.path.relpath(fam_path, ROOT)} was taken with another launch count per step: not used"
                 rd = None
             if rd:   # the same flops over rocprofv3's kernel durations of this command (no launch gaps): the two figures bracket the truth
                 roof["frac_rocprof"] = round(roof["algorithmic_flops_per_launch"] / (rd["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4)
@@ -1042,6 +1127,10 @@ def main():
                                           "bracketed steps eager)" if graph2d_default else "eager (default; MOPA_GRAPH_2D=1 replays the backbone from HIP graphs)")},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "value_with_host_inputs": None if host_value is None else round(host_value[0], 3),
+            "value_two_calls_per_domain": None if two_call_value is None else round(two_call_value[0], 3),
+            "two_calls_note": None if two_call_value is None else (
+                f"{two_call_value[1]} further steps in the reference's loop order -- model(source batch), then model(target batch), two passes per "
+                "network and iteration (train_xmuda_mopa.py:342-343,426-427) -- without the bn_groups / bn_group_points extension `value` uses"),
             "host_inputs_note": None if host_value is None else (
                 f"{host_value[1]} further steps with coords / feats / labels / images handed over as HOST tensors and img_indices as "
                 "numpy arrays (the reference's collate output), uploaded on a copy stream beside the compute; not part of `value`"),
