@@ -416,13 +416,16 @@ MOPA_API int mopa_bn_act_fwd_sync(const float* x, int32_t ldx, float* y, int32_t
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps, float leak,
                                   int32_t act, const float* res, int32_t ld_res, const double* gathered, int32_t world, float* stats,
                                   void* stream) {
-  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3) || world <= 0 || !gathered)
+  // num_rows == 0: a rank without rows at this layer still owns a copy of the running statistics -- they are updated from the
+  // gathered (global) moments like everywhere else, nothing is applied
+  if (num_rows < 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3) || world <= 0 || !gathered)
     return MOPA_ERR_ARG;
   if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   k_bn_finalize_sync<<<(C + 255) / 256, 256, 0, st>>>(gathered, world, C, gamma, beta, running_mean, running_var, momentum, eps, stats,
                                                       stats + C, stats + 2 * C, stats + 3 * C);
-  k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats, stats + C, leak, res, ld_res, act);
+  if (num_rows > 0)
+    k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats, stats + C, leak, res, ld_res, act);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

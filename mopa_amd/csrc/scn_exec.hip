@@ -262,7 +262,13 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
   hipEvent_t ev_ready = (hipEvent_t)io[IO_EV_READY], ev_done = (hipEvent_t)io[IO_EV_DONE];
   void* ws2 = (void*)io[IO_WS2];
   const size_t ws2_bytes = (size_t)io[IO_WS2_BYTES];
-  const bool side = wst && wst != st && ev_ready && ev_done && ws2;
+  bool side = wst && wst != st && ev_ready && ev_done && ws2;
+  // The second stream reads a convolution's output gradient `dy` after waiting for "dy complete" only.  That is enough while nothing
+  // later in the pass writes dy again -- true for the plain UNet, NOT for residual blocks: Program.backward_plan aliases an identity
+  // shortcut's gradient to the AddTable's output gradient, and the BatchNorm behind it ACCUMULATES into that slice (PL_ACC) on
+  // `stream` while a lagging weight gradient may still be reading it.  Programs with accumulating steps keep everything on `stream`.
+  for (int s = 0; s < n_steps && side; ++s)
+    if (plan_host[s * PL_W + PL_ACC]) side = false;
   int rc = refresh_forms(prog_host, n_ops, params_host, forms_host, geom_host, bufs_host, gbufs_host, plan_host, n_steps, io[IO_EPOCH], 1, st);
   if (rc) return rc;
   {

@@ -90,9 +90,15 @@ class Geometry3D:
             call("mopa_group_split", ptr(item_row[0]), None, b, N, ptr(meta, base), st)
             for l in range(L - 1):   # parents of the rows in front of the boundary at level l
                 call("mopa_group_split", ptr(item_row[l + 1]), ptr(meta, base + l), 0, N, ptr(meta, base + l + 1), st)
+            # the groups must not share a voxel (scan indices disjoint and increasing from group to group: merge_domains_3d offsets
+            # them): then every row of the points behind the boundary is a NEW row.  Checked on the device, read back with the rest.
+            meta[L] += 2 * (item_row[0][b:N].min() < meta[base]).to(torch.int32)
         m = meta.cpu().tolist()  # the one host sync of the geometry build
-        if m[L] != 0:
+        if m[L] & 1:
             raise RuntimeError("voxel coordinates out of range: need 0 <= x,y,z < 4096 and batch >= 0")
+        if m[L] > 1:
+            raise ValueError("group_points: a point behind a group boundary falls into a voxel of the group in front of it -- the groups' scan "
+                             "indices (coords[:, 3]) must be disjoint and increasing from group to group (mopa_amd.step.merge_domains_3d)")
         self.num_active = m[:L]
         A = self.num_active
         # split[l]: the row boundaries between the groups at level l ([] for every level = None)

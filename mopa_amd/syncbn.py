@@ -70,6 +70,10 @@ def fwd(x, y, gamma, beta, rmean, rvar, momentum, eps, leak, act, res, stats):
         # a rank without rows at this layer still takes part in the collective (moments with n = 0 are skipped by the Chan
         # combination); raising here would leave the other ranks blocked in all_gather for ever
         dist.all_gather_into_tensor(gathered, torch.zeros(2 * C + 1, dtype=torch.float64, device=dev), group=group)
+        # ... and still owns running statistics: updated from the global moments like on every other rank (stats-only call, rows = 0),
+        # so that whichever rank writes the checkpoint holds the same BatchNorm buffers
+        call("mopa_bn_act_fwd_sync", x.p, x.ld, y.p, y.ld, 0, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+             leak, int(act), None, 0, ptr(gathered), world, ptr(stats), stream())
         return gathered
     ws = _ws(query("mopa_bnrelu_rows_workspace_bytes", x.rows, C), dev)
     mine = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)

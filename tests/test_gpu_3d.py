@@ -496,6 +496,10 @@ def test_two_groups_of_scans_in_one_3d_pass_equal_two_calls(native, monkeypatch)
     assert [s[0] for s in g3.split] == ga.num_active and [s[1] for s in g3.split] == g.num_active
     with pytest.raises(ValueError):
         Geometry3D(torch.from_numpy(three), 7, 4096, "cuda", group_points=[len(both), len(ca)])
+    # the second batch NOT offset behind the first one's scan indices: its points fall into voxels of the first group -> refused
+    # (checked on the device inside the geometry's one read-back), where the boundary would silently mix the BatchNorm groups
+    with pytest.raises(ValueError, match="disjoint"):
+        Geometry3D(torch.from_numpy(np.concatenate([ca, ca[:100]])), 7, 4096, "cuda", group_points=len(ca))
 
     def gout(shape, seed):
         return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape, dtype=np.float32)).cuda()
