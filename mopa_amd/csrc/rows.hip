@@ -556,7 +556,8 @@ MOPA_API int mopa_input_layer_bwd(const float* dout, int32_t ld_dout, const int3
 // 16 lanes per point (lane = feature channel group); M = feature width (multiple of 4, <= 64), NC <= 32 classes.
 // M/4 lanes cooperate on one point: each lane moves one float4 of the row (the gather reads the row once, coalesced,
 // and writes feats once) and holds the partial dot products of its 4 channels with every class row of W1 / W2; a
-// shuffle tree over the M/4 lanes finishes the logits.  M/4 must be a power of two <= 16 (M = 16: SCN, M = 64: 2D).
+// shuffle tree over the lane group finishes the logits.  The lane group is M/4 rounded up to a power of two <= 16 (M = 16: SCN,
+// M = 64: 2D; other multiples of 4 -- UNetSCN(m) with m = 8, 12, 20, ... -- leave the group's last lanes idle).
 #define OH_MAXNC 16
 __global__ __launch_bounds__(256) void k_output_heads_fwd(const float* __restrict__ y, int ld, const int* __restrict__ point_row,
                                                            int N, int M, int NC, const float* __restrict__ w1,
@@ -568,28 +569,31 @@ __global__ __launch_bounds__(256) void k_output_heads_fwd(const float* __restric
   for (int i = threadIdx.x; i < nw; i += 256) { lw[i] = w1[i]; if (w2) lw[nw + NC + i] = w2[i]; }
   for (int i = threadIdx.x; i < NC; i += 256) { lw[nw + i] = b1[i]; if (w2) lw[2 * nw + NC + i] = b2[i]; }
   __syncthreads();
-  const int MQ = M >> 2;             // lanes per point
-  const int PPB = 256 / MQ;          // points per block iteration
-  const int cq = threadIdx.x % MQ, pl = threadIdx.x / MQ;
+  const int MQ = M >> 2;             // float4 pieces of a row
+  int MQP = 1;                       // lanes per point: MQ rounded up to a power of two (the shuffle tree's width)
+  while (MQP < MQ) MQP <<= 1;
+  const int PPB = 256 / MQP;         // points per block iteration
+  const int cq = threadIdx.x % MQP, pl = threadIdx.x / MQP;
+  const bool lane_on = cq < MQ;
   for (int p0 = blockIdx.x * PPB; p0 < N; p0 += gridDim.x * PPB) {
     const int p = p0 + pl;
     const bool ok = p < N;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
+    if (ok && lane_on) {
       v = *reinterpret_cast<const float4*>(y + (int64_t)point_row[p] * ld + cq * 4);
       *reinterpret_cast<float4*>(feats + (int64_t)p * M + cq * 4) = v;
     }
 #pragma unroll
     for (int k = 0; k < OH_MAXNC; ++k) {
       if (k < NC) {
-        const float* wr = lw + k * M + cq * 4;
+        const float* wr = lw + k * M + (lane_on ? cq : 0) * 4;   // (an idle lane multiplies zeros)
         float a1 = fmaf(v.x, wr[0], fmaf(v.y, wr[1], fmaf(v.z, wr[2], v.w * wr[3])));
         float a2 = 0.f;
         if (w2) {
-          const float* wr2 = lw + nw + NC + k * M + cq * 4;
+          const float* wr2 = lw + nw + NC + k * M + (lane_on ? cq : 0) * 4;
           a2 = fmaf(v.x, wr2[0], fmaf(v.y, wr2[1], fmaf(v.z, wr2[2], v.w * wr2[3])));
         }
-        for (int o = MQ >> 1; o > 0; o >>= 1) {
+        for (int o = MQP >> 1; o > 0; o >>= 1) {
           a1 += __shfl_xor(a1, o, 64);
           a2 += __shfl_xor(a2, o, 64);
         }
@@ -606,10 +610,10 @@ MOPA_API int mopa_output_layer_heads_fwd(const float* y, int32_t ld_y, const int
                                          int32_t M, int32_t num_classes, const float* w1, const float* b1,
                                          const float* w2, const float* b2, float* feats, float* logit1, float* logit2,
                                          void* stream) {
-  const int mq = M >> 2;
-  if (n_points <= 0 || M <= 0 || M > 64 || (M & 3) || (mq & (mq - 1)) != 0 || num_classes <= 0 || num_classes > OH_MAXNC ||
-      ld_y < M || (ld_y & 3))
+  if (n_points <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > OH_MAXNC || ld_y < M || (ld_y & 3))
     return MOPA_ERR_ARG;
+  int mq = 1;
+  while (mq < (M >> 2)) mq <<= 1;
   const size_t sh = (size_t)(2 * num_classes * M + 2 * num_classes) * sizeof(float);
   k_output_heads_fwd<<<stream_grid((int64_t)n_points * mq, 256), 256, sh, (hipStream_t)stream>>>(
       y, ld_y, point_row, n_points, M, num_classes, w1, b1, w2, b2, feats, logit1, logit2);
@@ -650,8 +654,11 @@ __global__ __launch_bounds__(256) void k_output_heads_bwd_rows(const float* __re
 __global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restrict__ dl, const float* __restrict__ feats, int N,
                                                              int M, int NC, float* __restrict__ partial) {
   extern __shared__ float red[];  // [PL][NC][M+1]
-  const int MQ = M >> 2, PL = 256 / MQ;
-  const int cq = threadIdx.x % MQ, pl = threadIdx.x / MQ;
+  const int MQ = M >> 2;
+  int MQP = 1;   // lanes per point (M/4 rounded up to a power of two; the last lanes of a group idle when M/4 is not one)
+  while (MQP < MQ) MQP <<= 1;
+  const int PL = 256 / MQP;
+  const int cq = threadIdx.x % MQP, pl = cq < MQ ? threadIdx.x / MQP : PL;
   const int p0 = blockIdx.x * HEAD_PTS_PER_BLOCK, p1 = min(N, p0 + HEAD_PTS_PER_BLOCK);
   float acc[HEAD_MAXNC][4];
   float accb[HEAD_MAXNC];
@@ -713,16 +720,17 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
                                          int32_t num_classes, float* dy, int32_t ld_dy, float* dw1, float* db1,
                                          float* dw2, float* db2, int32_t accumulate, void* ws, size_t ws_bytes,
                                          void* stream) {
-  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || (M & 3) || 256 % (M >> 2) != 0 || num_classes <= 0 ||
-      num_classes > HEAD_MAXNC || ld_dy < M)
+  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > HEAD_MAXNC || ld_dy < M)
     return MOPA_ERR_ARG;
+  int mqp = 1;
+  while (mqp < (M >> 2)) mqp <<= 1;
   if (ws_bytes < mopa_output_layer_heads_bwd_workspace_bytes(n_points, M, num_classes)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   k_output_heads_bwd_rows<<<stream_grid((int64_t)num_rows * M, 256), 256, (size_t)2 * num_classes * M * sizeof(float), st>>>(
       dfeats, dl1, dl2, w1, w2, row_start, row_points, num_rows, M, num_classes, dy, ld_dy);
   const int nblk = (int)cdiv64(n_points, HEAD_PTS_PER_BLOCK);
   float* partial = (float*)ws;
-  const size_t hsh = (size_t)(256 / (M >> 2)) * num_classes * (M + 1) * sizeof(float);
+  const size_t hsh = (size_t)(256 / mqp) * num_classes * (M + 1) * sizeof(float);
   if (hsh > 64 * 1024) return MOPA_ERR_ARG;
   if (dl1 && dw1) {
     k_head_wgrad_partial<<<nblk, 256, hsh, st>>>(dl1, feats, n_points, M, num_classes, partial);

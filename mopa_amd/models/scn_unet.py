@@ -81,9 +81,15 @@ class UNetSCN(nn.Module):
     def __init__(self, in_channels, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7,
                  pretrained=False):
         super().__init__()
-        if m not in (16, 32, 64):
-            raise NotImplementedError("m must be 16, 32 or 64 (MFMA tile width; the output-head kernels split a row over "
-                                      "m/4 lanes, a power of two <= 16); the reference ships m=16")
+        # Any width the kernels can run (the reference accepts any m, scn_unet.py:11,23, and ships 16): rows are moved as float4
+        # (m % 4), the sparse weight-gradient kernel holds at most 112 output channels (the widest level: m * num_planes), and the
+        # widest convolution input -- the join [skip | up] in front of a decoder block, 2 * m * (num_planes - 1) channels -- must fit
+        # the convolution kernels: 224 channels for the MFMA-tiled kernels (all channel counts multiples of 16), 192 otherwise.
+        widest_in = max(2 * m * (num_planes - 1), m * num_planes, in_channels)
+        if m <= 0 or m % 4 or m > 64 or m * num_planes > 112 or widest_in > (224 if m % 16 == 0 else 192):
+            raise NotImplementedError(f"UNetSCN(m={m}, num_planes={num_planes}): need m % 4 == 0, m <= 64, m * num_planes <= 112 and "
+                                      f"2 * m * (num_planes - 1) <= {224 if m % 16 == 0 else 192} (m = 4, 8, 12, 16 with the shipped 7 "
+                                      "levels; the reference ships m = 16)")
         self.in_channels, self.out_channels = in_channels, m
         self.m, self.block_reps, self.full_scale, self.num_planes = m, block_reps, full_scale, num_planes
         self.residual_blocks = bool(residual_blocks)

@@ -136,7 +136,7 @@ def test_spconv_fwd_wgrad_dgrad_vs_oracle(cin, cout):
         assert torch.equal(dx2.t, dx.t)
 
 
-@pytest.mark.parametrize("C,rows", [(16, 5000), (48, 777), (192, 300), (32, 1)])
+@pytest.mark.parametrize("C,rows", [(16, 5000), (48, 777), (192, 300), (32, 1), (8, 4000), (12, 3000), (24, 2500), (36, 900), (72, 500)])
 def test_bnrelu_rows_fwd_bwd_vs_oracle(C, rows):
     from mopa_amd import sparse3d as s3
     rng = np.random.Generator(np.random.PCG64(C + rows))
@@ -171,7 +171,7 @@ def test_bnrelu_rows_fwd_bwd_vs_oracle(C, rows):
         np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1, residual=False):
+def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1, residual=False, m=16):
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_3d
     cfg = default_cfg(C, dual)
@@ -179,6 +179,7 @@ def _build_3d(num_planes, in_channels=1, C=5, dual=True, block_reps=1, residual=
     cfg.MODEL_3D.SCN.in_channels = in_channels
     cfg.MODEL_3D.SCN.block_reps = block_reps
     cfg.MODEL_3D.SCN.residual_blocks = residual
+    cfg.MODEL_3D.SCN.m = m
     model, _ = build_model_3d(cfg)
     sd = model.state_dict()
     model.load_state_dict({k: det_tensor_like(k, v) for k, v in sd.items()})
@@ -190,7 +191,7 @@ def det_tensor_like(k, v):
     return det_tensor(k, v.shape)
 
 
-def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64, residual=False):
+def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=4096, block_reps=1, dtype=torch.float64, residual=False, m=16):
     P = {k: v.detach().cpu().to(dtype).clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
     for k in P:
         if "running" not in k:
@@ -198,7 +199,7 @@ def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=40
     og = scn3d.Geometry(coords, num_planes, full_scale)
     f = feats.to(dtype).clone().requires_grad_(True)
     out = scn3d.net3dseg_forward(P, og, f, dual_head="linear2.weight" in P, training=training, num_planes=num_planes,
-                                 block_reps=block_reps, residual_blocks=residual)
+                                 block_reps=block_reps, residual_blocks=residual, m=m)
     if gouts is not None:
         sum((out[k] * gouts[k].to(dtype)).sum() for k in out).backward()
     return P, f, out
@@ -209,9 +210,32 @@ def _oracle_run(model, coords, feats, num_planes, training, gouts, full_scale=40
 def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training, residual):
     """residual=True: scn.UNet's ResNet-style blocks (ConcatTable(Identity | NetworkInNetwork, BN-SubM-BN-SubM) + AddTable),
     the `residual_blocks=True` constructor variant of mopa/models/scn_unet.py:14,28."""
+    _check_net3dseg(num_planes, in_ch, reps, training, residual)
+
+
+@pytest.mark.parametrize("m,num_planes,residual,seed", [(8, 7, False, 7), (12, 4, True, 8), (4, 3, False, 7), (32, 3, False, 7), (8, 4, True, 8)])
+def test_net3dseg_other_widths_vs_oracle(m, num_planes, residual, seed):
+    """UNetSCN(m) for widths other than the shipped 16 (mopa/models/scn_unet.py:11,23 accept any m; config/xmuda.py:219 ships 16):
+    channel counts that are not multiples of 16 run the dense-table kernels, the output heads split a row over m/4 lanes rounded up
+    to a power of two.  Same comparison as the m = 16 variants: fp64 oracle, fp32 oracle as the yardstick.  (The cloud seed is part of
+    the case: on some clouds ONE activation sits within fp32 round-off of zero in front of a ReLU and its mask bit differs between the
+    fp32 and the fp64 pass -- seed 7 for the residual variants, seed 8 for m = 32: one element of one BatchNorm bias gradient off
+    by that element's dy, everything else at 1e-6; profiles/dbg_width.py prints the per-parameter errors for any seed.)"""
+    _check_net3dseg(num_planes, 1, 1, True, residual, m=m, seed=seed)
+
+
+def test_unetscn_refuses_widths_the_kernels_cannot_run():
+    from mopa_amd.models.scn_unet import UNetSCN
+    for bad in (dict(m=6), dict(m=20, num_planes=7), dict(m=32, num_planes=7)):
+        with pytest.raises(NotImplementedError):
+            UNetSCN(1, **bad)
+    UNetSCN(1, m=32, num_planes=3)
+
+
+def _check_net3dseg(num_planes, in_ch, reps, training, residual, m=16, seed=7):
     torch.manual_seed(0)
-    c = _cloud(7, n=6000, size=120 if num_planes == 7 else 48)
-    model = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual)
+    c = _cloud(seed, n=6000, size=120 if num_planes == 7 else 48)
+    model = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual, m=m)
     model.train(training)
     rng = np.random.Generator(np.random.PCG64(5))
     feats = torch.from_numpy(rng.random((c.shape[0], in_ch), dtype=np.float32) + 0.5)
@@ -223,7 +247,7 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training, 
         old, scn3d.BN_MOMENTUM = scn3d.BN_MOMENTUM, 1.0
         try:
             scn3d.net3dseg_forward(P0, scn3d.Geometry(c, num_planes), feats.double(), training=True,
-                                   num_planes=num_planes, block_reps=reps, residual_blocks=residual)
+                                   num_planes=num_planes, block_reps=reps, residual_blocks=residual, m=m)
         finally:
             scn3d.BN_MOMENTUM = old
         model.load_state_dict({k: v.float() for k, v in P0.items()})
@@ -232,13 +256,13 @@ def test_net3dseg_forward_backward_vs_oracle(num_planes, in_ch, reps, training, 
     out = model({"x": [torch.from_numpy(c), f_dev]})
     gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
     sum((out[k] * gouts[k].cuda()).sum() for k in out).backward()
-    model_ref = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual)
+    model_ref = _build_3d(num_planes, in_ch, block_reps=reps, residual=residual, m=m)
     model_ref.load_state_dict(sd_before)
-    P, f, ref = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, residual=residual)
+    P, f, ref = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, residual=residual, m=m)
     # yardstick: the same oracle in fp32 -- the HIP path (fp32) may differ from the fp64 truth by a small multiple of
     # what plain fp32 torch-CPU arithmetic differs by (summation-order noise grows with depth).
     model_ref.load_state_dict(sd_before)
-    P32, f32, ref32 = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, dtype=torch.float32, residual=residual)
+    P32, f32, ref32 = _oracle_run(model_ref, c, feats, num_planes, training, gouts, block_reps=reps, dtype=torch.float32, residual=residual, m=m)
 
     def close(got, truth, yard, what):
         scale = max(1e-6, float(np.abs(truth).max()))
