@@ -81,15 +81,14 @@ class UNetSCN(nn.Module):
     def __init__(self, in_channels, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7,
                  pretrained=False):
         super().__init__()
-        # Any width the kernels can run (the reference accepts any m, scn_unet.py:11,23, and ships 16): rows are moved as float4
-        # (m % 4), the sparse weight-gradient kernel holds at most 112 output channels (the widest level: m * num_planes), and the
-        # widest convolution input -- the join [skip | up] in front of a decoder block, 2 * m * (num_planes - 1) channels -- must fit
-        # the convolution kernels: 224 channels for the MFMA-tiled kernels (all channel counts multiples of 16), 192 otherwise.
-        widest_in = max(2 * m * (num_planes - 1), m * num_planes, in_channels)
-        if m <= 0 or m % 4 or m > 64 or m * num_planes > 112 or widest_in > (224 if m % 16 == 0 else 192):
-            raise NotImplementedError(f"UNetSCN(m={m}, num_planes={num_planes}): need m % 4 == 0, m <= 64, m * num_planes <= 112 and "
-                                      f"2 * m * (num_planes - 1) <= {224 if m % 16 == 0 else 192} (m = 4, 8, 12, 16 with the shipped 7 "
-                                      "levels; the reference ships m = 16)")
+        # The reference accepts any m (scn_unet.py:11,23) and ships 16.  Constructing is always possible for m % 4 == 0 (rows are moved
+        # as float4; state_dict names / shapes: tests/test_scn_structure.py); RUNNING needs widths the kernels hold -- the sparse
+        # weight-gradient kernel at most 112 output channels (the widest level: m * num_planes), the widest convolution input (the
+        # join [skip | up] in front of a decoder block: 2 * m * (num_planes - 1) channels) at most 224 channels in the MFMA-tiled
+        # kernels (every channel count a multiple of 16), 192 otherwise: m = 4, 8, 12, 16 with the shipped 7 levels.
+        if m <= 0 or m % 4:
+            raise NotImplementedError(f"UNetSCN(m={m}): m must be a positive multiple of 4 (the reference ships m = 16)")
+        self.not_runnable = self.why_not_runnable(in_channels, m, num_planes)
         self.in_channels, self.out_channels = in_channels, m
         self.m, self.block_reps, self.full_scale, self.num_planes = m, block_reps, full_scale, num_planes
         self.residual_blocks = bool(residual_blocks)
@@ -131,8 +130,20 @@ class UNetSCN(nn.Module):
         U(sm.put(2, _Slot()), planes)
         sm.put(3, _BNParams(m))
 
+    @staticmethod
+    def why_not_runnable(in_channels, m, num_planes):
+        """None, or the reason the HIP kernels cannot run this width (checked at the first forward, not at construction)."""
+        widest_in = max(2 * m * (num_planes - 1), m * num_planes, in_channels)
+        limit = 224 if m % 16 == 0 else 192
+        if m > 64 or m * num_planes > 112 or widest_in > limit:
+            return (f"UNetSCN(m={m}, num_planes={num_planes}): the sparse-conv kernels need m <= 64, m * num_planes <= 112 and "
+                    f"2 * m * (num_planes - 1) <= {limit} (m = 4, 8, 12, 16 with the shipped 7 levels; the reference ships m = 16)")
+        return None
+
     def geometry(self, locs, group_points=None) -> sparse3d.Geometry3D:
         """group_points: see Geometry3D (two groups of scans in one batch, BatchNorm per group)."""
+        if self.not_runnable:
+            raise NotImplementedError(self.not_runnable)
         dev = next(self.parameters()).device
         return sparse3d.Geometry3D(locs, self.num_planes, self.full_scale, dev, group_points=group_points)
 

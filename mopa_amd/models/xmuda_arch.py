@@ -221,6 +221,8 @@ class Net3DSeg(_CachedParams, nn.Module):
         # statistics, running updates and gradients per group in that order, everything else on the joint batch
         # (sparse3d.Geometry3D.split).  A geometry passed in must have been built the same way.
         gp = data_batch.get("bn_group_points") if isinstance(data_batch, dict) else None
+        if self.net_3d.not_runnable:
+            raise NotImplementedError(self.net_3d.not_runnable)
         if geom is None:
             with torch.cuda.device(dev):
                 geom = self.net_3d.geometry(locs, group_points=gp)

@@ -224,14 +224,6 @@ def test_net3dseg_other_widths_vs_oracle(m, num_planes, residual, seed):
     _check_net3dseg(num_planes, 1, 1, True, residual, m=m, seed=seed)
 
 
-def test_unetscn_refuses_widths_the_kernels_cannot_run():
-    from mopa_amd.models.scn_unet import UNetSCN
-    for bad in (dict(m=6), dict(m=20, num_planes=7), dict(m=32, num_planes=7)):
-        with pytest.raises(NotImplementedError):
-            UNetSCN(1, **bad)
-    UNetSCN(1, m=32, num_planes=3)
-
-
 def _check_net3dseg(num_planes, in_ch, reps, training, residual, m=16, seed=7):
     torch.manual_seed(0)
     c = _cloud(seed, n=6000, size=120 if num_planes == 7 else 48)

@@ -188,3 +188,18 @@ def test_native_executor_tables_follow_the_program():
         order = [int(r[1]) for r in plan]
         assert order == sorted(order, reverse=True)            # ... in reverse program order
         assert plan[nt["stem_step"], 0] == 1 and names[plan[nt["stem_step"], 1]].endswith("sparseModel.1")
+
+
+def test_unetscn_width_limits_are_stated_not_discovered_at_a_kernel_launch():
+    """The reference accepts any m (mopa/models/scn_unet.py:11,23); the product constructs every m % 4 == 0 (names and shapes as
+    pinned above) and says at the first forward -- not in a kernel's error code -- when the HIP kernels cannot run the width."""
+    from mopa_amd.models.scn_unet import UNetSCN
+    with pytest.raises(NotImplementedError):
+        UNetSCN(1, m=6)
+    for ok in (dict(m=4), dict(m=8), dict(m=12), dict(m=16), dict(m=32, num_planes=3), dict(m=16, in_channels=4)):
+        assert UNetSCN(ok.pop("in_channels", 1), **ok).not_runnable is None
+    for bad in (dict(m=20), dict(m=32), dict(m=32, num_planes=5), dict(m=64, num_planes=2)):
+        net = UNetSCN(1, **bad)
+        assert "sparse-conv kernels need" in net.not_runnable
+        with pytest.raises(NotImplementedError):
+            net.geometry(None)
