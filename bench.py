@@ -378,6 +378,14 @@ def main():
             for p in m.parameters():
                 dist.broadcast(p.data, 0)
     opts = [FlatAdam(m.parameters(), lr=1e-3) for m in models]
+    # 2D network under a process group: the 94.5 MB flat gradient goes out as 4 contiguous buckets in backward order, each all-reduced
+    # on a communication stream from the point of the backward pass where its last gradient kernel is enqueued (decoder + heads and
+    # layer4 are final ~20 ms before the stem).  MOPA_BENCH_BUCKETS=0: one collective behind the backward pass.
+    n_buckets = int(os.environ.get("MOPA_BENCH_BUCKETS", "4"))
+    bucket_bytes = None
+    if joint and multi and n_buckets > 1:
+        from mopa_amd import dense2d as _d2
+        bucket_bytes = opts[1].enable_buckets(n_buckets, extra_streams=lambda: [_d2.wgrad_stream(dev)])
     cw = torch.tensor(CLASS_WEIGHTS_KITTI if kitti else CLASS_WEIGHTS, device=dev)
     H, W = 302, 480
 
@@ -541,6 +549,7 @@ def main():
             # losses only (event), not behind that backward.
             ready = torch.cuda.Event()
             ready.record()
+            opts[1].arm_buckets()   # the last 2D backward of the iteration: its gradient buckets are reduced as they complete
             l2.backward()
             with dual.on_side(o2["seg_logit"], after=ready):
                 l3 = loss_3d()
@@ -553,6 +562,8 @@ def main():
                 l3 = loss_3d()
             if tl is not None:
                 tl.mark("losses_done")
+            if not supervised:
+                opts[1].arm_buckets()   # target half = the last 2D backward of the iteration
             l2.backward()
             if tl is not None:
                 tl.mark("bwd2d_end")
@@ -682,6 +693,7 @@ def main():
         l2 = loss_2d_of(o2s, o3[0], bs, lam_src, True) + loss_2d_of(o2t, o3[1], bt, lam_trg, False)
         ev = torch.cuda.Event()
         ev.record()
+        opts[1].arm_buckets()                   # (no-op without a process group)
         l2.backward()                           # main stream: the 2D backward of both halves
         if tl is not None:
             tl.mark("bwd2d_end", main)
@@ -1112,6 +1124,7 @@ def main():
                        # layer; "dgrad,wgrad" = exact-product forward pass)
                        "backend": (dist.get_backend() if multi else None),
                        "allreduces_per_step": round(sum(o.n_collectives for o in opts) / max(1, steps_run[0]), 2),
+                       "gradient_buckets_2d_bytes": bucket_bytes,
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
                        else "python walk (MOPA_SCN_NATIVE=0)",

@@ -220,6 +220,11 @@ class _Workspace:
 workspace = _Workspace()
 
 
+# id(parameter) -> callable(parameter): "every kernel that writes this parameter's gradient in this backward pass has been enqueued"
+# (FlatAdam's gradient buckets: mopa_amd/optim.py::FlatAdam.enable_buckets).  Empty unless an optimizer asked for it.
+GRAD_DONE_HOOKS = {}
+
+
 class GradSink:
     """Where the parameter gradients of one backward pass go.
 
@@ -229,10 +234,13 @@ class GradSink:
     Otherwise a fresh tensor is returned to autograd as usual.  ``MOPA_DIRECT_GRADS=0`` forces the second path.
     """
 
-    def __init__(self, params: dict, order):
-        self.params, self.order = params, list(order)
+    def __init__(self, params: dict, order, defer_hooks=False):
+        """defer_hooks: the caller takes every gradient buffer BEFORE it enqueues the kernels (the native 3D executor builds its
+        pointer tables first): "gradient enqueued" is then reported once, at returned()."""
+        self.params, self.order, self.defer_hooks = params, list(order), defer_hooks
         self.ret = {k: None for k in self.order}
         self.direct = os.environ.get("MOPA_DIRECT_GRADS", "1") != "0"
+        self._pending = []   # attached parameters handed out by the previous take(): their kernels are enqueued when the next one starts
 
     def _attached(self, p):
         g = p.grad
@@ -242,7 +250,11 @@ class GradSink:
     def take(self, *names):
         """-> ([gradient tensors], accumulate flag) for parameters that one kernel call writes together."""
         ps = [self.params[n] for n in names]
+        if GRAD_DONE_HOOKS and not self.defer_hooks:
+            self.flush()
         if all(self._attached(p) for p in ps):
+            if GRAD_DONE_HOOKS and not self.defer_hooks:
+                self._pending = ps
             return [p.grad for p in ps], True
         ts = []
         for n, p in zip(names, ps):
@@ -251,7 +263,18 @@ class GradSink:
             ts.append(self.ret[n])
         return ts, False
 
+    def flush(self, final=False):
+        """The kernels of everything handed out so far are enqueued: tell whoever watches these parameters."""
+        for p in self._pending:
+            h = GRAD_DONE_HOOKS.get(id(p))
+            if h is not None:
+                h(p, final)
+        self._pending = []
+
     def returned(self):
+        if GRAD_DONE_HOOKS:   # end of the backward pass: every parameter of this network is final, taken or not (a head without a loss)
+            self._pending = list(self.params.values())
+            self.flush(final=True)
         return tuple(self.ret[k] for k in self.order)
 
 

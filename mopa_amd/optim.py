@@ -20,10 +20,21 @@ import os
 import torch
 import torch.distributed as dist
 
-from ._lib import WEIGHTS_EPOCH, call, ptr, stream
+from ._lib import GRAD_DONE_HOOKS, WEIGHTS_EPOCH, call, ptr, stream
 
 # MOPA_FORCE_COLLECTIVES=1: issue the all-reduce in a one-rank process group too (exercises the RCCL path on a 1-GPU box)
 _FORCE_COLLECTIVES = os.environ.get("MOPA_FORCE_COLLECTIVES") == "1"
+
+
+class _Works:
+    """Several asynchronous collectives behind the one `work.wait()` the callers use."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -106,15 +117,121 @@ class FlatAdam(torch.optim.Optimizer):
         self.grad.zero_()
         self._checked = False
 
+    def _collectives_on(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
+
     def all_reduce(self, async_op=False):
-        """Sum the flat gradient over ranks (RCCL when the process group backend is 'nccl')."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
-            self._check_grads()
-            self._checked = True   # once per iteration (~0.1 ms of host time for 200 parameters)
-            self.n_collectives += 1
-            self.collective_backend = dist.get_backend()
-            return dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=async_op)
-        return None
+        """Sum the flat gradient over ranks (RCCL when the process group backend is 'nccl').  With armed buckets (enable_buckets +
+        arm_buckets): the buckets whose all-reduce the backward pass has issued already are only waited for (the current stream
+        waits for the communication stream; the host does not block), the others are issued now."""
+        if not self._collectives_on():
+            return None
+        self._check_grads()
+        self._checked = True   # once per iteration (~0.1 ms of host time for 200 parameters)
+        self.collective_backend = dist.get_backend()
+        if self._armed:
+            for b in range(len(self._buckets)):
+                if not self._bucket_issued[b]:
+                    self._issue_bucket(b)
+            self._armed = False
+            cur = torch.cuda.current_stream(self.grad.device) if self.grad.is_cuda else None
+            works, self._bucket_works = self._bucket_works, []
+            if async_op:
+                return _Works(works)
+            for w in works:
+                w.wait()
+            if cur is not None and self._comm is not None:
+                cur.wait_stream(self._comm)
+            return None
+        self.n_collectives += 1
+        return dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    # ---- gradient buckets: the flat buffer cut into contiguous ranges in BACKWARD order, each all-reduced as soon as the backward
+    # pass has enqueued the last kernel that writes into it -- the collective of the layers that finish first (decoder, layer4)
+    # runs on a communication stream under the rest of the backward pass.  One flat buffer stays the optimizer's view.
+    _armed = False
+    _buckets = ()
+    _comm = None
+
+    def enable_buckets(self, n_buckets=4, extra_streams=None):
+        """Cut the flat gradient buffer into `n_buckets` contiguous ranges of about equal size; bucket 0 holds the LAST parameters
+        (their gradients are final first).  `extra_streams`: callable -> streams besides the current one that gradient kernels
+        run on (the 2D weight-gradient stream); a bucket's collective is ordered behind all of them.  Takes effect for a
+        backward pass only after arm_buckets()."""
+        n_par = len(self.params)
+        target = self.n / max(1, n_buckets)
+        cuts, acc = [n_par], 0
+        for i in range(n_par - 1, -1, -1):     # walk the parameters in backward order
+            acc += self._slices[i][1]
+            if acc >= target and len(cuts) < n_buckets and i > 0:
+                cuts.append(i)
+                acc = 0
+        cuts.append(0)
+        self._buckets = []                     # (first parameter, one past the last, flat offset lo, hi)
+        for hi_p, lo_p in zip(cuts[:-1], cuts[1:]):
+            if lo_p == hi_p:
+                continue
+            lo = self._slices[lo_p][0]
+            hi = self.n if hi_p == n_par else self._slices[hi_p][0]
+            self._buckets.append((lo_p, hi_p, lo, hi))
+        self._bucket_of = {}
+        for b, (lo_p, hi_p, _, _) in enumerate(self._buckets):
+            for i in range(lo_p, hi_p):
+                self._bucket_of[id(self.params[i])] = b
+        self._extra_streams = extra_streams
+        self._comm = torch.cuda.Stream(device=self.grad.device) if self.grad.is_cuda else None
+        self._bucket_works, self._bucket_issued, self._bucket_left = [], [False] * len(self._buckets), [0] * len(self._buckets)
+        return [(hi - lo) * 4 for _, _, lo, hi in self._buckets]
+
+    def arm_buckets(self):
+        """Call right before the LAST backward pass of the iteration (gradients of earlier passes accumulate first: the reference
+        runs the source and the target half before the optimizer step, train_xmuda_mopa.py:342-427)."""
+        if not self._buckets or not self._collectives_on():
+            return False
+        self._check_grads()
+        self._checked = True
+        self._armed = True
+        self._bucket_works = []
+        self._bucket_issued = [False] * len(self._buckets)
+        self._bucket_left = [hi_p - lo_p for lo_p, hi_p, _, _ in self._buckets]
+        self._done_ids = set()
+        for p in self.params:
+            GRAD_DONE_HOOKS[id(p)] = self._grad_done
+        return True
+
+    def _grad_done(self, p, final=False):
+        """GradSink: the kernels writing p's gradient in this backward pass are enqueued (reported once per parameter: a parameter
+        two kernels write -- the 2D head's point and pixel parts -- is reported after the first; its bucket also holds the decoder
+        layers that follow both in stream order, and a bucket that went out before a late writer is refused below)."""
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        if id(p) in self._done_ids:
+            if self._bucket_issued[b] and not final:
+                raise RuntimeError("FlatAdam buckets: a gradient was written after its bucket's all-reduce had been issued")
+            return
+        self._done_ids.add(id(p))
+        self._bucket_left[b] -= 1
+        # buckets go out in order (every rank issues the same sequence of collectives): bucket b only once b - 1 is out
+        while b < len(self._buckets) and self._bucket_left[b] <= 0 and not self._bucket_issued[b] and (b == 0 or self._bucket_issued[b - 1]):
+            self._issue_bucket(b)
+            b += 1
+
+    def _issue_bucket(self, b):
+        _, _, lo, hi = self._buckets[b]
+        self._bucket_issued[b] = True
+        self.n_collectives += 1
+        self.collective_backend = dist.get_backend()
+        view = self.grad[lo:hi]
+        if self._comm is None:
+            self._bucket_works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        self._comm.wait_stream(torch.cuda.current_stream(self.grad.device))
+        for st in (self._extra_streams() if self._extra_streams is not None else ()):
+            if st is not None:
+                self._comm.wait_stream(st)
+        with torch.cuda.stream(self._comm):
+            self._bucket_works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0, closure=None):

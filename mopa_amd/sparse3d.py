@@ -731,7 +731,7 @@ def _native_backward(ctx, dfeats, dl1, dl2):
     dev = geom.device
     N, m, C = geom.n_points, spec.m, spec.num_classes
     A = geom.num_active
-    sink = GradSink(P, spec.order)
+    sink = GradSink(P, spec.order, defer_hooks=True)   # (the pointer tables below take every gradient before the one native call)
 
     def cont(t):
         return None if t is None else t.contiguous().float()

@@ -105,6 +105,29 @@ def main():
             failures.append(f"{tag}: a one-rank all-reduce changed the flat gradient buffer")
         if not torch.isfinite(opt.flat).all():
             failures.append(f"{tag}: parameters not finite after the update")
+
+        # the same gradient through 3 buckets issued from inside the backward pass on the communication stream (FlatAdam.enable_buckets):
+        # every bucket goes out before backward() returns, and a one-rank sum leaves the buffer equal to the un-bucketed gradient
+        opt.enable_buckets(3)
+        opt.zero_grad()
+        o = ml(batch)
+        (o["seg_logit"] * ups[0]).sum().backward()      # un-bucketed reference at the updated weights
+        ref = opt.grad.clone()
+        opt.zero_grad()
+        n0 = opt.n_collectives
+        o = ml(batch)
+        loss_b = (o["seg_logit"] * ups[0]).sum()
+        if not opt.arm_buckets():
+            failures.append(f"{tag}: arm_buckets refused under a process group")
+        loss_b.backward()
+        early, left = sum(opt._bucket_issued), list(opt._bucket_left)
+        opt.all_reduce()
+        torch.cuda.synchronize()
+        if early != 3 or opt.n_collectives - n0 != 3:
+            failures.append(f"{tag}: {early} of 3 buckets issued inside the backward pass (gradients still missing per bucket: {left}), "
+                            f"{opt.n_collectives - n0} collectives")
+        if not torch.equal(opt.grad, ref):
+            failures.append(f"{tag}: the bucketed all-reduce changed the flat gradient buffer")
     dist.barrier()
     dist.destroy_process_group()
     if failures:

@@ -147,3 +147,70 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout        # exactly one JSON line, from rank 0
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["dry"] is True and line["distinct_scans"] is True and line["loss_weight_rank0"] == 1.0
+
+
+def _bucket_worker(rank, world, port, q):
+    """Gradient buckets (FlatAdam.enable_buckets): the flat buffer all-reduced as 4 contiguous ranges, each issued from inside the
+    backward pass when GradSink reports its last gradient kernel enqueued -- must equal the single flat all-reduce bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mopa_amd._lib import GradSink
+    from mopa_amd.optim import FlatAdam
+
+    def make():
+        g = torch.Generator().manual_seed(3)
+        names = [f"layer{i}.weight" for i in range(11)]
+        shapes = [(7, 5), (13,), (3, 3, 3), (64,), (2, 9), (31,), (5, 5), (17,), (4, 4, 4), (6,), (10, 3)]
+        return names, [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+
+    def fill(params):   # rank-dependent gradients, written in place like the HIP kernels do
+        g = torch.Generator().manual_seed(100 + rank)
+        return [torch.randn(p.shape, generator=g) for p in params]
+
+    names, pa = make()
+    _, pb = make()
+    oa, ob = FlatAdam(pa, lr=1e-3), FlatAdam(pb, lr=1e-3)
+    sizes = ob.enable_buckets(4)
+    oa.zero_grad(); ob.zero_grad()
+    ga = fill(pa)
+    for p, g in zip(pa, ga):
+        p.grad.copy_(g)
+    oa.all_reduce()                                   # reference: ONE collective
+    # bucketed: a "backward pass" that hands the parameters out in reverse order, two at a time, through GradSink
+    armed = ob.arm_buckets()
+    sink = GradSink(dict(zip(names, pb)), names)
+    issued_during_backward = []
+    for i in range(len(pb) - 1, -1, -2):
+        group = [names[j] for j in (i, i - 1) if j >= 0]
+        gs, acc = sink.take(*group)
+        assert acc
+        for n_, gbuf in zip(group, gs):
+            gbuf.copy_(ga[names.index(n_)])
+        issued_during_backward.append(sum(ob._bucket_issued))
+    sink.returned()
+    early = sum(ob._bucket_issued)
+    ob.all_reduce()
+    same = torch.equal(oa.grad, ob.grad)
+    # a second iteration re-arms cleanly; un-armed passes use the single collective
+    n_before = ob.n_collectives
+    ob.zero_grad()
+    ob.all_reduce()
+    q.put((rank, armed and same, len(sizes), early, issued_during_backward, ob.n_collectives - n_before, oa.n_collectives))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_equals_the_flat_one_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, nb, early, trace, later, flat_calls in res:
+        assert ok, f"rank {rank}: bucketed result differs from the flat all-reduce"
+        assert nb == 4 and early == 4, (nb, early)                # every bucket went out from inside the backward pass ...
+        assert trace[0] == 0 and trace == sorted(trace) and trace[-1] >= 2, trace   # ... progressively, not all at the end
+        assert later == 1 and flat_calls == 1

@@ -33,7 +33,9 @@ def _launch(script_args, timeout):
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
-def test_bench_joint_step_one_rank_over_rccl():
+@pytest.mark.parametrize("buckets", [4, 0])
+def test_bench_joint_step_one_rank_over_rccl(buckets, monkeypatch):
+    monkeypatch.setenv("MOPA_BENCH_BUCKETS", str(buckets))
     r = _launch([os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"], 900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -41,7 +43,12 @@ def test_bench_joint_step_one_rank_over_rccl():
     d = json.loads(lines[0])      # bench.py asserts a finite loss before it prints
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"]["backend"] == "nccl"                 # the process group is RCCL ...
-    assert d["config"]["allreduces_per_step"] == 2.0        # ... and both flat gradient buffers went through it in every step
+    # ... and every step's gradients went through it: the 3D network's flat buffer as one collective (asynchronous, side stream), the 2D
+    # network's as 4 buckets issued from inside its backward pass on a communication stream (or as one collective behind it)
+    assert d["config"]["allreduces_per_step"] == (5.0 if buckets else 2.0), d["config"]["allreduces_per_step"]
+    if buckets:
+        bb = d["config"]["gradient_buckets_2d_bytes"]
+        assert len(bb) == 4 and sum(bb) >= 4 * 23_614_794 and max(bb) < 2 * min(bb) + 8_000_000, bb
     assert d["roofline"] is not None and d["roofline_sparse_conv"] is not None
 
 
