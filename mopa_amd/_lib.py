@@ -82,6 +82,8 @@ SIGNATURES = {
     "mopa_output_layer_heads_bwd": ("i", "ppppppppiiiipippppipzp"),
     "mopa_bn_act_fwd": ("i", "pipiiippppfffipiippzp"),
     "mopa_bn_act_bwd": ("i", "pipipiiipfipipiiippiipzp"),
+    "mopa_bn_act_fwd_groups": ("i", "pipiiiiiippppfffipiippzp"),
+    "mopa_bn_act_bwd_groups": ("i", "pipipiiiiiipfipipiiippiipzp"),
     "mopa_bn_sync_moments": ("i", "piiippzp"),
     "mopa_bn_act_fwd_sync": ("i", "pipiiippppfffipipipp"),
     "mopa_bn_sync_bwd_sums": ("i", "pipiiipfipippippzp"),

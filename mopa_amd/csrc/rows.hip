@@ -17,19 +17,52 @@ static inline int bn_rows_per_block(int64_t num_rows) {
 }
 static inline int bn_num_blocks(int64_t num_rows) { return (int)cdiv64(num_rows, bn_rows_per_block(num_rows)); }
 
+// Up to three consecutive row ranges of one tensor that BatchNorm treats as separate batches (the source / target / VGI batch of
+// one iteration in one pass: mopa_amd Net2DSeg "bn_groups", Net3DSeg "bn_group_points").  One launch per kernel serves all groups
+// (blockIdx.y = group): a layer is 3 launches per direction instead of 3 per group.  Every group keeps the block partition its
+// own call would have (rows per block from ITS row count), so the sums -- and the results -- are bit-identical to per-group calls.
+#define BN_MAX_GROUPS 3
+struct BnGroups {
+  int n;
+  int row0[BN_MAX_GROUPS], rows[BN_MAX_GROUPS], rpb[BN_MAX_GROUPS], nblk[BN_MAX_GROUPS], poff[BN_MAX_GROUPS];  // poff: first partial block
+  int nblk_max, nblk_total;
+};
+static inline bool bn_make_groups(BnGroups* g, int num_rows, int n_groups, int split1, int split2) {
+  if (n_groups < 1 || n_groups > BN_MAX_GROUPS || num_rows <= 0) return false;
+  const int b[4] = {0, n_groups > 1 ? split1 : num_rows, n_groups > 2 ? split2 : num_rows, num_rows};
+  g->n = n_groups;
+  g->nblk_max = g->nblk_total = 0;
+  for (int k = 0; k < BN_MAX_GROUPS; ++k) { g->row0[k] = g->rows[k] = g->nblk[k] = g->poff[k] = 0; g->rpb[k] = 1; }
+  for (int k = 0; k < n_groups; ++k) {
+    const int r0 = b[k], r1 = k == n_groups - 1 ? num_rows : b[k + 1];
+    if (r1 <= r0) return false;
+    g->row0[k] = r0; g->rows[k] = r1 - r0;
+    g->rpb[k] = bn_rows_per_block(r1 - r0);
+    g->nblk[k] = bn_num_blocks(r1 - r0);
+    g->poff[k] = g->nblk_total;
+    g->nblk_total += g->nblk[k];
+    if (g->nblk[k] > g->nblk_max) g->nblk_max = g->nblk[k];
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------ BN statistics
 // partial[blk][0][c] = sum(x - x0), partial[blk][1][c] = sum((x - x0)^2) with x0 = first row (shifted sums keep
 // fp32 accurate when |mean| >> std).  C % 4 == 0.
-__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int ld, int A, int C, int rpb,
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ x, int ld, int C, const BnGroups grp,
                                                            float* __restrict__ partial) {
   extern __shared__ float lds[];  // [2][RL][C]
+  const int gi = blockIdx.y;
+  if ((int)blockIdx.x >= grp.nblk[gi]) return;
   const int CQ = C >> 2;
   const int RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-  const int rbeg = blockIdx.x * rpb, rend = min(A, rbeg + rpb);
+  const int rpb = grp.rpb[gi];
+  const int rbeg = grp.row0[gi] + blockIdx.x * rpb, rend = min(grp.row0[gi] + grp.rows[gi], rbeg + rpb);
+  partial += (int64_t)grp.poff[gi] * 2 * C;
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (rl < RL) {
-    const float4 k = *reinterpret_cast<const float4*>(x + cq * 4);
+    const float4 k = *reinterpret_cast<const float4*>(x + (int64_t)grp.row0[gi] * ld + cq * 4);
     for (int row = rbeg + rl; row < rend; row += RL) {
       const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ld + cq * 4);
       float d0 = v.x - k.x, d1 = v.y - k.y, d2 = v.z - k.z, d3 = v.w - k.w;
@@ -69,12 +102,21 @@ __device__ __forceinline__ void bn_block_sum2(const float* __restrict__ partial,
   s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
   ss = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
 }
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int nblk, const float* __restrict__ x0, int A, int C,
+// Groups are finalised one after the other by the same block: the running statistics see them in call order.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial_all, const BnGroups grp, const float* __restrict__ x_all,
+                              int ldx, int C,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                              float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
-                              float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                              float eps, int training, float* __restrict__ stats_all) {
   const int c = blockIdx.x;
+ for (int gi = 0; gi < grp.n; ++gi) {
+  const float* __restrict__ partial = partial_all + (int64_t)grp.poff[gi] * 2 * C;
+  const float* __restrict__ x0 = x_all + (int64_t)grp.row0[gi] * ldx;
+  const int nblk = grp.nblk[gi], A = grp.rows[gi];
+  float* __restrict__ scale = stats_all + (int64_t)gi * 4 * C;
+  float* __restrict__ shift = scale + C;
+  float* __restrict__ save_mean = scale + 2 * C;
+  float* __restrict__ save_invstd = scale + 3 * C;
   float mean, var;
   if (training) {
     double s, ss;
@@ -101,21 +143,25 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     save_mean[c] = mean;
     save_invstd[c] = invstd;
   }
+  __syncthreads();   // (bn_block_sum2's shared scratch is re-used by the next group; thread 0's running statistics are ordered by it too)
+ }
 }
 
 // y = act(x*scale + shift (+ res));  act: 0 = identity, 1 = leaky-ReLU(leak).
 // Thread = (row lane rl, channel quad cq): the per-channel constants live in registers and the thread walks rows
 // rl, rl + RL*grid, ... -- no per-element constant loads, no 64-bit division (the grid-stride form was TA-bound at 2.7 TB/s).
 __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ x, int ldx, float* __restrict__ y,
-                                                        int ldy, int A, int C, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float leak,
-                                                        const float* __restrict__ res, int ld_res, int act) {
+                                                        int ldy, const BnGroups grp, int C, const float* __restrict__ stats_all,
+                                                        float leak, const float* __restrict__ res, int ld_res, int act) {
   const int CQ = C >> 2, RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
   if (rl >= RL) return;
+  const int gi = blockIdx.y;
+  const float* __restrict__ scale = stats_all + (int64_t)gi * 4 * C;
   const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
-  const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
-  for (int row = blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
+  const float4 sh = *reinterpret_cast<const float4*>(scale + C + cq * 4);
+  const int A = grp.row0[gi] + grp.rows[gi];
+  for (int row = grp.row0[gi] + blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
     const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
@@ -141,32 +187,48 @@ static inline int bn_apply_grid(int64_t num_rows, int C) {
 }
 
 MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
-  return align_up((size_t)bn_num_blocks(num_rows) * 2 * C * sizeof(float), 256);
+  // partial blocks of a grouped call: every group partitions its own rows (>= 32 rows per block, <= 2048 blocks per group)
+  int64_t nb = (int64_t)num_rows / 32 + BN_MAX_GROUPS;
+  if (nb > BN_MAX_GROUPS * 2048) nb = BN_MAX_GROUPS * 2048;
+  if (nb < bn_num_blocks(num_rows)) nb = bn_num_blocks(num_rows);
+  return align_up((size_t)nb * 2 * C * sizeof(float), 256);
 }
 
 // y = act(batchnorm(x) (+ res)).  stats[4][C] receives scale, shift, mean, invstd (saved for backward).
 // act: 0 identity / 1 leaky-ReLU(leak).  res (optional) is added before the activation (ResNet BasicBlock tail).
+// n_groups (1..3) consecutive row ranges [0, split1), [split1, split2), [split2, num_rows) are normalised as separate batches, in that
+// order (running statistics: group 0 first); stats = [n_groups][4][C].  (Workspace: mopa_bnrelu_rows_workspace_bytes of the whole
+// tensor + one block per extra group.)
+MOPA_API int mopa_bn_act_fwd_groups(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
+                                    int32_t n_groups, int32_t split1, int32_t split2,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float leak, int32_t act, const float* res, int32_t ld_res,
+                                    int32_t training, float* stats, void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
+  if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
+  BnGroups grp;
+  if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  if (training) {
+    if (ws_bytes < (size_t)grp.nblk_total * 2 * C * sizeof(float)) return MOPA_ERR_WORKSPACE;
+    const int RL = 256 / (C >> 2);
+    if (RL < 1) return MOPA_ERR_ARG;
+    k_bn_stats_partial<<<dim3(grp.nblk_max, grp.n), 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, C, grp, partial);
+  }
+  k_bn_finalize<<<C, 256, 0, st>>>(partial, grp, x, ldx, C, gamma, beta, running_mean, running_var, momentum, eps, training, stats);
+  int maxrows = 0;
+  for (int k = 0; k < grp.n; ++k) maxrows = grp.rows[k] > maxrows ? grp.rows[k] : maxrows;
+  k_bn_relu_apply<<<dim3(bn_apply_grid(maxrows, C), grp.n), 256, 0, st>>>(x, ldx, y, ldy, grp, C, stats, leak, res, ld_res, act);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
 MOPA_API int mopa_bn_act_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
                              const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float momentum, float eps, float leak, int32_t act, const float* res, int32_t ld_res,
                              int32_t training, float* stats, void* ws, size_t ws_bytes, void* stream) {
-  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
-  if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = bn_num_blocks(num_rows);
-  float* partial = (float*)ws;
-  if (training) {
-    if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
-    const int RL = 256 / (C >> 2);
-    if (RL < 1) return MOPA_ERR_ARG;
-    k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, bn_rows_per_block(num_rows), partial);
-  }
-  k_bn_finalize<<<C, 256, 0, st>>>(partial, nblk, x, num_rows, C, gamma, beta, running_mean, running_var, momentum,
-                                   eps, training, stats, stats + C, stats + 2 * C, stats + 3 * C);
-  k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats,
-                                                                                  stats + C, leak, res, ld_res, act);
-  MOPA_CHECK_LAUNCH();
-  return MOPA_OK;
+  return mopa_bn_act_fwd_groups(x, ldx, y, ldy, num_rows, C, 1, 0, 0, gamma, beta, running_mean, running_var, momentum, eps, leak, act,
+                                res, ld_res, training, stats, ws, ws_bytes, stream);
 }
 
 MOPA_API int mopa_bnrelu_rows_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
@@ -187,15 +249,20 @@ __device__ __forceinline__ float bn_dz(float g, float xv, float sc, float sh, fl
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, int ld_dy,
-                                                         const float* __restrict__ x, int ldx, int A, int C,
+                                                         const float* __restrict__ x, int ldx, int C,
                                                          const float* __restrict__ stats, float leak,
-                                                         const float* __restrict__ ymask, int ld_ym, int act, int rpb,
+                                                         const float* __restrict__ ymask, int ld_ym, int act, const BnGroups grp,
                                                          float* __restrict__ partial) {
   extern __shared__ float lds[];
+  const int gi = blockIdx.y;
+  if ((int)blockIdx.x >= grp.nblk[gi]) return;
   const int CQ = C >> 2;
   const int RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-  const int rbeg = blockIdx.x * rpb, rend = min(A, rbeg + rpb);
+  const int rpb = grp.rpb[gi];
+  const int rbeg = grp.row0[gi] + blockIdx.x * rpb, rend = min(grp.row0[gi] + grp.rows[gi], rbeg + rpb);
+  partial += (int64_t)grp.poff[gi] * 2 * C;
+  stats += (int64_t)gi * 4 * C;
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (rl < RL) {
     float sc[4], sh[4], mu[4], is[4];
@@ -233,24 +300,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
 }
 
 // dgamma/dbeta (+= if accumulate) and the two per-channel means used by the apply pass (coef[2][C]).
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int A, int C,
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial_all, const BnGroups grp, int C,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                                          float* __restrict__ coef) {
-  const int c = blockIdx.x;   // one block per channel (see k_bn_finalize)
-  double s, ss;
-  bn_block_sum2(partial, nblk, C, c, s, ss);
-  if (threadIdx.x == 0) {
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
-    coef[c] = (float)(s / A);
-    coef[C + c] = (float)(ss / A);
+                                                          float* __restrict__ coef_all) {
+  const int c = blockIdx.x;   // one block per channel (see k_bn_finalize); the groups' parameter gradients add up in group order
+  for (int gi = 0; gi < grp.n; ++gi) {
+    double s, ss;
+    bn_block_sum2(partial_all + (int64_t)grp.poff[gi] * 2 * C, grp.nblk[gi], C, c, s, ss);
+    if (threadIdx.x == 0) {
+      dbeta[c] = ((accumulate || gi > 0) ? dbeta[c] : 0.f) + (float)s;
+      dgamma[c] = ((accumulate || gi > 0) ? dgamma[c] : 0.f) + (float)ss;
+      coef_all[(int64_t)gi * 2 * C + c] = (float)(s / grp.rows[gi]);
+      coef_all[(int64_t)gi * 2 * C + C + c] = (float)(ss / grp.rows[gi]);
+    }
+    __syncthreads();
   }
 }
 
 // training: dx = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = scale * dz.   dx (+)= if acc_dx.
 // dres (optional) receives dz, the gradient of the residual input (+= if acc_dres).
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x,
-                                                       int ldx, float* __restrict__ dx, int ld_dx, int A, int C,
+                                                       int ldx, float* __restrict__ dx, int ld_dx, const BnGroups grp, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ coef,
                                                        float leak, int training, int acc_dx, const float* __restrict__ ymask,
                                                        int ld_ym, int act, float* __restrict__ dres, int ld_dres, int acc_dres) {
@@ -258,6 +328,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   const int CQ = C >> 2, RL = 256 / CQ;
   const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
   if (rl >= RL) return;
+  const int gi = blockIdx.y;
+  stats += (int64_t)gi * 4 * C;
+  coef += (int64_t)gi * 2 * C;
   float sc[4], sh[4], mean[4], inv[4], c0[4], c1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -265,7 +338,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     sc[j] = stats[c]; sh[j] = stats[C + c]; mean[j] = stats[2 * C + c]; inv[j] = stats[3 * C + c];
     c0[j] = coef[c]; c1[j] = coef[C + c];
   }
-  for (int row = blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
+  const int A = grp.row0[gi] + grp.rows[gi];
+  for (int row = grp.row0[gi] + blockIdx.x * RL + rl; row < A; row += gridDim.x * RL) {
     const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
     const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
     float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,33 +375,45 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 }
 
 MOPA_API size_t mopa_bnrelu_rows_bwd_workspace_bytes(int32_t num_rows, int32_t C) {
-  return mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)2 * C * sizeof(float), 256);
+  return mopa_bnrelu_rows_workspace_bytes(num_rows, C) + align_up((size_t)BN_MAX_GROUPS * 2 * C * sizeof(float), 256);
 }
 
 // General backward of mopa_bn_act_fwd.  ymask: the forward output y (required when a residual was added; optional
 // otherwise).  dres: gradient of the residual input (optional).
+// The grouped form: stats = the forward's [n_groups][4][C]; the groups' parameter gradients add up in group order.
+MOPA_API int mopa_bn_act_bwd_groups(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
+                                    int32_t num_rows, int32_t C, int32_t n_groups, int32_t split1, int32_t split2, const float* stats,
+                                    float leak, int32_t act, const float* ymask, int32_t ld_ym, float* dres, int32_t ld_dres,
+                                    int32_t accumulate_dres, int32_t training, float* dgamma, float* dbeta,
+                                    int32_t accumulate_param_grads, int32_t accumulate_dx, void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3))
+    return MOPA_ERR_ARG;
+  if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_bnrelu_rows_bwd_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+  BnGroups grp;
+  if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
+  const int RL = 256 / (C >> 2);
+  k_bn_bwd_partial<<<dim3(grp.nblk_max, grp.n), 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, C, stats, leak, ymask,
+                                                                                               ld_ym, act, grp, partial);
+  k_bn_bwd_finalize<<<C, 256, 0, st>>>(partial, grp, C, dgamma, dbeta, accumulate_param_grads, coef);
+  int maxrows = 0;
+  for (int k = 0; k < grp.n; ++k) maxrows = grp.rows[k] > maxrows ? grp.rows[k] : maxrows;
+  k_bn_bwd_apply<<<dim3(bn_apply_grid(maxrows, C), grp.n), 256, 0, st>>>(
+      dy, ld_dy, x, ldx, dx, ld_dx, grp, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
+      ld_dres, accumulate_dres);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
 MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
                              int32_t num_rows, int32_t C, const float* stats, float leak, int32_t act,
                              const float* ymask, int32_t ld_ym, float* dres, int32_t ld_dres, int32_t accumulate_dres,
                              int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads,
                              int32_t accumulate_dx, void* ws, size_t ws_bytes, void* stream) {
-  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ld_dx < C || ((ldx | ld_dy | ld_dx) & 3))
-    return MOPA_ERR_ARG;
-  if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
-  if (ws_bytes < mopa_bnrelu_rows_bwd_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = bn_num_blocks(num_rows);
-  float* partial = (float*)ws;
-  float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
-  const int RL = 256 / (C >> 2);
-  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask,
-                                                                          ld_ym, act, bn_rows_per_block(num_rows), partial);
-  k_bn_bwd_finalize<<<C, 256, 0, st>>>(partial, nblk, num_rows, C, dgamma, dbeta, accumulate_param_grads, coef);
-  k_bn_bwd_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(
-      dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef, leak, training, accumulate_dx, ymask, ld_ym, act, dres,
-      ld_dres, accumulate_dres);
-  MOPA_CHECK_LAUNCH();
-  return MOPA_OK;
+  return mopa_bn_act_bwd_groups(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, 1, 0, 0, stats, leak, act, ymask, ld_ym, dres, ld_dres,
+                                accumulate_dres, training, dgamma, dbeta, accumulate_param_grads, accumulate_dx, ws, ws_bytes, stream);
 }
 
 MOPA_API int mopa_bnrelu_rows_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
@@ -405,7 +491,9 @@ MOPA_API int mopa_bn_sync_moments(const float* x, int32_t ldx, int32_t num_rows,
   const int nblk = bn_num_blocks(num_rows), RL = 256 / (C >> 2);
   if (RL < 1) return MOPA_ERR_ARG;
   float* partial = (float*)ws;
-  k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, num_rows, C, bn_rows_per_block(num_rows), partial);
+  BnGroups one;
+  bn_make_groups(&one, num_rows, 1, 0, 0);
+  k_bn_stats_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, C, one, partial);
   k_bn_local_moments<<<C, 256, 0, st>>>(partial, nblk, x, num_rows, C, moments);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
@@ -424,8 +512,11 @@ MOPA_API int mopa_bn_act_fwd_sync(const float* x, int32_t ldx, float* y, int32_t
   hipStream_t st = (hipStream_t)stream;
   k_bn_finalize_sync<<<(C + 255) / 256, 256, 0, st>>>(gathered, world, C, gamma, beta, running_mean, running_var, momentum, eps, stats,
                                                       stats + C, stats + 2 * C, stats + 3 * C);
-  if (num_rows > 0)
-    k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, num_rows, C, stats, stats + C, leak, res, ld_res, act);
+  if (num_rows > 0) {
+    BnGroups one;
+    bn_make_groups(&one, num_rows, 1, 0, 0);
+    k_bn_relu_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(x, ldx, y, ldy, one, C, stats, leak, res, ld_res, act);
+  }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -461,8 +552,9 @@ MOPA_API int mopa_bn_sync_bwd_sums(const float* dy, int32_t ld_dy, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int nblk = bn_num_blocks(num_rows), RL = 256 / (C >> 2);
   float* partial = (float*)ws;
-  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, num_rows, C, stats, leak, ymask, ld_ym, act,
-                                                                          bn_rows_per_block(num_rows), partial);
+  BnGroups one;
+  bn_make_groups(&one, num_rows, 1, 0, 0);
+  k_bn_bwd_partial<<<nblk, 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, C, stats, leak, ymask, ld_ym, act, one, partial);
   k_bn_bwd_local_sums<<<C, 256, 0, st>>>(partial, nblk, C, dgamma, dbeta, accumulate_param_grads, sums);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
@@ -480,7 +572,9 @@ MOPA_API int mopa_bn_act_bwd_sync(const float* dy, int32_t ld_dy, const float* x
   if ((ymask && (ld_ym < C || (ld_ym & 3))) || (dres && (ld_dres < C || (ld_dres & 3)))) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   k_bn_bwd_coef_sync<<<(2 * C + 255) / 256, 256, 0, st>>>(sums_global, gathered, world, C, coef_ws);
-  k_bn_bwd_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(dy, ld_dy, x, ldx, dx, ld_dx, num_rows, C, stats, coef_ws, leak, 1,
+  BnGroups one;
+  bn_make_groups(&one, num_rows, 1, 0, 0);
+  k_bn_bwd_apply<<<bn_apply_grid(num_rows, C), 256, 0, st>>>(dy, ld_dy, x, ldx, dx, ld_dx, one, C, stats, coef_ws, leak, 1,
                                                              accumulate_dx, ymask, ld_ym, act, dres, ld_dres, accumulate_dres);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

@@ -219,10 +219,10 @@ MOPA_API int mopa_scn_forward(const int32_t* prog_host, int32_t n_ops, const int
       const int64_t* p = params_host + i * 4;
       int r0[SCN_MAX_GROUPS], r1[SCN_MAX_GROUPS];
       const int ng = bn_groups(geom_host, o[OP_LSRC], src.rows, r0, r1);
-      for (int g = 0; g < ng && !rc; ++g)
-        rc = mopa_bnrelu_rows_fwd(src.p + (int64_t)r0[g] * src.ld, src.ld, dst.p + (int64_t)r0[g] * dst.ld, dst.ld, r1[g] - r0[g], src.C,
-                                  (const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], momentum, eps, leak, training,
-                                  stats + (int64_t)NG * o[OP_ABUF] + g * 4 * src.C, ws, ws_bytes, st);
+      // all groups of the layer in one set of launches (bit-identical to one call per row range: rows.hip::BnGroups)
+      rc = mopa_bn_act_fwd_groups(src.p, src.ld, dst.p, dst.ld, src.rows, src.C, ng, r1[0], ng > 1 ? r1[1] : 0, (const float*)p[0],
+                                  (const float*)p[1], (float*)p[2], (float*)p[3], momentum, eps, leak, 1, nullptr, 0, training,
+                                  stats + (int64_t)NG * o[OP_ABUF], ws, ws_bytes, st);
     } else if (o[OP_KIND] == K_CONV) {
       const int l = o[OP_LSRC] < o[OP_LDST] ? o[OP_LSRC] : o[OP_LDST];
       const Table t = table_of(geom_host, o[OP_CKIND], l, false);
@@ -291,10 +291,10 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
     if (pl[PL_KIND] == K_BN) {
       int r0[SCN_MAX_GROUPS], r1[SCN_MAX_GROUPS];
       const int ng = bn_groups(geom_host, o[OP_LSRC], x.rows, r0, r1);
-      for (int k = 0; k < ng && !rc; ++k)   // (the parameter gradients of the groups add up)
-        rc = mopa_bnrelu_rows_bwd(dy.p + (int64_t)r0[k] * dy.ld, dy.ld, x.p + (int64_t)r0[k] * x.ld, x.ld, dx.p + (int64_t)r0[k] * dx.ld, dx.ld,
-                                  r1[k] - r0[k], x.C, stats + (int64_t)NG * o[OP_ABUF] + k * 4 * x.C, leak, training, (float*)g[0],
-                                  (float*)g[1], (int)g[2] || k > 0, pl[PL_ACC], ws, ws_bytes, st);
+      // (the parameter gradients of the groups add up, in group order)
+      rc = mopa_bn_act_bwd_groups(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, ng, r1[0], ng > 1 ? r1[1] : 0,
+                                  stats + (int64_t)NG * o[OP_ABUF], leak, 1, nullptr, 0, nullptr, 0, 0, training, (float*)g[0], (float*)g[1],
+                                  (int)g[2], pl[PL_ACC], ws, ws_bytes, st);
       if (rc) break;
       continue;
     }

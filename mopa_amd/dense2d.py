@@ -463,6 +463,9 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
     call("mopa_colsum", x.p, x.ld, x.rows, x.C, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream())
 
 
+GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the BatchNorm groups of one pass in one set of launches
+
+
 def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
     """Returns None, or -- synchronised BatchNorm (mopa_amd.syncbn) in training mode -- the gathered moments for bn_bwd."""
     if training and syncbn.active():
@@ -474,6 +477,28 @@ def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
          ptr(P[name + ".running_mean"]), ptr(P[name + ".running_var"]), BN_MOMENTUM, BN_EPS, 0.0, int(act),
          res.p if res is not None else None, res.ld if res is not None else 0, int(training), ptr(stats), ptr(ws),
          ws.numel(), stream())
+
+
+def bn_fwd_groups(x: View, y: View, P, name, act, res, training, stats, G):
+    """bn_fwd for G consecutive, equally sized row groups of one tensor in ONE set of launches (3 instead of 3 G): statistics, running
+    updates (group 0 first) and the apply per group, bit-identical to G calls of bn_fwd on the row ranges.  stats: (G, 4, C)."""
+    n = x.rows // G
+    wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bn_act_fwd_groups", x.p, x.ld, y.p, y.ld, x.rows, x.C, G, n, 2 * n, ptr(P[name + ".weight"]), ptr(P[name + ".bias"]),
+         ptr(P[name + ".running_mean"]), ptr(P[name + ".running_var"]), BN_MOMENTUM, BN_EPS, 0.0, int(act),
+         res.p if res is not None else None, res.ld if res is not None else 0, int(training), ptr(stats), ptr(ws),
+         ws.numel(), stream())
+
+
+def bn_bwd_groups(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, G, acc_params=False):
+    n = x.rows // G
+    wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    call("mopa_bn_act_bwd_groups", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, G, n, 2 * n, ptr(stats), 0.0, int(act),
+         ymask.p if ymask is not None else None, ymask.ld if ymask is not None else 0,
+         dres.p if dres is not None else None, dres.ld if dres is not None else 0, int(acc_dres), int(training),
+         ptr(dgamma), ptr(dbeta), int(acc_params), 0, ptr(ws), ws.numel(), stream())
 
 
 def bn_bwd(dy: View, x: View, dx: View, stats, act, ymask, dres, acc_dres, training, dgamma, dbeta, acc_dx=False,
@@ -519,8 +544,12 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
     def bn(name, x, act=1, res=None, out=None):
         y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
         stats = torch.empty(G, 4, x.C, dtype=torch.float32, device=dev)
-        gathered = [bn_fwd(_group(x, g, G), _group(y, g, G), P, name, act, None if res is None else _group(res, g, G), training,
-                           stats[g]) for g in range(G)]
+        if G > 1 and not (training and syncbn.active()) and GROUPED_BN:
+            bn_fwd_groups(x, y, P, name, act, res, training, stats, G)     # one set of launches for all groups
+            gathered = [None] * G
+        else:
+            gathered = [bn_fwd(_group(x, g, G), _group(y, g, G), P, name, act, None if res is None else _group(res, g, G), training,
+                               stats[g]) for g in range(G)]
         if training:
             nbt.append(P[name + ".num_batches_tracked"])
         tape.append(("bn", name, x, y, stats, act, res, gathered))
@@ -652,10 +681,13 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             dx = like(x)
             gmap[key(x)] = dx
             (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
-            for g in range(G):
-                bn_bwd(_group(dy, g, G), _group(x, g, G), _group(dx, g, G), stats[g], act,
-                       _group(y, g, G) if res is not None else None, None if dres is None else _group(dres, g, G), acc_dres, training,
-                       dg, db, acc_params=pacc or g > 0, gathered=gathered[g])
+            if G > 1 and GROUPED_BN and all(gt is None for gt in gathered):
+                bn_bwd_groups(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, training, dg, db, G, acc_params=pacc)
+            else:
+                for g in range(G):
+                    bn_bwd(_group(dy, g, G), _group(x, g, G), _group(dx, g, G), stats[g], act,
+                           _group(y, g, G) if res is not None else None, None if dres is None else _group(dres, g, G), acc_dres, training,
+                           dg, db, acc_params=pacc or g > 0, gathered=gathered[g])
         elif kind == "conv":
             _, name, op, x, out, V = rec
             dout = gmap.pop(key(out))

@@ -386,6 +386,29 @@ def bnrelu_fwd(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats
          BN_MOMENTUM, BN_EPS, LEAK, int(training), ptr(stats), ptr(ws), ws.numel(), stream())
 
 
+def _splits(groups):
+    s = [r1 for _, r1 in groups[:-1]] + [0, 0]
+    return s[0], s[1]
+
+
+def bnrelu_fwd_groups(x: View, y: View, gamma, beta, rmean, rvar, training: bool, stats: torch.Tensor, groups):
+    """All row groups of one layer in one set of launches (3 kernels instead of 3 per group); stats: (len(groups), 4, C).  Bit-identical
+    to bnrelu_fwd per row range (csrc/rows.hip::BnGroups) -- what the native executor issues too."""
+    wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    s1, s2 = _splits(groups)
+    call("mopa_bn_act_fwd_groups", x.p, x.ld, y.p, y.ld, x.rows, x.C, len(groups), s1, s2, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+         BN_MOMENTUM, BN_EPS, LEAK, 1, None, 0, int(training), ptr(stats), ptr(ws), ws.numel(), stream())
+
+
+def bnrelu_bwd_groups(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool, acc_params: bool, groups):
+    wsb = query("mopa_bnrelu_rows_bwd_workspace_bytes", x.rows, x.C)
+    ws = _ws(wsb, x.t.device)
+    s1, s2 = _splits(groups)
+    call("mopa_bn_act_bwd_groups", dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.rows, x.C, len(groups), s1, s2, ptr(stats), LEAK, 1,
+         None, 0, None, 0, 0, int(training), ptr(dgamma), ptr(dbeta), int(acc_params), int(acc_dx), ptr(ws), ws.numel(), stream())
+
+
 def bnrelu_bwd(dy: View, x: View, dx: View, stats, training: bool, dgamma, dbeta, acc_dx: bool, acc_params: bool = False,
                gathered=None):
     if gathered is not None:   # the forward pass of this layer ran with global statistics
@@ -832,9 +855,14 @@ class SCNNetFunction(torch.autograd.Function):
                 _, name, src, dst = op
                 groups = bn_row_groups(geom, src.level)
                 st = torch.empty(len(groups), 4, src.C, dtype=torch.float32, device=dev)
-                gathered = [bnrelu_fwd(rows_of(view(src), r0, r1), rows_of(view(dst), r0, r1), P[name + ".weight"], P[name + ".bias"],
-                                       P[name + ".running_mean"], P[name + ".running_var"], training, st[g])
-                            for g, (r0, r1) in enumerate(groups)]
+                if training and syncbn.active():   # collectives between the kernels of a layer: one call per group
+                    gathered = [bnrelu_fwd(rows_of(view(src), r0, r1), rows_of(view(dst), r0, r1), P[name + ".weight"], P[name + ".bias"],
+                                           P[name + ".running_mean"], P[name + ".running_var"], training, st[g])
+                                for g, (r0, r1) in enumerate(groups)]
+                else:
+                    bnrelu_fwd_groups(view(src), view(dst), P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                                      P[name + ".running_var"], training, st, groups)
+                    gathered = [None]
                 stats[name] = st
                 if gathered[0] is not None:
                     stats[name + "/moments"] = gathered
@@ -916,10 +944,13 @@ class SCNNetFunction(torch.autograd.Function):
                 _, name, src, dy_ref, dx_ref, acc = step
                 (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
                 moments = ctx.stats.get(name + "/moments")
-                for g, (r0, r1) in enumerate(bn_row_groups(geom, src.level)):   # (the groups' parameter gradients add up)
-                    bnrelu_bwd(rows_of(gview(dy_ref), r0, r1), rows_of(views[src.key], r0, r1), rows_of(gview(dx_ref), r0, r1),
-                               ctx.stats[name][g], ctx.training, dg, db, acc, pacc or g > 0,
-                               gathered=None if moments is None else moments[g])
+                groups = bn_row_groups(geom, src.level)
+                if moments is None:
+                    bnrelu_bwd_groups(gview(dy_ref), views[src.key], gview(dx_ref), ctx.stats[name], ctx.training, dg, db, acc, pacc, groups)
+                else:
+                    for g, (r0, r1) in enumerate(groups):   # (the groups' parameter gradients add up)
+                        bnrelu_bwd(rows_of(gview(dy_ref), r0, r1), rows_of(views[src.key], r0, r1), rows_of(gview(dx_ref), r0, r1),
+                                   ctx.stats[name][g], ctx.training, dg, db, acc, pacc or g > 0, gathered=moments[g])
             else:
                 _, name, kind, l, src, dout_ref, dx_ref = step
                 dout = gview(dout_ref)

@@ -7,7 +7,7 @@ Usage (repo root, after `gpurun -- bash profiles/make_final.sh`): python profile
 import collections, csv, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.abspath(__file__))
 F = os.path.join(R, "..", "gpurun_out", "final")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r4"
 TITLE = {"3d": "Net3DSeg-only training step (bs 8, 1x MI355X) -- BASELINE configs[1]",
          "joint": "joint 2D+3D xMUDA step (bs 8+8, 1x MI355X) -- BASELINE configs[2]",
          "kitti": "A2D2->SemanticKITTI-shape joint step (bs 2+2, 120,000-pt scans, 10 classes, 1x MI355X) -- BASELINE configs[4] per GPU",
