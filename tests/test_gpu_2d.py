@@ -92,6 +92,42 @@ def test_conv_transpose_fwd_bwd():
     _close(db, br.grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("G,C,res", [(2, 64, True), (2, 24, False), (3, 128, True)])
+def test_grouped_batchnorm_is_bit_identical_to_one_call_per_group(G, C, res):
+    """mopa_bn_act_{fwd,bwd}_groups (all row groups of a layer in one set of launches, blockIdx.y = group) against one mopa_bn_act_*
+    call per row range, the form the reference's G separate passes correspond to: outputs, saved statistics, running statistics
+    (updated group after group), input / residual / parameter gradients -- identical bits."""
+    from mopa_amd.dense2d import _group, bn_bwd, bn_bwd_groups, bn_fwd, bn_fwd_groups, new_img
+    rng = np.random.Generator(np.random.PCG64(3 + G + C))
+    B, H, W = 2 * G, 9, 11
+    mk = lambda scale=1.0, shift=0.0: _nhwc(torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32) * scale + shift))  # noqa: E731
+    x, r, g = mk(2.0, 1.0), (mk() if res else None), mk()
+    def params():
+        return {"bn.weight": torch.linspace(0.5, 1.5, C).cuda(), "bn.bias": torch.linspace(-1, 1, C).cuda(),
+                "bn.running_mean": torch.zeros(C, device="cuda"), "bn.running_var": torch.ones(C, device="cuda")}
+    Pa, Pb = params(), params()
+    ya, yb = new_img(B, H, W, C, "cuda"), new_img(B, H, W, C, "cuda")
+    sa, sb = torch.empty(G, 4, C, device="cuda"), torch.empty(G, 4, C, device="cuda")
+    for k in range(G):
+        bn_fwd(_group(x, k, G), _group(ya, k, G), Pa, "bn", 1, None if r is None else _group(r, k, G), True, sa[k])
+    bn_fwd_groups(x, yb, Pb, "bn", 1, r, True, sb, G)
+    assert torch.equal(ya.t, yb.t) and torch.equal(sa, sb)
+    assert torch.equal(Pa["bn.running_mean"], Pb["bn.running_mean"]) and torch.equal(Pa["bn.running_var"], Pb["bn.running_var"])
+    out = []
+    for grouped in (False, True):
+        dx, dres = new_img(B, H, W, C, "cuda"), (new_img(B, H, W, C, "cuda") if res else None)
+        dg, db = torch.full((C,), 0.25, device="cuda"), torch.full((C,), -0.5, device="cuda")   # accumulate into existing values
+        if grouped:
+            bn_bwd_groups(g, x, dx, sb, 1, yb if res else None, dres, False, True, dg, db, G, acc_params=True)
+        else:
+            for k in range(G):
+                bn_bwd(_group(g, k, G), _group(x, k, G), _group(dx, k, G), sa[k], 1, _group(ya, k, G) if res else None,
+                       None if dres is None else _group(dres, k, G), False, True, dg, db, acc_params=True)
+        out.append((dx.t.clone(), None if dres is None else dres.t.clone(), dg, db))
+    for a, b in zip(*out):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
 def test_maxpool_and_residual_bn():
     from mopa_amd._lib import call, ptr, stream
     from mopa_amd.dense2d import bn_bwd, bn_fwd, new_img
