@@ -38,37 +38,57 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
     *reinterpret_cast<uchar4*>(idx + o * C + cq * 4) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
   }
 }
-// Gather-form backward (no atomics): each input pixel sums the <= 4 windows that contain it and point at it.
+// Gather-form backward (no atomics).  One thread per 2 x 2 block of input pixels and channel quad: the block (rows 2a, 2a+1, columns
+// 2b, 2b+1) lies under exactly the four windows (a, b), (a, b+1), (a+1, b), (a+1, b+1) -- an even row or column under one of them,
+// an odd one under two -- so four (argmax, dy) pairs serve four outputs (one thread per input pixel loaded nine pairs for the same
+// four: 2.2 TB/s).  The sums are taken in the same window order as before (oy then ox ascending): same bits.
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ dy, int ld_dy, const unsigned char* __restrict__ idx,
                                                       int B, int H, int W, int C, float* __restrict__ dx, int ld_dx, int accumulate) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2, CQ = C >> 2;
-  const int64_t total = (int64_t)B * H * W * CQ;
+  const int HB = (H + 1) / 2, WB = (W + 1) / 2;   // 2 x 2 blocks
+  const int64_t total = (int64_t)B * HB * WB * CQ;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cq = (int)(i % CQ);
     int64_t r = i / CQ;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H), b = (int)(r / H);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    // windows with oy*2-1+ky == iy, ky in 0..2  ->  oy in {(iy+1)/2, iy/2 ...}
-    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
-      const int ky = iy - (oy * 2 - 1);
-      if (oy >= OH || ky < 0 || ky > 2) continue;
-      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-        const int kx = ix - (ox * 2 - 1);
-        if (ox >= OW || kx < 0 || kx > 2) continue;
-        const int64_t o = ((int64_t)(b * OH + oy) * OW + ox);
-        const uchar4 w = *reinterpret_cast<const uchar4*>(idx + o * C + cq * 4);
-        const float4 g = *reinterpret_cast<const float4*>(dy + o * ld_dy + cq * 4);
-        const int tap = ky * 3 + kx;
-        if (w.x == tap) s[0] += g.x;
-        if (w.y == tap) s[1] += g.y;
-        if (w.z == tap) s[2] += g.z;
-        if (w.w == tap) s[3] += g.w;
+    const int bx = (int)(r % WB); r /= WB;
+    const int by = (int)(r % HB), b = (int)(r / HB);
+    float4 g[2][2];
+    uchar4 w[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int oy = by + a, ox = bx + c;
+        if (oy < OH && ox < OW) {
+          const int64_t o = ((int64_t)(b * OH + oy) * OW + ox);
+          w[a][c] = *reinterpret_cast<const uchar4*>(idx + o * C + cq * 4);
+          g[a][c] = *reinterpret_cast<const float4*>(dy + o * ld_dy + cq * 4);
+        } else {
+          w[a][c] = make_uchar4(255, 255, 255, 255);
+          g[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
-    }
-    float4* p = reinterpret_cast<float4*>(dx + ((int64_t)(b * H + iy) * W + ix) * ld_dx + cq * 4);
-    if (accumulate) { const float4 q = *p; s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w; }
-    *p = make_float4(s[0], s[1], s[2], s[3]);
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int iy = 2 * by + py, ix = 2 * bx + px;
+        if (iy >= H || ix >= W) continue;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a <= py; ++a)        // window rows containing iy: by (tap row 1 + py) and, for the odd row, by + 1 (tap row 0)
+#pragma unroll
+          for (int c = 0; c <= px; ++c) {
+            const int tap = (a == 0 ? 1 + py : 0) * 3 + (c == 0 ? 1 + px : 0);
+            if (w[a][c].x == tap) s[0] += g[a][c].x;
+            if (w[a][c].y == tap) s[1] += g[a][c].y;
+            if (w[a][c].z == tap) s[2] += g[a][c].z;
+            if (w[a][c].w == tap) s[3] += g[a][c].w;
+          }
+        float4* p = reinterpret_cast<float4*>(dx + ((int64_t)(b * H + iy) * W + ix) * ld_dx + cq * 4);
+        if (accumulate) { const float4 q = *p; s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w; }
+        *p = make_float4(s[0], s[1], s[2], s[3]);
+      }
   }
 }
 MOPA_API int mopa_maxpool3x3s2_fwd(const float* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, float* y,
@@ -82,8 +102,8 @@ MOPA_API int mopa_maxpool3x3s2_fwd(const float* x, int32_t ldx, int32_t B, int32
 MOPA_API int mopa_maxpool3x3s2_bwd(const float* dy, int32_t ld_dy, const uint8_t* argmax, int32_t B, int32_t H, int32_t W,
                                    int32_t C, float* dx, int32_t ld_dx, int32_t accumulate, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ld_dx < C || ld_dy < C || ((ld_dx | ld_dy) & 3)) return MOPA_ERR_ARG;
-  k_maxpool_bwd<<<stream_grid((int64_t)B * H * W * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(dy, ld_dy, argmax, B, H, W, C,
-                                                                                                  dx, ld_dx, accumulate);
+  k_maxpool_bwd<<<stream_grid((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(
+      dy, ld_dy, argmax, B, H, W, C, dx, ld_dx, accumulate);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -152,6 +172,20 @@ MOPA_API int mopa_dropout_rows_dseed(const float* x, int32_t ldx, float* y, int3
 // pixel's row is ONE coalesced 256-byte read across its lanes, each lane keeps its float4 of every W[k] in registers and a
 // 4-step shuffle tree sums the partial dot products (round 1: one thread per pixel walked the 256-B row by itself and the
 // kernel moved 5.5x its algorithmic bytes -- profiles/r1_joint_hbm_traffic.json).
+// Sum over the MQ (power of two) consecutive lanes of a pixel, result in all of them.  Up to 16 lanes = one DPP row: four VALU
+// instructions with a data-parallel-primitive operand (quad swaps, half-row mirror, row mirror) instead of four ds_bpermute round
+// trips through the LDS crossbar per class -- the round-1..3 kernel issued 20 of those per pixel and ran at 1.8 TB/s.
+template <int CTRL> __device__ __forceinline__ float ph_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ph_lane_sum(float v, int MQ) {
+  if (MQ >= 2) v = ph_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (MQ >= 4) v = ph_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (MQ >= 8) v = ph_dpp_add<0x141>(v);   // row_half_mirror
+  if (MQ >= 16) v = ph_dpp_add<0x140>(v);  // row_mirror
+  for (int o = 16; o < MQ; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __global__ __launch_bounds__(256) void k_pixel_head_fwd(const float* __restrict__ x, int ld, int B, int Hp, int Wp, int H, int W,
                                                          int M, int NC, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ pred) {
@@ -166,25 +200,32 @@ __global__ __launch_bounds__(256) void k_pixel_head_fwd(const float* __restrict_
   }
   const int PPB = 256 / MQ;                    // pixels per block and iteration
   const int64_t total = (int64_t)B * H * W;
-  for (int64_t i = (int64_t)blockIdx.x * PPB + threadIdx.x / MQ; i < total; i += (int64_t)gridDim.x * PPB) {
-    const int wq = (int)(i % W);
-    const int64_t r = i / W;
-    const int h = (int)(r % H), b = (int)(r / H);
-    const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * Hp + h) * Wp + wq) * ld + cq * 4);
-    float acc[PH_MAXNC];
+  // PH_UN pixels per lane group and iteration: their row reads are issued back to back (one 16-byte load in flight per lane left
+  // the kernel waiting on HBM latency: 16 KB per CU in flight)
+  constexpr int PH_UN = 4;
+  const int64_t step = (int64_t)gridDim.x * PPB;
+  for (int64_t i0 = (int64_t)blockIdx.x * PPB + threadIdx.x / MQ; i0 < total; i0 += step * PH_UN) {
+    float4 v[PH_UN];
 #pragma unroll
-    for (int k = 0; k < PH_MAXNC; ++k) {
-      acc[k] = 0.f;
-      if (k < NC) {   // uniform
-        acc[k] = fmaf(v.x, wr[k].x, fmaf(v.y, wr[k].y, fmaf(v.z, wr[k].z, v.w * wr[k].w)));
-        for (int o = MQ >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
-      }
+    for (int u = 0; u < PH_UN; ++u) {
+      const int64_t i = i0 + u * step < total ? i0 + u * step : total - 1;   // (clamped: an in-bounds read, result not stored)
+      const int wq = (int)(i % W);
+      const int64_t r = i / W;
+      const int h = (int)(r % H), b = (int)(r / H);
+      v[u] = *reinterpret_cast<const float4*>(x + ((int64_t)(b * Hp + h) * Wp + wq) * ld + cq * 4);
     }
-    if (cq < NC) {
+#pragma unroll
+    for (int u = 0; u < PH_UN; ++u) {
+      const int64_t i = i0 + u * step;
       float out = 0.f;
 #pragma unroll
-      for (int k = 0; k < PH_MAXNC; ++k) out = cq == k ? acc[k] + bk[k] : out;
-      pred[i * NC + cq] = out;
+      for (int k = 0; k < PH_MAXNC; ++k) {
+        if (k < NC) {   // uniform
+          const float a = ph_lane_sum(fmaf(v[u].x, wr[k].x, fmaf(v[u].y, wr[k].y, fmaf(v[u].z, wr[k].z, v[u].w * wr[k].w))), MQ);
+          out = cq == k ? a + bk[k] : out;
+        }
+      }
+      if (cq < NC && i < total) pred[i * NC + cq] = out;
     }
   }
 }

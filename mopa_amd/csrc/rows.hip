@@ -722,22 +722,57 @@ __global__ __launch_bounds__(256) void k_output_heads_bwd_rows(const float* __re
                                                                 const float* __restrict__ w2, const int* __restrict__ row_start,
                                                                 const int* __restrict__ row_points, int A, int M, int NC,
                                                                 float* __restrict__ dy, int ld) {
+  // thread = (row, channel quad): one float4 of the row (round 1-3: one thread per ELEMENT -- 64 threads of a 2D row each read the
+  // row's CSR bounds and every class gradient of its points; 1.1 TB/s at 2.3 M mostly empty pixel rows).  HB_UN rows per thread and
+  // iteration, their CSR bounds loaded first.  (Measured and not kept: also prefetching the first point and its gradients of every
+  // row before the arithmetic -- three quarters of the pixel rows are empty, the unconditional loads cost more than the chain: 385 ->
+  // 580 us.  What is left is the dependent chain bounds -> point -> gradients of the rows that do have a point.)
   extern __shared__ float lw[];  // w1[NC][M] | w2[NC][M]
   const int nw = NC * M;
   for (int i = threadIdx.x; i < nw; i += 256) { lw[i] = w1[i]; lw[nw + i] = w2 ? w2[i] : 0.f; }
   __syncthreads();
-  const int64_t total = (int64_t)A * M;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / M), c = (int)(i - (int64_t)row * M);
-    float acc = 0.f;
-    for (int k = row_start[row]; k < row_start[row + 1]; ++k) {
-      const int p = row_points[k];
-      float v = dfeats ? dfeats[(int64_t)p * M + c] : 0.f;
-      if (dl1) for (int j = 0; j < NC; ++j) v = fmaf(dl1[(int64_t)p * NC + j], lw[j * M + c], v);
-      if (dl2) for (int j = 0; j < NC; ++j) v = fmaf(dl2[(int64_t)p * NC + j], lw[nw + j * M + c], v);
-      acc += v;
+  const int MQ = M >> 2;
+  const int64_t total = (int64_t)A * MQ;
+  constexpr int HB_UN = 4;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < total; i0 += step * HB_UN) {
+    int ka[HB_UN], kb[HB_UN];
+#pragma unroll
+    for (int u = 0; u < HB_UN; ++u) {
+      const int64_t i = i0 + u * step;
+      const int row = (int)((i < total ? i : total - 1) / MQ);
+      ka[u] = row_start[row];
+      kb[u] = row_start[row + 1];
     }
-    dy[(int64_t)row * ld + c] = acc;
+#pragma unroll
+    for (int u = 0; u < HB_UN; ++u) {
+      const int64_t i = i0 + u * step;
+      if (i >= total) break;
+      const int row = (int)(i / MQ), cq = (int)(i - (int64_t)row * MQ);
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = ka[u]; k < kb[u]; ++k) {
+        const int p = row_points[k];
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dfeats) {
+          const float4 d = *reinterpret_cast<const float4*>(dfeats + (int64_t)p * M + cq * 4);
+          v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w;
+        }
+        if (dl1)
+          for (int j = 0; j < NC; ++j) {
+            const float g = dl1[(int64_t)p * NC + j];
+            const float* wr = lw + j * M + cq * 4;
+            v[0] = fmaf(g, wr[0], v[0]); v[1] = fmaf(g, wr[1], v[1]); v[2] = fmaf(g, wr[2], v[2]); v[3] = fmaf(g, wr[3], v[3]);
+          }
+        if (dl2)
+          for (int j = 0; j < NC; ++j) {
+            const float g = dl2[(int64_t)p * NC + j];
+            const float* wr = lw + nw + j * M + cq * 4;
+            v[0] = fmaf(g, wr[0], v[0]); v[1] = fmaf(g, wr[1], v[1]); v[2] = fmaf(g, wr[2], v[2]); v[3] = fmaf(g, wr[3], v[3]);
+          }
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      }
+      *reinterpret_cast<float4*>(dy + (int64_t)row * ld + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
   }
 }
 
@@ -814,13 +849,14 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
                                          int32_t num_classes, float* dy, int32_t ld_dy, float* dw1, float* db1,
                                          float* dw2, float* db2, int32_t accumulate, void* ws, size_t ws_bytes,
                                          void* stream) {
-  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > HEAD_MAXNC || ld_dy < M)
+  if (n_points <= 0 || num_rows <= 0 || M <= 0 || M > 64 || (M & 3) || num_classes <= 0 || num_classes > HEAD_MAXNC || ld_dy < M ||
+      (ld_dy & 3) || (((uintptr_t)dy | (uintptr_t)dfeats) & 15))
     return MOPA_ERR_ARG;
   int mqp = 1;
   while (mqp < (M >> 2)) mqp <<= 1;
   if (ws_bytes < mopa_output_layer_heads_bwd_workspace_bytes(n_points, M, num_classes)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  k_output_heads_bwd_rows<<<stream_grid((int64_t)num_rows * M, 256), 256, (size_t)2 * num_classes * M * sizeof(float), st>>>(
+  k_output_heads_bwd_rows<<<stream_grid(cdiv64((int64_t)num_rows * (M >> 2), 4), 256), 256, (size_t)2 * num_classes * M * sizeof(float), st>>>(
       dfeats, dl1, dl2, w1, w2, row_start, row_points, num_rows, M, num_classes, dy, ld_dy);
   const int nblk = (int)cdiv64(n_points, HEAD_PTS_PER_BLOCK);
   float* partial = (float*)ws;
