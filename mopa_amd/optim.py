@@ -174,14 +174,21 @@ class FlatAdam(torch.optim.Optimizer):
             lo = self._slices[lo_p][0]
             hi = self.n if hi_p == n_par else self._slices[hi_p][0]
             self._buckets.append((lo_p, hi_p, lo, hi))
-        self._bucket_of = {}
+        self._bucket_of = {}                   # id(parameter) -> (bucket, parameter index)
         for b, (lo_p, hi_p, _, _) in enumerate(self._buckets):
             for i in range(lo_p, hi_p):
-                self._bucket_of[id(self.params[i])] = b
+                self._bucket_of[id(self.params[i])] = (b, i)
         self._extra_streams = extra_streams
         self._comm = torch.cuda.Stream(device=self.grad.device) if self.grad.is_cuda else None
         self._bucket_works, self._bucket_issued, self._bucket_left = [], [False] * len(self._buckets), [0] * len(self._buckets)
         return [(hi - lo) * 4 for _, _, lo, hi in self._buckets]
+
+    def disable_buckets(self):
+        """Back to one collective per iteration; drops this optimizer's entries from the GradSink hook table."""
+        for p in self.params:
+            if GRAD_DONE_HOOKS.get(id(p)) == self._grad_done:
+                del GRAD_DONE_HOOKS[id(p)]
+        self._buckets, self._armed = (), False
 
     def arm_buckets(self):
         """Call right before the LAST backward pass of the iteration (gradients of earlier passes accumulate first: the reference
@@ -205,7 +212,9 @@ class FlatAdam(torch.optim.Optimizer):
         layers that follow both in stream order, and a bucket that went out before a late writer is refused below)."""
         if not self._armed:
             return
-        b = self._bucket_of[id(p)]
+        b, i = self._bucket_of.get(id(p), (None, None))
+        if b is None or self.params[i] is not p:   # (an id re-issued to another tensor after this optimizer's parameter died)
+            return
         if id(p) in self._done_ids:
             if self._bucket_issued[b] and not final:
                 raise RuntimeError("FlatAdam buckets: a gradient was written after its bucket's all-reduce had been issued")
