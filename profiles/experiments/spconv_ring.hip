@@ -375,6 +375,219 @@ __global__ __launch_bounds__(64 * (4 * T + RG_NLMAX)) void k_spconv_ring(const i
 #endif
 }
 
+// ==================================================================================================================
+// k_spconv_pt4: the persistent form of k_spconv_t4 WITHOUT the weight ring (round 4, second experiment).  The ring kernel above showed
+// that (a) streaming weights through LDS costs more than it saves and (b) its team structure alone only matches k_spconv_t4 because it
+// pays 7-10 k cycles per tile in serial overheads.  This kernel keeps k_spconv_t4's operand path (row gathers AND packed weights straight
+// into a register ring) and its arithmetic, and spends the persistent structure on the one lever that is left: no cold prologue --
+//   * the NEXT tile's metadata is fetched into registers while the current tile's units run and written to LDS when they are done;
+//   * the next tile's first D units of loads are issued BEFORE the team hand-off and the ordered sum of the current tile, so the
+//     gather latency runs under them;
+//   * no s_barrier after start-up (team hand-offs = spin-waits on LDS counters, as above).
+template <int NTW, int NKU, bool PART, int T>
+__global__ __launch_bounds__(256 * T) void k_spconv_pt4(const int* __restrict__ grp_start, const int* __restrict__ grp_o,
+                                                         const int* __restrict__ grp_in, const int* __restrict__ grp_out,
+                                                         int K, int A_out, const float* __restrict__ in, int ld_in, int cin,
+                                                         const float* __restrict__ Wp, int w_flip, float* __restrict__ out,
+                                                         int ld_out, int ntiles, int ncg) {
+  constexpr int D = 2, CP = NTW * 16, LD = CP + RG_PAD, ACCB = 65 * LD * 4, NW = 4 * T;
+  constexpr int MSW = 15, MS1 = MSW + 1, METAB = (MS1 * 100 + 15) / 16 * 16;   // 60 groups of a tile per chunk: ONE pass of 64 lanes x int4 per array
+  static_assert(ACCB < 65536 && ACCB % 16 == 0, "metadata packing");
+  typedef typename RgVec<NTW>::T BT;
+  extern __shared__ float4 smem4[];
+  char* smem = reinterpret_cast<char*>(smem4);
+  const int nkc = cin >> 4;
+  const int NU = (nkc + NKU - 1) / NKU;
+  char* accs = smem;
+  char* metas = accs + NW * ACCB;
+  unsigned* flags = reinterpret_cast<unsigned*>(metas + NW * METAB);
+  unsigned *f_arr = flags, *f_arr2 = flags + 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = blockIdx.x % ncg, bidx = blockIdx.x / ncg, nblk = gridDim.x / ncg;
+  const int nbatch = (ntiles + T - 1) / T;
+  const int rounds = (nbatch + nblk - 1) / nblk;
+  if (tid < 16) flags[tid] = 0u;
+  {
+    float4* a4 = reinterpret_cast<float4*>(accs + wave * ACCB);
+    for (int i = lane; i < 65 * LD / 4; i += 64) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int team = wave >> 2, wv = wave & 3, r = lane & 15, q = lane >> 4;
+  char* acc_c = accs + wave * ACCB;
+  const char* tacc = accs + team * 4 * ACCB;
+  unsigned* m_in = reinterpret_cast<unsigned*>(metas + wave * METAB);
+  unsigned short* m_out = reinterpret_cast<unsigned short*>(metas + wave * METAB + MS1 * 64);
+  unsigned* m_w = reinterpret_cast<unsigned*>(metas + wave * METAB + MS1 * 96);   // [MS1] byte offset of the group's W[o] slice
+  const int G = grp_start[ntiles];
+  const unsigned ld4 = (unsigned)ld_in >> 2;
+  const char* __restrict__ in_b = reinterpret_cast<const char*>(in);
+  const char* __restrict__ wcg = reinterpret_cast<const char*>(Wp) + (size_t)cg * K * cin * CP * 4;
+  const unsigned a_off = (unsigned)(q * 16);
+  const unsigned b_off = (unsigned)(lane * NTW * 16);
+  char* acc_lane = acc_c + r * NTW * 4;
+  float4 A[D][NKU];
+  float4 B[D][NKU][NTW];
+
+  // ---- metadata of (tile, chunk c0) for this wave: global -> registers (pm_*) -> LDS
+  int4 pm_i[1], pm_o[1];
+  int pm_g = 0;
+  auto meta_fetch = [&](int gb, int c0) {
+    {
+      const int h = 0;
+      const int e = lane * 4;
+      const int i = min(e >> 4, MSW);
+      const int g = min(gb + wv + 4 * (c0 + i), G - 1);
+      const int src = g * 16 + (e & 15);
+      pm_i[h] = *reinterpret_cast<const int4*>(grp_in + src);
+      pm_o[h] = *reinterpret_cast<const int4*>(grp_out + src);
+    }
+    pm_g = grp_o[min(gb + wv + 4 * (c0 + min(lane, MSW)), G - 1)];
+  };
+  auto meta_store = [&](int nch) {
+    {
+      const int h = 0;
+      const int e = lane * 4;
+      if (e < MS1 * 16) {
+        const bool dead = (e >> 4) >= nch;
+        const int4 vi = pm_i[h], vo = pm_o[h];
+        uint4 wi;
+        wi.x = dead ? 0u : (unsigned)max(vi.x, 0) * ld4; wi.y = dead ? 0u : (unsigned)max(vi.y, 0) * ld4;
+        wi.z = dead ? 0u : (unsigned)max(vi.z, 0) * ld4; wi.w = dead ? 0u : (unsigned)max(vi.w, 0) * ld4;
+        const unsigned o0 = (unsigned)((dead || vo.x < 0) ? 64 : vo.x) * (LD * 4), o1 = (unsigned)((dead || vo.y < 0) ? 64 : vo.y) * (LD * 4);
+        const unsigned o2 = (unsigned)((dead || vo.z < 0) ? 64 : vo.z) * (LD * 4), o3 = (unsigned)((dead || vo.w < 0) ? 64 : vo.w) * (LD * 4);
+        *reinterpret_cast<uint4*>(m_in + e) = wi;
+        *reinterpret_cast<uint2*>(m_out + e) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+      }
+    }
+    if (lane < MS1) m_w[lane] = lane < nch ? (unsigned)((w_flip ? K - 1 - pm_g : pm_g) * cin * CP * 4) : 0u;
+    asm volatile("" ::: "memory");
+  };
+  auto tile_range = [&](int rd, int& gb, int& nmine) {
+    const int tile = (rd * nblk + bidx) * T + team;
+    gb = 0;
+    int ge = 0;
+    if (rd < rounds && tile < ntiles) { gb = grp_start[tile]; ge = grp_start[tile + 1]; }
+    const int ng = ge - gb;
+    nmine = ng > wv ? (ng - wv + 3) >> 2 : 0;
+  };
+
+  int ig, iku, cgp, cku, nch;
+  unsigned io_n, wo_n;
+  uint2 mo_n;
+#define PT_ISSUE(S)                                                                                        \
+  {                                                                                                        \
+    const char* wp_ = wcg + __builtin_amdgcn_readfirstlane(wo_n);                                          \
+    const unsigned arow_ = io_n * 16u + a_off;                                                             \
+    _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                                      \
+      const int kc_ = PART ? min(iku * NKU + j, nkc - 1) : iku * NKU + j;                                  \
+      A[S][j] = *reinterpret_cast<const float4*>(in_b + (arow_ + (unsigned)(kc_ * 64)));                   \
+      _Pragma("unroll") for (int v_ = 0; v_ < NTW; ++v_)                                                   \
+        B[S][j][v_] = *reinterpret_cast<const float4*>(wp_ + (size_t)kc_ * (16 * CP * 4) + (b_off + v_ * 16)); \
+    }                                                                                                      \
+    if (++iku == NU) { iku = 0; ig = ig + 1 < nch ? ig + 1 : MSW; }                                        \
+    io_n = m_in[ig * 16 + r];                                                                              \
+    wo_n = m_w[ig];                                                                                        \
+  }
+#define PT_PROLOGUE()                                                                                      \
+  {                                                                                                        \
+    ig = nch > 0 ? 0 : MSW; iku = 0; cgp = ig; cku = 0;                                                    \
+    io_n = m_in[ig * 16 + r]; wo_n = m_w[ig];                                                              \
+    mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < D; ++s_) {                                                     \
+      PT_ISSUE(s_);                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+  }
+#define PT_LOOP()                                                                                          \
+  {                                                                                                        \
+    const int U_ = nch * NU;                                                                               \
+    for (int u = 0; u < U_; u += D) {                                                                      \
+      _Pragma("unroll") for (int s = 0; s < D; ++s) {                                                      \
+        if (u + s >= U_) { PT_ISSUE(s); continue; }                                                        \
+        const unsigned ol[4] = {mo_n.x & 0xffffu, mo_n.x >> 16, mo_n.y & 0xffffu, mo_n.y >> 16};           \
+        BT v[4];                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const BT*>(acc_lane + ol[j]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        f32x4 d[NTW];                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};                \
+        _Pragma("unroll") for (int j = 0; j < NKU; ++j) {                                                  \
+          const bool live = !PART || cku * NKU + j < nkc;                                                  \
+          const float av[4] = {live ? A[s][j].x : 0.f, live ? A[s][j].y : 0.f, live ? A[s][j].z : 0.f, live ? A[s][j].w : 0.f}; \
+          _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                               \
+            const float* bw = reinterpret_cast<const float*>(&B[s][j][0]) + s2 * NTW;                      \
+            _Pragma("unroll") for (int t = 0; t < NTW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t], d[t], 0, 0, 0); \
+          }                                                                                                \
+        }                                                                                                  \
+        if (++cku == NU) { cku = 0; cgp = cgp + 1 < nch ? cgp + 1 : MSW; }                                 \
+        mo_n = *reinterpret_cast<const uint2*>(m_out + cgp * 16 + q * 4);                                  \
+        PT_ISSUE(s);                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+          float* vf = reinterpret_cast<float*>(&v[j]);                                                     \
+          _Pragma("unroll") for (int t = 0; t < NTW; ++t) vf[t] += d[t][j];                                \
+          *reinterpret_cast<BT*>(acc_lane + ol[j]) = v[j];                                                 \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  int gb, nmine;
+  tile_range(0, gb, nmine);
+  meta_fetch(gb, 0);
+  nch = min(MSW, nmine);
+  meta_store(nch);
+  PT_PROLOGUE();
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int tile = (rd * nblk + bidx) * T + team;
+    int gb_n, nmine_n;
+    tile_range(rd + 1, gb_n, nmine_n);
+    meta_fetch(gb_n, 0);   // the next tile's metadata travels while this tile's units run
+    if (rd > 0) rg_spin_ge(f_arr2 + team, 4u * (unsigned)rd);   // my accumulator's rows were zeroed by my team mates' sums
+    for (int c0 = 0;;) {
+      PT_LOOP();
+      c0 += MSW;
+      if (c0 >= nmine) break;
+      // a tile with more than 4 MSW groups (rare): the rest chunk by chunk, not prefetched
+      meta_fetch(gb, c0);
+      nch = min(MSW, nmine - c0);
+      meta_store(nch);
+      PT_PROLOGUE();
+      if (c0 + MSW >= nmine) meta_fetch(gb_n, 0);   // (the next tile's again: its registers were used above)
+    }
+    gb = gb_n; nmine = nmine_n;
+    nch = min(MSW, nmine);
+    meta_store(nch);
+    constexpr bool EARLY = NKU * (1 + NTW) <= 9;   // wider units: the ring's registers do not fit beside the ordered sum (spills)
+    if (EARLY) PT_PROLOGUE();   // the next tile's first loads: in flight under the hand-off and the ordered sum below
+    rg_add1(f_arr + team, lane);
+    rg_spin_ge(f_arr + team, 4u * (unsigned)(rd + 1));
+    {
+      constexpr int V = CP / 4;
+      const int row0 = tile * 64;
+#pragma unroll
+      for (int i = lane; i < 16 * V; i += 64) {
+        const int rr = 16 * wv + i / V, c4 = i % V;
+        const char* p0 = tacc + (rr * LD + c4 * 4) * 4;
+        float4 sum = *reinterpret_cast<const float4*>(p0);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+          const float4 p = *reinterpret_cast<const float4*>(p0 + w2 * ACCB);
+          sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+        }
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) *reinterpret_cast<float4*>(const_cast<char*>(p0) + w2 * ACCB) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile < ntiles && row0 + rr < A_out)
+          *reinterpret_cast<float4*>(out + (int64_t)(row0 + rr) * ld_out + cg * CP + c4 * 4) = sum;
+      }
+    }
+    rg_add1(f_arr2 + team, lane);
+    if (!EARLY) PT_PROLOGUE();
+  }
+#undef PT_ISSUE
+#undef PT_PROLOGUE
+#undef PT_LOOP
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 static int rg_env(const char* name, int dflt) {
   const char* s = getenv(name);
@@ -395,9 +608,41 @@ static int rg_slots(int ntw, int K, int cin) {
   return R;
 }
 
+template <int NTW, int NKU, bool PART>
+static int pt_go(const int* gs, const int* go, const int* gi, const int* gout, int K, int num_out, const float* in, int ld_in, int cin,
+                 const float* Wp, int cout, int w_flip, float* out, int ld_out, hipStream_t st) {
+  constexpr int T = 3, LD = NTW * 16 + RG_PAD;
+  const size_t lds = (size_t)4 * T * (65 * LD * 4 + ((16 * 100 + 15) / 16 * 16)) + 64;
+  auto kern = k_spconv_pt4<NTW, NKU, PART, T>;
+  static std::atomic<int> attr_set{0};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MOPA_ERR_LAUNCH;
+    attr_set.store(1, std::memory_order_release);
+  }
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int ntiles = (int)cdiv64(num_out, 64), ncg = cout / (NTW * 16);
+  const int nbatch = (ntiles + T - 1) / T;
+  int nblk = cus / ncg;
+  if (nblk < 1) nblk = 1;
+  if (nblk > nbatch) nblk = nbatch;
+  kern<<<nblk * ncg, 256 * T, lds, st>>>(gs, go, gi, gout, K, num_out, in, ld_in, cin, Wp, w_flip, out, ld_out, ntiles, ncg);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
 int mopa_ring_plan(int K, int64_t num_out, int cin, int cout) {
-  static const int enable = rg_env("MOPA_SPCONV_RING", 0);   // 0 = off, 1 = every shape it supports, 2 = 27-offset tables only
+  static const int enable = rg_env("MOPA_SPCONV_RING", 0);   // 0 = off, 1 = every shape it supports, 2 = 27-offset tables only, 3 / 4 = k_spconv_pt4 (all / 27-offset)
   if (!enable) return 0;
+  if (enable >= 3) {
+    if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || K > 27 || (enable == 4 && K != 27)) return 0;
+    static const int min_tiles_pt = rg_env("MOPA_RING_MIN_TILES", 0);
+    if (cdiv64(num_out, 64) < min_tiles_pt) return 0;
+    return (cout % 32 == 0) ? 2 : 1;
+  }
   if (cin % 16 || cout % 16 || cin > 224 || cout > 224 || K > 27) return 0;
   if (enable == 2 && K != 27) return 0;
   static const int force_ntw = rg_env("MOPA_RING_NTW", 0);   // tuning only
@@ -462,6 +707,26 @@ static int rg_go(const int* gs, const int* go, const int* gi, const int* gout, i
 int mopa_ring_launch(const int* gs, const int* go, const int* gi, const int* gout, int K, int num_out, const float* in, int ld_in,
                      int cin, const float* Wp, int cout, int w_flip, float* out, int ld_out, int ntw, hipStream_t st) {
   const int nkc = cin / 16;
+  static const int enable = rg_env("MOPA_SPCONV_RING", 0);
+  if (enable >= 3) {
+#define PT(N, KU, P) return pt_go<N, KU, P>(gs, go, gi, gout, K, num_out, in, ld_in, cin, Wp, cout, w_flip, out, ld_out, st)
+    if (ntw == 1) {
+      if (nkc == 1) PT(1, 1, false);
+      if (nkc == 2) PT(1, 2, false);
+      if (nkc % 5 == 0) PT(1, 5, false);
+      if (nkc % 7 == 0) PT(1, 7, false);
+      if (nkc % 3 == 0) PT(1, 3, false);
+      if (nkc % 4 == 0) PT(1, 4, false);
+      PT(1, 4, true);
+    }
+    if (nkc == 1) PT(2, 1, false);
+    if (nkc == 2) PT(2, 2, false);
+    if (nkc % 5 == 0) PT(2, 5, false);
+    if (nkc % 3 == 0) PT(2, 3, false);
+    if (nkc % 4 == 0) PT(2, 4, false);
+    PT(2, 4, true);
+#undef PT
+  }
 #define RG(N, KU, P) return rg_go<N, KU, P>(gs, go, gi, gout, K, num_out, in, ld_in, cin, Wp, cout, w_flip, out, ld_out, st)
   // unit = group x NKU chunks: the same unit widths as k_spconv_t4 picks for this column-group width (bit-identical sums)
   if (ntw == 1) {
