@@ -99,9 +99,12 @@ SIGNATURES = {
     "mopa_wino_bwd_weight": ("i", "ppiiipipzp"),
     "mopa_wino4_weight": ("i", "piiipp"),
     "mopa_wino4_weight_t": ("i", "piiipp"),
+    "mopa_wino4_weight_f": ("i", "piiipp"),
+    "mopa_wino4_conv": ("i", "pipppiiiiiiipip"),
     "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),
+    "mopa_wino4_input_bn": ("i", "piiiiipipp"),
     "mopa_wino4_output": ("i", "piiiippiip"),
     "mopa_wino4_dout": ("i", "piiiiipp"),
     "mopa_wino4_wgrad_workspace_bytes": ("z", "iii"),

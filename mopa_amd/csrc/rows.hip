@@ -199,13 +199,15 @@ MOPA_API size_t mopa_bnrelu_rows_workspace_bytes(int32_t num_rows, int32_t C) {
 // n_groups (1..3) consecutive row ranges [0, split1), [split1, split2), [split2, num_rows) are normalised as separate batches, in that
 // order (running statistics: group 0 first); stats = [n_groups][4][C].  (Workspace: mopa_bnrelu_rows_workspace_bytes of the whole
 // tensor + one block per extra group.)
+// y == null: statistics, running statistics and stats only -- the consumer applies scale / shift / activation while it reads x
+// (mopa_wino4_input_bn: the BatchNorm between two convolutions of a ResNet block never materialises its output).
 MOPA_API int mopa_bn_act_fwd_groups(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t num_rows, int32_t C,
                                     int32_t n_groups, int32_t split1, int32_t split2,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float leak, int32_t act, const float* res, int32_t ld_res,
                                     int32_t training, float* stats, void* ws, size_t ws_bytes, void* stream) {
-  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MOPA_ERR_ARG;
-  if (res && (ld_res < C || (ld_res & 3))) return MOPA_ERR_ARG;
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || (ldx & 3) || (y && (ldy < C || (ldy & 3)))) return MOPA_ERR_ARG;
+  if (res && (ld_res < C || (ld_res & 3) || !y)) return MOPA_ERR_ARG;
   BnGroups grp;
   if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -217,9 +219,11 @@ MOPA_API int mopa_bn_act_fwd_groups(const float* x, int32_t ldx, float* y, int32
     k_bn_stats_partial<<<dim3(grp.nblk_max, grp.n), 256, (size_t)2 * RL * C * sizeof(float), st>>>(x, ldx, C, grp, partial);
   }
   k_bn_finalize<<<C, 256, 0, st>>>(partial, grp, x, ldx, C, gamma, beta, running_mean, running_var, momentum, eps, training, stats);
-  int maxrows = 0;
-  for (int k = 0; k < grp.n; ++k) maxrows = grp.rows[k] > maxrows ? grp.rows[k] : maxrows;
-  k_bn_relu_apply<<<dim3(bn_apply_grid(maxrows, C), grp.n), 256, 0, st>>>(x, ldx, y, ldy, grp, C, stats, leak, res, ld_res, act);
+  if (y) {
+    int maxrows = 0;
+    for (int k = 0; k < grp.n; ++k) maxrows = grp.rows[k] > maxrows ? grp.rows[k] : maxrows;
+    k_bn_relu_apply<<<dim3(bn_apply_grid(maxrows, C), grp.n), 256, 0, st>>>(x, ldx, y, ldy, grp, C, stats, leak, res, ld_res, act);
+  }
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

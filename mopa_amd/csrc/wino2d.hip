@@ -241,8 +241,12 @@ __global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, 
   wf_wino4_body(w, O, I, dgrad, U, transpose, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// BN: the input is the raw output of the previous convolution and BatchNorm + ReLU are applied on the way in -- y = relu(x * scale +
+// shift) with scale / shift of the image's BatchNorm group from stats[G][4][C] (mopa_bn_act_fwd_groups with y == null), the very
+// expression of k_bn_relu_apply, so V is bit-identical to transforming the materialised y; the zero padding stays zero.
+template <bool BN>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, int ld_in, int B, int H, int W, int C, int th, int tw,
-                                                   float* __restrict__ V) {
+                                                   float* __restrict__ V, const float* __restrict__ stats, int imgs_per_group) {
   const int64_t T = (int64_t)B * th * tw;
   const int64_t total = T * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -251,6 +255,11 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, 
     const int b = (int)(t / (th * tw));
     const int rt = (int)(t - (int64_t)b * th * tw);
     const int ty = rt / tw, tx = rt - ty * tw;
+    float sc = 1.f, sh = 0.f;
+    if (BN) {
+      const float* __restrict__ sg = stats + (int64_t)(b / imgs_per_group) * 4 * C;
+      sc = sg[ch]; sh = sg[C + ch];
+    }
     float m[6][6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {   // B^T d, column by column
@@ -259,7 +268,12 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, 
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int y = 4 * ty - 1 + a;
-        d[a] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? in[((int64_t)(b * H + y) * W + x) * ld_in + ch] : 0.f;
+        const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        d[a] = inside ? in[((int64_t)(b * H + y) * W + x) * ld_in + ch] : 0.f;
+        if (BN && inside) {
+          const float o = fmaf(d[a], sc, sh);
+          d[a] = o > 0.f ? o : o * 0.f;
+        }
       }
       w4_bt(d, tc);
 #pragma unroll
@@ -367,7 +381,18 @@ MOPA_API int mopa_wino4_weight(const float* weight, int32_t O, int32_t I, int32_
 MOPA_API int mopa_wino4_input(const float* in, int32_t ld_in, int32_t B, int32_t H, int32_t W, int32_t C, float* V, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
-  k_wino4_in<<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V);
+  k_wino4_in<false><<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V, nullptr, 1);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+// V of relu(batchnorm(in)): `in` is the BatchNorm's INPUT, stats = [n_groups][4][C] as mopa_bn_act_fwd_groups wrote it (scale, shift,
+// mean, invstd), the B images are n_groups equal consecutive groups.  Bit-identical to mopa_wino4_input on the applied tensor.
+MOPA_API int mopa_wino4_input_bn(const float* in, int32_t ld_in, int32_t B, int32_t H, int32_t W, int32_t C, const float* stats,
+                                 int32_t n_groups, float* V, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C || !stats || n_groups < 1 || B % n_groups) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  k_wino4_in<true><<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V, stats,
+                                                                                              B / n_groups);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -391,7 +416,7 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
 // Every stale weight form of the 2D network in ONE launch: after an optimizer step the first use of each conv re-laid out
 // its weight with a tiny kernel of its own (igemm layouts, Winograd transforms: ~95 launches of 8-10 us per joint step, serialised
 // on the main stream between the convolutions).  desc_host [n][8] int64: source, destination, O, I, KH, KW, kind (0 = igemm
-// layout, 1 = F(2x2) transform, 2 = F(4x4) transform), arg (kind 0: mode 0-3; kinds 1, 2: bit 0 = dgrad, bit 1 = transposed).
+// layout, 1 = F(2x2) transform, 2 = F(4x4) transform), arg (kind 0: mode 0-3; kinds 1, 2: bit 0 = dgrad, bits 1-2 = 1 transposed / 2 fragment layout (F(4x4) only)).
 #define WF_MAX 48
 struct WeightFormDescs { int64_t src[WF_MAX], dst[WF_MAX]; int32_t O[WF_MAX], I[WF_MAX], KH[WF_MAX], KW[WF_MAX], kind[WF_MAX], arg[WF_MAX]; };
 __global__ void k_weight_forms_batched(const WeightFormDescs d) {
@@ -401,7 +426,7 @@ __global__ void k_weight_forms_batched(const WeightFormDescs d) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x, istep = gridDim.x * blockDim.x;
   if (d.kind[e] == 0) wf_relayout_body(src, dst, d.O[e], d.I[e], d.KH[e], d.KW[e], d.arg[e], i0, istep);
   else if (d.kind[e] == 1) wf_wino2_body(src, d.O[e], d.I[e], d.arg[e] & 1, dst, i0, istep);
-  else wf_wino4_body(src, d.O[e], d.I[e], d.arg[e] & 1, dst, (d.arg[e] >> 1) & 1, i0, istep);
+  else wf_wino4_body(src, d.O[e], d.I[e], d.arg[e] & 1, dst, (d.arg[e] >> 1) & 3, i0, istep);
 }
 MOPA_API int mopa_conv2d_weight_forms_batched(const int64_t* desc_host, int32_t n, void* stream) {
   if (!desc_host || n <= 0 || n > WF_MAX) return MOPA_ERR_ARG;
@@ -413,7 +438,8 @@ MOPA_API int mopa_conv2d_weight_forms_batched(const int64_t* desc_host, int32_t 
     const int64_t O = r[2], I = r[3], KH = r[4], KW = r[5], kind = r[6], arg = r[7];
     if (!r[0] || !r[1] || O <= 0 || I <= 0 || kind < 0 || kind > 2) return MOPA_ERR_ARG;
     if (kind == 0 && (KH <= 0 || KW <= 0 || arg < 0 || arg > 3 || O * I * KH * KW >= (1ll << 31))) return MOPA_ERR_ARG;
-    if (kind != 0 && (KH != 3 || KW != 3 || arg < 0 || arg > 3 || (kind == 1 && (arg & 2)))) return MOPA_ERR_ARG;
+    if (kind != 0 && (KH != 3 || KW != 3 || arg < 0 || arg > 5 || (kind == 1 && (arg & 6))
+                      || ((arg & 4) && (O % 16 || I % 16)))) return MOPA_ERR_ARG;
     d.src[e] = r[0]; d.dst[e] = r[1]; d.O[e] = (int)O; d.I[e] = (int)I; d.KH[e] = (int)KH; d.KW[e] = (int)KW; d.kind[e] = (int)kind; d.arg[e] = (int)arg;
     const int64_t ne = kind == 0 ? O * I * KH * KW : O * I;
     if (ne > nmax) nmax = ne;
@@ -721,6 +747,312 @@ MOPA_API int mopa_wino4_gemm_output(const float* V, const float* Ut, const float
 #else
   k_wino4_gemm_out<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(V, Ut, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
                                                                     mtiles, ntn, T * Cin, Cin);
+#endif
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+
+// ================================================================================================================
+// F(4x4): the WHOLE convolution in one kernel -- input transform, 36 GEMMs, output transform.  Neither V nor M (2.25x the
+// activations each) exists in HBM: the layer reads its input once (plus the tile halos, from L2) and writes its output once.
+// Why: the 64/128-channel layers at 152x240 and 304x480 are bound by that traffic (k_wino4_in writes V, k_wino4_gemm_out reads it:
+// 672 MB per 64 -> 64 layer at 16 x 152 x 240 against 149 MB in + 149 MB out).
+// How: a persistent workgroup of four waves, one per CU (144 KB of LDS, one wave per SIMD with the whole 512-register file), walks
+// work items = (16 consecutive tiles = one MFMA M dimension) x (64 output channels); an item takes Cin / 64 steps of 64 input channels.
+//   transform  wave w takes the 16 input channels [64 r + 16 w, + 16) of step r: lane (tile t = lane % 16, quad q = lane / 16) holds
+//              the 6x6 patch of its tile for channels 4 q .. 4 q + 3 (36 dwordx4 loads, a safe address outside the image, zeroed
+//              afterwards), applies B^T d B in registers -- the arithmetic of k_wino4_in, V has the same bits -- and writes the 36
+//              points lane-linearly into LDS ([chunk][point][lane] float4).  The float4 a lane wrote IS an A-operand fragment:
+//              v_mfma_f32_16x16x4_f32 step j takes A[m = t][k = q] = channel 4 q + j -- the k index is a permutation of the chunk's
+//              channels, and the weight fragments (mopa_wino4_weight_f) use the same one.
+//   multiply   wave w owns output channels [n0 + 16 w, + 16): per chunk and point one ds_read_b128 (A) and one global dwordx4 (B: a
+//              1-KiB lane-linear run, L2-resident, two buffers of eighteen points: one in flight while the other multiplies) feed
+//              four MFMAs into acc[point] -- 36 x 4 accumulator registers (AGPRs) that live across the steps of an item, so the
+//              output transform runs ONCE per item.
+//   fold       Y = A^T M A from the 36 accumulators (constants folded at compile time) + bias into an LDS tile [256 pixels][64
+//              channels] (over V, behind a barrier), stored as whole 256-byte pixel rows (dwordx4, optional accumulate).  The lines
+//              of the NEXT step's patch are touched in front of it (into L2).
+// BN: the input is a BatchNorm's input and relu(x * scale + shift) is convolved (LazyImg, as k_wino4_in<true>).
+template <bool BN>
+__global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in, int ld_in, const float* __restrict__ Uf,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int ld_out, int B, int H,
+                                                     int W, int th, int tw, int Cin, int Cout, int accumulate,
+                                                     const float* __restrict__ stats, int imgs_per_group, int nitems
+#ifdef W4C_PROFILE
+                                                     , long long* prof
+#endif
+                                                     ) {
+#ifdef W4C_PROFILE
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define W4C_T(K_) { const long long n_ = __builtin_readcyclecounter(); pt[K_] += n_ - tprev; tprev = n_; }
+#else
+#define W4C_T(K_)
+#endif
+  extern __shared__ __attribute__((aligned(16))) float w4c_lds[];   // [4][36][64] float4; the output tile [256][64] floats over it
+  f32x4w* __restrict__ lds = reinterpret_cast<f32x4w*>(w4c_lds);
+  const int tid = threadIdx.x, lane = tid & 63, t = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ny = Cout >> 6;
+  const int T = B * th * tw, tt = th * tw;
+  const int nround = Cin >> 6, nchunk = Cin >> 4, nnb = Cout >> 4;
+  const f32x4w zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t pstride = (int64_t)nchunk * nnb * 64;   // float4 elements per transform point
+  f32x4w acc[36];
+#pragma unroll
+  for (int p = 0; p < 36; ++p) acc[p] = zero4;
+  f32x4w sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+  unsigned rmask = 0, cmask = 0;
+  float pf_sink = 0.f;
+  // transform phase: lane = (tile tx_ = lane / 4, channel quad qx_ = lane % 4) -- four consecutive lanes read 64 contiguous bytes (with
+  // the MFMA numbering t + 16 q every lane of a load would start a segment of its own); the fragment goes to slot tx_ + 16 qx_
+  const int tx_ = lane >> 2, qx_ = lane & 3;
+  f32x4w bA[18], bB[18];
+  // the patch of step (IT_, R_): tile coordinates, in-image masks, BatchNorm constants, 36 loads.  PF_: touch the lines only (into
+  // L2, one step ahead: the 144 patch registers of a real prefetch do not fit beside the accumulators and the weight buffers) --
+  // a dword load per lane into one scratch register that is kept alive until the next real patch has been waited for.
+#define W4C_PATCH(IT_, R_, PF_)                                                                               \
+  {                                                                                                           \
+    const int tile_ = ((IT_) / ny) * 16 + tx_;                                                                \
+    const bool tv_ = tile_ < T;                                                                               \
+    const int tb_ = tv_ ? tile_ / tt : 0, trt_ = tv_ ? tile_ - tb_ * tt : 0;                                  \
+    const int tty_ = trt_ / tw, ttx_ = trt_ - tty_ * tw;                                                      \
+    const int y0_ = 4 * tty_ - 1, x0_ = 4 * ttx_ - 1;                                                         \
+    const int ch0_ = ((R_) << 6) + (wv << 4) + 4 * qx_;                                                       \
+    const float* __restrict__ pin_ = in + ((int64_t)(tb_ * H + y0_) * W + x0_) * ld_in + ch0_;               \
+    const float* __restrict__ psafe_ = in + ch0_;                                                             \
+    unsigned rm_ = 0, cm_ = 0;                                                                                \
+    _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_) {                                                        \
+      rm_ |= (tv_ && (unsigned)(y0_ + a_) < (unsigned)H) ? (1u << a_) : 0u;                                   \
+      cm_ |= ((unsigned)(x0_ + a_) < (unsigned)W) ? (1u << a_) : 0u;                                          \
+    }                                                                                                         \
+    if (!(PF_)) {                                                                                             \
+      rmask = rm_; cmask = cm_;                                                                               \
+      if (BN) {                                                                                               \
+        const float* __restrict__ sg_ = stats + (int64_t)(tb_ / imgs_per_group) * 4 * Cin + ch0_;            \
+        sc = *reinterpret_cast<const f32x4w*>(sg_);                                                           \
+        sh = *reinterpret_cast<const f32x4w*>(sg_ + Cin);                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_)                                                          \
+      _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {                                                      \
+        const bool ins_ = ((rm_ >> a_) & (cm_ >> c_) & 1u) != 0u;                                             \
+        const float* __restrict__ src_ = ins_ ? pin_ + ((int64_t)a_ * W + c_) * ld_in : psafe_;              \
+        if (PF_) { if (qx_ == 0) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src_)); } /* "+": ONE register */ \
+        else d[a_][c_] = *reinterpret_cast<const f32x4w*>(src_);                                              \
+      }                                                                                                       \
+  }
+#define W4C_LOADB(BQ, C_, P0_)                                                                                \
+  {                                                                                                           \
+    const f32x4w* __restrict__ ub_ = Ufw + (int64_t)((r << 2) + (C_)) * nnb * 64 + (int64_t)(P0_) * pstride;  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 18; ++i_) BQ[i_] = ub_[i_ * pstride];                            \
+  }
+#define W4C_MUL6(BQ, C_, P0_, I0_)                                                                            \
+  {                                                                                                           \
+    const f32x4w* __restrict__ la_ = lds + ((C_) * 36 + (P0_) + (I0_)) * 64 + lane;                           \
+    f32x4w av_[6];                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) av_[i_] = la_[i_ * 64];                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                        \
+      acc[(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][0], BQ[(I0_) + i_][0], acc[(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][1], BQ[(I0_) + i_][1], acc[(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][2], BQ[(I0_) + i_][2], acc[(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][3], BQ[(I0_) + i_][3], acc[(P0_) + (I0_) + i_], 0, 0, 0); \
+    }                                                                                                         \
+  }
+#define W4C_MUL(BQ, C_, P0_) { W4C_MUL6(BQ, C_, P0_, 0) W4C_MUL6(BQ, C_, P0_, 6) W4C_MUL6(BQ, C_, P0_, 12) }
+  constexpr float AT[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+  int item = blockIdx.x, r = 0;
+  while (item < nitems) {
+    const int tg = item / ny, n0 = (item - tg * ny) << 6;
+    const f32x4w* __restrict__ Ufw = reinterpret_cast<const f32x4w*>(Uf) + (int64_t)((n0 >> 4) + wv) * 64 + lane;
+    W4C_T(0)
+    // ---- transform: patch -> V chunk wv (everyone is done with the LDS of the previous step: barrier at its end)
+    f32x4w d[6][6];
+    W4C_PATCH(item, r, false);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const bool inside = ((rmask >> a) & (cmask >> c) & 1u) != 0u;
+        f32x4w v = d[a][c];
+        if (BN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = fmaf(v[e], sc[e], sh[e]);
+            v[e] = o > 0.f ? o : o * 0.f;
+          }
+        }
+        d[a][c] = inside ? v : zero4;
+      }
+    asm volatile("" :: "v"(pf_sink));   // (the touch loads of the previous step were issued before this patch: they have landed)
+    W4C_T(1)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)
+      const f32x4w d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+      d[0][c] = 4.f * d0 - 5.f * d2 + d4;
+      d[1][c] = -4.f * (d1 + d2) + d3 + d4;
+      d[2][c] = 4.f * (d1 - d2) - d3 + d4;
+      d[3][c] = -2.f * d1 - d2 + 2.f * d3 + d4;
+      d[4][c] = 2.f * d1 - d2 - 2.f * d3 + d4;
+      d[5][c] = 4.f * d1 - 5.f * d3 + d5;
+    }
+    {
+      f32x4w* __restrict__ lw = lds + (wv * 36) * 64 + tx_ + 16 * qx_;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {   // (.) B
+        const f32x4w d0 = d[a][0], d1 = d[a][1], d2 = d[a][2], d3 = d[a][3], d4 = d[a][4], d5 = d[a][5];
+        lw[(a * 6 + 0) * 64] = 4.f * d0 - 5.f * d2 + d4;
+        lw[(a * 6 + 1) * 64] = -4.f * (d1 + d2) + d3 + d4;
+        lw[(a * 6 + 2) * 64] = 4.f * (d1 - d2) - d3 + d4;
+        lw[(a * 6 + 3) * 64] = -2.f * d1 - d2 + 2.f * d3 + d4;
+        lw[(a * 6 + 4) * 64] = 2.f * d1 - d2 - 2.f * d3 + d4;
+        lw[(a * 6 + 5) * 64] = 4.f * d1 - 5.f * d3 + d5;
+      }
+    }
+    W4C_LOADB(bA, 0, 0);
+    W4C_LOADB(bB, 0, 18);
+    const bool last_round = r + 1 == nround;
+    const int nitem = last_round ? item + (int)gridDim.x : item, nr = last_round ? 0 : r + 1;
+    W4C_T(2)
+    __syncthreads();   // V is complete
+    W4C_T(3)
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {   // (a loop, not 8 units of straight-line code: the scheduler would hoist every weight load)
+      W4C_MUL(bA, c, 0);   if (c < 3) W4C_LOADB(bA, c + 1, 0);
+      W4C_MUL(bB, c, 18);  if (c < 3) W4C_LOADB(bB, c + 1, 18);
+    }
+    W4C_T(4)
+    __syncthreads();   // everyone is done reading V
+    W4C_T(5)
+    // touch the next step's patch: it comes from L2 instead of HBM when the loop comes round
+    if (nitem < nitems) W4C_PATCH(nitem, nr, true);
+    if (last_round) {
+      // ---- output transform: lane holds M[point][tile 4 q + i][channel n0 + 16 wv + t], i = 0..3
+      float o[4][16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < 6; ++pi) {
+        float srow[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) srow[i][c] = 0.f;
+#pragma unroll
+        for (int pj = 0; pj < 6; ++pj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (AT[pj][c] != 0.f) srow[i][c] = fmaf(AT[pj][c], acc[pi * 6 + pj][i], srow[i][c]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (AT[pi][a] != 0.f) o[i][a * 4 + c] = fmaf(AT[pi][a], srow[i][c], o[i][a * 4 + c]);
+      }
+#pragma unroll
+      for (int p = 0; p < 36; ++p) acc[p] = zero4;
+      const float bvv = bias ? bias[n0 + (wv << 4) + t] : 0.f;
+      float* __restrict__ ot = w4c_lds + (wv << 4) + t;   // [tile 16][pixel 16][channel 64]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[((4 * q + i) * 16 + e) * 64] = o[i][e] + bvv;
+      __syncthreads();
+      // whole pixel rows: thread = (pixel wv * 4 + q of the tile, channel quad t); one tile per iteration (uniform coordinates)
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+        const int otile = (tg << 4) + k;
+        if (otile >= T) break;
+        const int b = otile / tt, rt = otile - b * tt;
+        const int ty = rt / tw, tx = rt - ty * tw;
+        const int y = 4 * ty + wv, x = 4 * tx + q;
+        if (y < H && x < W) {
+          f32x4w v = *reinterpret_cast<const f32x4w*>(w4c_lds + ((k * 16 + wv * 4 + q) * 64 + 4 * t));
+          f32x4w* gp = reinterpret_cast<f32x4w*>(out + ((int64_t)(b * H + y) * W + x) * ld_out + n0 + 4 * t);
+          if (accumulate) v += *gp;
+          *gp = v;
+        }
+      }
+      __syncthreads();   // the tile has been read: the next step may write V over it
+    }
+    W4C_T(6)
+    item = nitem; r = nr;
+  }
+#undef W4C_PATCH
+#undef W4C_LOADB
+#undef W4C_MUL
+#undef W4C_MUL6
+#ifdef W4C_PROFILE
+  if (blockIdx.x == 100 && tid == 0)
+    for (int k = 0; k < 8; ++k) prof[k] = pt[k];
+#endif
+}
+
+// B-operand fragments of k_wino4_conv from the OIHW weight (weight_forms.h: transpose = 2); dgrad as in mopa_wino4_weight.
+MOPA_API int mopa_wino4_weight_f(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* Uf, void* stream) {
+  if (O <= 0 || I <= 0 || O % 16 || I % 16) return MOPA_ERR_ARG;
+  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, Uf, 2);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// out (NHWC, row stride ld_out) = conv3x3(in) (+ bias) (+= if accumulate) through F(4x4,3x3) in ONE kernel: mopa_wino4_input +
+// mopa_wino4_gemm_output without V.  Uf: mopa_wino4_weight_f.  Cin % 64 == 0, Cout % 64 == 0; `in` / `out` 16-byte aligned, ld_in % 4 ==
+// ld_out % 4 == 0.
+// stats != null: `in` is a BatchNorm's input, stats = [n_groups][4][Cin] (mopa_bn_act_fwd_groups with y == null), the B images are
+// n_groups equal consecutive groups and relu(batchnorm(in)) is what is convolved (as mopa_wino4_input_bn).
+MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, const float* bias, float* out, int32_t ld_out, int32_t B,
+                             int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, const float* stats, int32_t n_groups,
+                             void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || ld_in < Cin || (ld_in & 3) || ld_out < Cout ||
+      (ld_out & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+    return MOPA_ERR_ARG;
+  if (stats && (n_groups < 1 || B % n_groups)) return MOPA_ERR_ARG;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const int64_t T = (int64_t)B * th * tw;
+  const int64_t nitems = cdiv64(T, 16) * (Cout / 64);
+  if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
+  const size_t ldsb = (size_t)4 * 36 * 64 * 16;
+  static bool attr[2] = {false, false};
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOPA_ERR_LAUNCH;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int v = stats ? 1 : 0;
+  const void* kern = stats ? reinterpret_cast<const void*>(k_wino4_conv<true>) : reinterpret_cast<const void*>(k_wino4_conv<false>);
+  if (!attr[v]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return MOPA_ERR_LAUNCH;
+    attr[v] = true;
+  }
+  const unsigned nblk = (unsigned)(nitems < ncu ? nitems : ncu);   // persistent: one workgroup per CU (144 KB of LDS each)
+#ifdef W4C_PROFILE
+  static long long* prof = nullptr;
+  if (!prof) hipMallocManaged(&prof, 128);
+  k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
+                                                             nullptr, 1, (int)nitems, prof);
+  hipStreamSynchronize((hipStream_t)stream);
+  {
+    const double n_ = (double)nitems / nblk * (Cin / 64);
+    printf("[w4c profile] block 100 wave 0, cycles per step: loop head %.0f | patch wait + apply %.0f | transform, lds write, B + patch issue %.0f | "
+           "barrier %.0f | multiply %.0f | barrier %.0f | fold + store %.0f   (steps per block %.1f)\n",
+           prof[0] / n_, prof[1] / n_, prof[2] / n_, prof[3] / n_, prof[4] / n_, prof[5] / n_, prof[6] / n_, n_);
+  }
+#else
+  if (stats)
+    k_wino4_conv<true><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
+                                                              stats, B / n_groups, (int)nitems);
+  else
+    k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
+                                                               nullptr, 1, (int)nitems);
 #endif
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

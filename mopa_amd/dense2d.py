@@ -38,6 +38,19 @@ class Img(View):
         self.B, self.H, self.W = B, H, W
 
 
+class LazyImg(Img):
+    """relu(batchnorm(x)) that is never written: `t` is the BatchNorm's INPUT x, `bn` = (stats (G, 4, C), G).  The one consumer --
+    a Winograd F(4x4) convolution -- applies scale / shift / ReLU inside its input transform (mopa_wino4_input_bn, bit-identical
+    to transforming the materialised tensor) and keeps V for its weight gradient; BatchNorm's backward recomputes the mask from x
+    anyway.  One apply pass (read x, write y) and one launch less per such layer."""
+
+    __slots__ = ("bn",)
+
+    def __init__(self, x: Img, stats, G):
+        super().__init__(x.t, x.B, x.H, x.W, x.col, x.C)
+        self.bn = (stats, G)
+
+
 def new_img(B, H, W, C, dev, ld=None, zero=False):
     alloc = torch.zeros if zero else torch.empty
     return Img(alloc(B * H * W, ld or C, dtype=torch.float32, device=dev), B, H, W, 0, C)
@@ -156,20 +169,22 @@ def relayout_cached(w, shape, O, I, KH, KW, mode):
     return _cached_weight_form(w, ("relayout", mode), build, (O, I, KH, KW, 0, mode))
 
 
-def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: bool = False):
+def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: int = 0):
     """U[(F+2)^2][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version.
-    transposed (F = 4 only): U^T[36][C][R], the k-contiguous operand of the fused GEMM + output-transform kernel."""
+    transposed (F = 4 only): 1 = U^T[36][C][R], the k-contiguous operand of the fused GEMM + output-transform kernel; 2 = the MFMA
+    B-operand fragments of the one-kernel convolution (mopa_wino4_conv), [36][R / 16][C / 16][64 lanes][4]."""
     O, I = w.shape[0], w.shape[1]
+    transposed = int(transposed)
 
     def build():
         R, C = (O if dgrad else I), (I if dgrad else O)
-        u = torch.empty((F + 2) ** 2, (C if transposed else R), (R if transposed else C), dtype=torch.float32, device=w.device)
-        name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight_t" if transposed else "mopa_wino4_weight")
+        u = torch.empty((F + 2) ** 2, (C if transposed == 1 else R), (R if transposed == 1 else C), dtype=torch.float32, device=w.device)
+        name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f")[transposed]
         call(name, ptr(w), O, I, int(dgrad), ptr(u), stream())
         return u
     assert not (transposed and F != 4)
-    return _cached_weight_form(w, ("wino", F, int(dgrad), int(transposed)), build,
-                               (O, I, 3, 3, 1 if F == 2 else 2, int(dgrad) | (int(transposed) << 1)))
+    return _cached_weight_form(w, ("wino", F, int(dgrad), transposed), build,
+                               (O, I, 3, 3, 1 if F == 2 else 2, int(dgrad) | (transposed << 1)))
 
 
 # F(4x4) layers whose 36 GEMMs and output transform run as ONE kernel (mopa_wino4_gemm_output: M is never materialised): needs
@@ -185,6 +200,23 @@ def wino4_fused(cin, cout, B, H, W):
     # (64 input channels = one K chunk per point: there the batched GEMM is the most memory-bound and the fused kernel already
     #  wins on one round of blocks -- 64 -> 64 at 152x240: 189 -> 175 us)
     return cin % 64 == 0 and cout % 32 == 0 and (blocks >= WINO4_FUSED_MIN_BLOCKS or (cin == 64 and 2 * blocks >= WINO4_FUSED_MIN_BLOCKS))
+
+
+# F(4x4) layers that run as ONE kernel (mopa_wino4_conv: input transform, 36 GEMMs and output transform; neither V nor M reaches
+# HBM): 64-aligned channels on both sides and at least MOPA_WINO4_DIRECT_MIN_TILES tiles.  MOPA_WINO4_DIRECT=0 switches it off.
+WINO4_DIRECT = os.environ.get("MOPA_WINO4_DIRECT", "0") != "0"
+WINO4_DIRECT_MIN_TILES = int(os.environ.get("MOPA_WINO4_DIRECT_MIN_TILES", "16384"))
+WINO4_DIRECT_MAX_CIN = int(os.environ.get("MOPA_WINO4_DIRECT_MAX_CIN", "128"))
+
+
+def wino4_direct(cin, cout, B, H, W):
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    return WINO4_DIRECT and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN and T >= WINO4_DIRECT_MIN_TILES
+
+
+def wino4_layout(cin, cout, B, H, W):
+    """Weight form of an F(4x4) layer: 2 = fragments (one-kernel convolution), 1 = transposed (fused GEMM + output transform), 0."""
+    return 2 if wino4_direct(cin, cout, B, H, W) else int(wino4_fused(cin, cout, B, H, W))
 
 
 def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
@@ -231,23 +263,34 @@ def wino_eligible(cin, cout, k, s, p, B, H, W):
     return wino_tile(cin, cout, k, s, p, B, H, W) != 0
 
 
-def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2):
+def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2, bn_in=None):
     """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform.
-    U: wino_weight_cached(w, dgrad, F, transposed=(F == 4 and wino4_fused(cin, cout, B, H, W)))."""
+    U: wino_weight_cached(w, dgrad, F, transposed=(F == 4 and wino4_fused(cin, cout, B, H, W))).
+    bn_in = (stats, G) (F = 4 only): x is a BatchNorm's input and relu(batchnorm(x)) is what gets convolved (LazyImg)."""
     dev = U.device
     th, tw = (H + F - 1) // F, (W + F - 1) // F
     T, NP = B * th * tw, (F + 2) ** 2
     sfx = "" if F == 2 else "4"
+    if F == 4 and wino4_direct(cin, cout, B, H, W):
+        if tuple(U.shape) != (36, cin, cout):
+            raise RuntimeError("wino_conv: the one-kernel F(4x4) path takes the fragment weight form")
+        call("mopa_wino4_conv", x_p, ld_in, ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
+             int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1, stream())
+        return None   # no V: the weight gradient transforms the input itself
     V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
+    if bn_in is not None:
+        if F != 4:
+            raise RuntimeError("wino_conv: a deferred BatchNorm needs the F(4x4) input transform")
+        call("mopa_wino4_input_bn", x_p, ld_in, B, H, W, cin, ptr(bn_in[0]), bn_in[1], ptr(V), stream())
+    else:
+        call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     if F == 4 and wino4_fused(cin, cout, B, H, W):
         if tuple(U.shape) != (36, cout, cin):
             raise RuntimeError("wino_conv: the fused F(4x4) path takes the transposed weight transform")
-        call("mopa_wino4_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
         call("mopa_wino4_gemm_output", ptr(V), ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
              int(accumulate), stream())
         return V
     M = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
-    call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
     igemm_batched(ptr(V), ptr(U), ptr(M), g1, NP, T * cin, cin * cout, T * cout)
     call(f"mopa_wino{sfx}_output", ptr(M), B, H, W, cout, ptr(bias) if bias is not None else None, out_p, ld_out, int(accumulate), stream())
@@ -272,7 +315,10 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
     dM = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
     if V is None:
         V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
-        call(f"mopa_wino{sfx}_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
+        if hasattr(x, "bn"):   # a deferred BatchNorm (LazyImg): applied on the way in, as the forward pass did
+            call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, cin, ptr(x.bn[0]), x.bn[1], ptr(V), stream())
+        else:
+            call(f"mopa_wino{sfx}_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
     call(f"mopa_wino{sfx}_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
     ws = _ws(query(f"mopa_wino{sfx}_wgrad_workspace_bytes", T, cin, cout), dev)
     call(f"mopa_wino{sfx}_bwd_weight", ptr(V), ptr(dM), T, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
@@ -366,14 +412,25 @@ class ConvOp:
         return _geom(B=x.B, IH=x.H, IW=x.W, OHl=out.H, OWl=out.W, OHa=out.H, OWa=out.W, IS=self.s, IY0=-self.p,
                      IX0=-self.p, TH=self.k, TW=self.k, KWF=self.k, Cin=self.I, Cout=self.O, ld_in=x.ld, ld_out=out.ld)
 
+    def takes_lazy(self, B, H, W, training):
+        """May the input be a LazyImg?  The forward pass must be F(4x4) (the input transform applies the BatchNorm) and, in
+        training, the weight gradient must run on the V kept from it -- nothing else of this layer reads the input."""
+        a = (self.I, self.O, self.k, self.s, self.p, B, H, W)
+        return (wino_tile(*a, "fwd") == 4
+                and (not training or (wino_tile(*a, "wgrad") == 4 and wino_wgrad_eligible(*a))))
+
     def forward(self, x: Img, out: Img, keep_v: bool = False):
         """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
         F = wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "fwd")
+        lazy = getattr(x, "bn", None)
+        if lazy is not None and not self.takes_lazy(x.B, x.H, x.W, keep_v):
+            raise RuntimeError("ConvOp.forward: this layer cannot consume a deferred BatchNorm (ask takes_lazy first)")
         if F:
             V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O,
-                          wino_weight_cached(self.w, False, F, F == 4 and wino4_fused(self.I, self.O, x.B, x.H, x.W)), self.b, out.p, out.ld, F=F)
+                          wino_weight_cached(self.w, False, F, wino4_layout(self.I, self.O, x.B, x.H, x.W) if F == 4 else 0), self.b, out.p, out.ld,
+                          F=F, bn_in=lazy)
             same = F == wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad")   # V serves the weight gradient
-            return V if keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
+            return V if V is not None and keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 
@@ -382,6 +439,9 @@ class ConvOp:
         """wgrad_side: the caller joins the weight-gradient stream itself (join_wgrad_stream) after the whole backward pass."""
         dev = self.w.device
         k, s, p = self.k, self.s, self.p
+        if hasattr(x, "bn") and V is None and not (wino_wgrad_eligible(self.I, self.O, k, s, p, x.B, x.H, x.W)
+                                                   and wino_tile(self.I, self.O, k, s, p, x.B, x.H, x.W, "wgrad") == 4):
+            raise RuntimeError("ConvOp.backward: the input was a deferred BatchNorm and this layer's weight gradient cannot apply it")
         # weight gradient: the split-K reduction writes (or accumulates into) the OIHW gradient tensor directly.  It depends on x
         # and dout only and nothing downstream of this layer waits for it: it runs on the weight-gradient stream, beside the
         # backward-data chain that the rest of the backward pass is waiting for (Net2DFunction.backward joins the stream).
@@ -398,7 +458,8 @@ class ConvOp:
         F = wino_tile(self.O, self.I, k, s, p, x.B, x.H, x.W, "dgrad")   # backward-data of a stride-1 3x3 conv is one, too
         if F:
             wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I,
-                      wino_weight_cached(self.w, True, F, F == 4 and wino4_fused(self.O, self.I, x.B, x.H, x.W)), None, dx.p, dx.ld, acc_dx, F=F)
+                      wino_weight_cached(self.w, True, F, wino4_layout(self.O, self.I, x.B, x.H, x.W) if F == 4 else 0), None, dx.p, dx.ld, acc_dx,
+                      F=F)
             return
         wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:
@@ -464,6 +525,8 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
 
 
 GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the BatchNorm groups of one pass in one set of launches
+# A/B switch: bn1 of a ResNet block is applied inside conv2's input transform instead of being written out (LazyImg)
+DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
 
 
 def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
@@ -479,13 +542,15 @@ def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
          ws.numel(), stream())
 
 
-def bn_fwd_groups(x: View, y: View, P, name, act, res, training, stats, G):
+def bn_fwd_groups(x: View, y: View | None, P, name, act, res, training, stats, G):
     """bn_fwd for G consecutive, equally sized row groups of one tensor in ONE set of launches (3 instead of 3 G): statistics, running
-    updates (group 0 first) and the apply per group, bit-identical to G calls of bn_fwd on the row ranges.  stats: (G, 4, C)."""
+    updates (group 0 first) and the apply per group, bit-identical to G calls of bn_fwd on the row ranges.  stats: (G, 4, C).
+    y = None: no apply pass (the consumer applies stats while it reads x: LazyImg)."""
     n = x.rows // G
     wsb = query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C)
     ws = _ws(wsb, x.t.device)
-    call("mopa_bn_act_fwd_groups", x.p, x.ld, y.p, y.ld, x.rows, x.C, G, n, 2 * n, ptr(P[name + ".weight"]), ptr(P[name + ".bias"]),
+    call("mopa_bn_act_fwd_groups", x.p, x.ld, y.p if y is not None else None, y.ld if y is not None else 0, x.rows, x.C, G, n, 2 * n,
+         ptr(P[name + ".weight"]), ptr(P[name + ".bias"]),
          ptr(P[name + ".running_mean"]), ptr(P[name + ".running_var"]), BN_MOMENTUM, BN_EPS, 0.0, int(act),
          res.p if res is not None else None, res.ld if res is not None else 0, int(training), ptr(stats), ptr(ws),
          ws.numel(), stream())
@@ -541,9 +606,17 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
     tape = []
     nbt = []   # BatchNorm2d.num_batches_tracked of every layer that ran: bumped together at the end (one launch, not 43)
 
-    def bn(name, x, act=1, res=None, out=None):
-        y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
+    def bn(name, x, act=1, res=None, out=None, defer=False):
         stats = torch.empty(G, 4, x.C, dtype=torch.float32, device=dev)
+        if defer:   # statistics only; the next convolution's input transform applies them
+            assert act == 1 and res is None and out is None
+            bn_fwd_groups(x, None, P, name, act, None, training, stats, G)
+            y = LazyImg(x, stats, G)
+            if training:
+                nbt.append(P[name + ".num_batches_tracked"])
+            tape.append(("bn", name, x, y, stats, act, None, [None] * G))
+            return y
+        y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
         if G > 1 and not (training and syncbn.active()) and GROUPED_BN:
             bn_fwd_groups(x, y, P, name, act, res, training, stats, G)     # one set of launches for all groups
             gathered = [None] * G
@@ -602,7 +675,10 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
             q = f"{pre}{lname}.{b}."
             s = stride if b == 0 else 1
             has_ds = (q + "downsample.0.weight") in P
-            y1 = bn(q + "bn1", conv(q + "conv1", x, 3, s, 1))
+            z1 = conv(q + "conv1", x, 3, s, 1)
+            defer = (DEFER_BN and not (training and syncbn.active())
+                     and ConvOp(P[q + "conv2.weight"], None, 3, 1, 1).takes_lazy(z1.B, z1.H, z1.W, training))
+            y1 = bn(q + "bn1", z1, defer=defer)
             z = conv(q + "conv2", y1, 3, 1, 1)
             idt = bn(q + "downsample.1", conv(q + "downsample.0", x, 1, s, 0), act=0) if has_ds else x
             last = b == nblocks - 1
@@ -656,8 +732,8 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
     gmap = {}
     dimg = None
 
-    def key(v):
-        return (v.t.data_ptr(), v.col, v.C)
+    def key(v):   # (a LazyImg shares its BatchNorm input's buffer: its gradient is another tensor)
+        return (v.t.data_ptr(), v.col, v.C) + ((1,) if hasattr(v, "bn") else ())
 
     def like(v: Img, zero=False):
         return new_img(v.B, v.H, v.W, v.C, dev, zero=zero)

@@ -780,3 +780,117 @@ def test_source_and_target_batch_in_one_pass_equal_two_calls(winograd, monkeypat
     print("worst parameter-gradient difference (relative):", worst)
     with pytest.raises(ValueError):
         b2({"img": src["img"][:1].repeat(3, 1, 1, 1), "img_indices": list(src["img_indices"][:1]) * 3, "bn_groups": 2})
+
+
+@pytest.mark.parametrize("G,B,C,H,W", [(1, 2, 64, 13, 18), (2, 4, 128, 9, 11), (1, 1, 64, 16, 24)])
+def test_input_transform_with_batchnorm_applied_on_the_way_in(G, B, C, H, W):
+    """mopa_wino4_input_bn on a BatchNorm's input x (+ the layer's stats, mopa_bn_act_fwd_groups with y = null) against
+    mopa_wino4_input on the materialised relu(batchnorm(x)): identical bits, including the zero padding around the image and
+    the ragged last tile row / column; the statistics-only call leaves stats and running statistics as the full call does."""
+    from mopa_amd._lib import call, ptr, stream
+    from mopa_amd.dense2d import bn_fwd_groups, new_img
+    rng = np.random.Generator(np.random.PCG64(17 + C + H))
+    x = _nhwc(torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32) * 1.5 + 0.5))
+    def params():
+        return {"bn.weight": torch.linspace(0.5, 1.5, C).cuda(), "bn.bias": torch.linspace(-1, 1, C).cuda(),
+                "bn.running_mean": torch.zeros(C, device="cuda"), "bn.running_var": torch.ones(C, device="cuda")}
+    Pa, Pb = params(), params()
+    y = new_img(B, H, W, C, "cuda")
+    sa, sb = torch.empty(G, 4, C, device="cuda"), torch.empty(G, 4, C, device="cuda")
+    bn_fwd_groups(x, y, Pa, "bn", 1, None, True, sa, G)
+    bn_fwd_groups(x, None, Pb, "bn", 1, None, True, sb, G)
+    assert torch.equal(sa, sb)
+    assert torch.equal(Pa["bn.running_mean"], Pb["bn.running_mean"]) and torch.equal(Pa["bn.running_var"], Pb["bn.running_var"])
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    Va, Vb = torch.empty(36 * T * C, device="cuda"), torch.full((36 * T * C,), 7.0, device="cuda")
+    call("mopa_wino4_input", y.p, y.ld, B, H, W, C, ptr(Va), stream())
+    call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, C, ptr(sb), G, ptr(Vb), stream())
+    assert torch.equal(Va, Vb)
+    assert float((y.t < 0).sum()) == 0 and float((y.t == 0).float().mean()) > 0.1   # (the ReLU did cut something)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_deferred_batchnorm_gives_the_bits_of_the_materialised_one(groups, monkeypatch):
+    """DEFER_BN: bn1 of every ResNet block whose conv2 runs F(4x4) in the forward pass and in the weight gradient is applied inside
+    conv2's input transform, its output never exists.  Whole network, training mode, two iterations (running statistics carry
+    over): logits, every parameter gradient and every buffer bit-identical to the pass that writes the tensor out."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    batch = synth.make_batch(2 * groups, H=96, W=128)
+    if groups > 1:
+        batch["bn_groups"] = groups
+
+    def run(defer):
+        monkeypatch.setattr(dense2d, "DEFER_BN", defer)
+        torch.manual_seed(5)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        m.output_all = True
+        outs = []
+        for it in range(2):
+            o = m(batch)
+            g = torch.Generator(device="cuda").manual_seed(it)
+            sum((o[k] * torch.randn(o[k].shape, device="cuda", generator=g)).sum() for k in ("seg_logit", "seg_logit2", "seg_logit_all")).backward()
+            outs.append(o["seg_logit"].detach().clone())
+        torch.cuda.synchronize()
+        return outs, [p.grad.clone() for p in m.parameters() if p.grad is not None], [b.clone() for b in m.buffers()]
+
+    calls = []
+    inner = dense2d.call
+    monkeypatch.setattr(dense2d, "call", lambda name, *a: (calls.append(name), inner(name, *a))[1])
+    oa, ga, ba = run(False)
+    n_off = calls.count("mopa_wino4_input_bn")
+    ob, gb, bb = run(True)
+    assert n_off == 0 and calls.count("mopa_wino4_input_bn") > 0, "no layer of this input size took the deferred path"
+    for a, b in zip(oa + ga + ba, ob + gb + bb):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,acc,dgrad,G", [(64, 64, 37, 51, False, False, 0), (128, 64, 21, 30, True, False, 0),
+                                                      (64, 128, 16, 24, False, True, 0), (64, 64, 19, 22, False, False, 2),
+                                                      (128, 128, 9, 13, True, True, 1)])
+def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, G, monkeypatch):
+    """mopa_wino4_conv (input transform, 36 GEMMs, output transform of F(4x4) in one kernel; V and M never written) through
+    dense2d.wino_conv, forced on for small shapes: against an fp64 conv3x3 (padding 1; dgrad: the transposed convolution's weight form)
+    and against the two-kernel path; ragged tiles, a tile group beyond T, the input as a column slice of a wider buffer, bias,
+    accumulation, and (G > 0) a deferred BatchNorm + ReLU applied on the way in for G image groups."""
+    import torch.nn.functional as F
+    from mopa_amd import dense2d
+    from mopa_amd._lib import call, ptr, stream
+    from mopa_amd.dense2d import bn_fwd_groups
+    rng = np.random.Generator(np.random.PCG64(900 + cin + W))
+    B = 2 if G != 1 else 3
+    wide = torch.from_numpy(rng.standard_normal((B * H * W, cin + 64)).astype(np.float32)).cuda()
+    xin = dense2d.Img(wide, B, H, W, 64, cin)                      # columns [64, 64 + cin) of a wider buffer
+    x = wide[:, 64:].contiguous().reshape(B, H, W, cin)
+    stats = None
+    if G:
+        P = {"bn.weight": torch.linspace(0.5, 1.5, cin).cuda(), "bn.bias": torch.linspace(-1, 1, cin).cuda(),
+             "bn.running_mean": torch.zeros(cin, device="cuda"), "bn.running_var": torch.ones(cin, device="cuda")}
+        stats = torch.empty(G, 4, cin, device="cuda")
+        y = dense2d.new_img(B, H, W, cin, "cuda")
+        bn_fwd_groups(xin, y, P, "bn", 1, None, True, stats, G)
+        x = y.t.reshape(B, H, W, cin)                               # what the convolution sees
+    w = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3) if dgrad else (cout, cin, 3, 3)) * 0.05).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+    prev = torch.from_numpy(rng.standard_normal((B * H * W, cout)).astype(np.float32)).cuda()
+    wref = w.flip(2, 3).transpose(0, 1) if dgrad else w            # backward-data of a conv = conv with the rotated, transposed filter
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wref.double().cpu(), None if acc else bias.double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    if acc:
+        ref = ref + prev.double().cpu()
+    O, I = (cin, cout) if dgrad else (cout, cin)
+    outs = []
+    for direct in (True, False):
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 0 if direct else 1 << 62)
+        monkeypatch.setattr(dense2d, "WINO4_FUSED_MIN_BLOCKS", 0)
+        assert dense2d.wino4_direct(cin, cout, B, H, W) == direct
+        U = torch.empty(36, cin, cout, device="cuda") if direct else torch.empty(36, cout, cin, device="cuda")
+        call("mopa_wino4_weight_f" if direct else "mopa_wino4_weight_t", ptr(w), O, I, int(dgrad), ptr(U), stream())
+        out = prev.clone() if acc else torch.full((B * H * W, cout), float("nan"), device="cuda")
+        V = dense2d.wino_conv(xin.p, xin.ld, B, H, W, cin, cout, U, None if acc else bias, ptr(out), cout, accumulate=acc, F=4,
+                              bn_in=(stats, G) if G else None)
+        assert (V is None) == direct
+        _close(out, ref.float().numpy(), rtol=1e-4, atol=3e-5)
+        outs.append(out)
+    _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
