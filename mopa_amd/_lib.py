@@ -100,7 +100,7 @@ SIGNATURES = {
     "mopa_wino4_weight": ("i", "piiipp"),
     "mopa_wino4_weight_t": ("i", "piiipp"),
     "mopa_wino4_weight_f": ("i", "piiipp"),
-    "mopa_wino4_conv": ("i", "pipppiiiiiiipip"),
+    "mopa_wino4_conv": ("i", "pipppiiiiiiipipp"),
     "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),

@@ -474,6 +474,7 @@ MOPA_API int mopa_conv2d_weight_forms_batched(const int64_t* desc_host, int32_t 
 // on grids of at least two full rounds of blocks (>= 1024) and, at 64 input channels, from one round on; it loses to the batched
 // GEMM on ~570-block grids with more K per point (a 58-block tail round) and on the short deep levels: dense2d.wino4_fused.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
 // A^T of F(4x4,3x3), transposed: c_w4_at[j][c] = AT[c][j]
 __constant__ float c_w4_at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
 #define W4G_BM 64
@@ -775,10 +776,11 @@ MOPA_API int mopa_wino4_gemm_output(const float* V, const float* Ut, const float
 //              of the NEXT step's patch are touched in front of it (into L2).
 // BN: the input is a BatchNorm's input and relu(x * scale + shift) is convolved (LazyImg, as k_wino4_in<true>).
 template <bool BN>
-__global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in, int ld_in, const float* __restrict__ Uf,
+__global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__ in, int ld_in, const float* __restrict__ Uf,
                                                      const float* __restrict__ bias, float* __restrict__ out, int ld_out, int B, int H,
                                                      int W, int th, int tw, int Cin, int Cout, int accumulate,
-                                                     const float* __restrict__ stats, int imgs_per_group, int nitems
+                                                     const float* __restrict__ stats, int imgs_per_group, int nitems,
+                                                     float* __restrict__ Vout
 #ifdef W4C_PROFILE
                                                      , long long* prof
 #endif
@@ -789,25 +791,28 @@ __global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in
 #else
 #define W4C_T(K_)
 #endif
-  extern __shared__ __attribute__((aligned(16))) float w4c_lds[];   // [4][36][64] float4; the output tile [256][64] floats over it
+  extern __shared__ __attribute__((aligned(16))) float w4c_lds[];   // [2][36][64] float4; the output tile [256][64] floats over it
   f32x4w* __restrict__ lds = reinterpret_cast<f32x4w*>(w4c_lds);
   const int tid = threadIdx.x, lane = tid & 63, t = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ny = Cout >> 6;
   const int T = B * th * tw, tt = th * tw;
-  const int nround = Cin >> 6, nchunk = Cin >> 4, nnb = Cout >> 4;
+  const int nround = Cin >> 5, nchunk = Cin >> 4, nnb = Cout >> 4;
   const f32x4w zero4 = {0.f, 0.f, 0.f, 0.f};
   const int64_t pstride = (int64_t)nchunk * nnb * 64;   // float4 elements per transform point
   f32x4w acc[36];
 #pragma unroll
   for (int p = 0; p < 36; ++p) acc[p] = zero4;
-  f32x4w sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+  const f32x2w zero2 = {0.f, 0.f};
+  f32x2w sc = {1.f, 1.f}, sh = zero2;
   unsigned rmask = 0, cmask = 0;
   float pf_sink = 0.f;
-  // transform phase: lane = (tile tx_ = lane / 4, channel quad qx_ = lane % 4) -- four consecutive lanes read 64 contiguous bytes (with
-  // the MFMA numbering t + 16 q every lane of a load would start a segment of its own); the fragment goes to slot tx_ + 16 qx_
-  const int tx_ = lane >> 2, qx_ = lane & 3;
-  f32x4w bA[18], bB[18];
+  // transform phase: lane = (tile tx_ = lane / 4, channel pair pr_ = lane % 4 of the wave's 8 channels) -- four consecutive lanes read
+  // 32 contiguous bytes (with the MFMA numbering t + 16 q every lane of a load would start a segment of its own).  Channel
+  // 8 wv + 2 pr_ + e of the step = chunk wv / 2, quad qq_ = 2 (wv % 2) + pr_ / 2, half hh_ = pr_ % 2 of the float4 in slot tx_ + 16 qq_.
+  const int tx_ = lane >> 2, pr_ = lane & 3;
+  const int qq_ = ((wv & 1) << 1) + (pr_ >> 1), hh_ = pr_ & 1;
+  f32x4w bA[6], bB[6];
   // the patch of step (IT_, R_): tile coordinates, in-image masks, BatchNorm constants, 36 loads.  PF_: touch the lines only (into
   // L2, one step ahead: the 144 patch registers of a real prefetch do not fit beside the accumulators and the weight buffers) --
   // a dword load per lane into one scratch register that is kept alive until the next real patch has been waited for.
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in
     const int tb_ = tv_ ? tile_ / tt : 0, trt_ = tv_ ? tile_ - tb_ * tt : 0;                                  \
     const int tty_ = trt_ / tw, ttx_ = trt_ - tty_ * tw;                                                      \
     const int y0_ = 4 * tty_ - 1, x0_ = 4 * ttx_ - 1;                                                         \
-    const int ch0_ = ((R_) << 6) + (wv << 4) + 4 * qx_;                                                       \
+    const int ch0_ = ((R_) << 5) + (wv << 3) + 2 * pr_;                                                       \
     const float* __restrict__ pin_ = in + ((int64_t)(tb_ * H + y0_) * W + x0_) * ld_in + ch0_;               \
     const float* __restrict__ psafe_ = in + ch0_;                                                             \
     unsigned rm_ = 0, cm_ = 0;                                                                                \
@@ -830,22 +835,27 @@ __global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in
       rmask = rm_; cmask = cm_;                                                                               \
       if (BN) {                                                                                               \
         const float* __restrict__ sg_ = stats + (int64_t)(tb_ / imgs_per_group) * 4 * Cin + ch0_;            \
-        sc = *reinterpret_cast<const f32x4w*>(sg_);                                                           \
-        sh = *reinterpret_cast<const f32x4w*>(sg_ + Cin);                                                     \
+        sc = *reinterpret_cast<const f32x2w*>(sg_);                                                           \
+        sh = *reinterpret_cast<const f32x2w*>(sg_ + Cin);                                                     \
       }                                                                                                       \
     }                                                                                                         \
     _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_)                                                          \
       _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {                                                      \
         const bool ins_ = ((rm_ >> a_) & (cm_ >> c_) & 1u) != 0u;                                             \
         const float* __restrict__ src_ = ins_ ? pin_ + ((int64_t)a_ * W + c_) * ld_in : psafe_;              \
-        if (PF_) { if (qx_ == 0) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src_)); } /* "+": ONE register */ \
-        else d[a_][c_] = *reinterpret_cast<const f32x4w*>(src_);                                              \
+        if (PF_) { if (wv == 0 && pr_ == 0) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src_)); } /* "+": ONE register; one lane per 128-byte line */ \
+        else d[a_][c_] = *reinterpret_cast<const f32x2w*>(src_);                                              \
       }                                                                                                       \
   }
+#ifdef W4C_NOB   /* timing probe (wrong results): the weight fragments are loaded once per block */
+#define W4C_NOB_GUARD if (nob_first)
+#else
+#define W4C_NOB_GUARD
+#endif
 #define W4C_LOADB(BQ, C_, P0_)                                                                                \
   {                                                                                                           \
-    const f32x4w* __restrict__ ub_ = Ufw + (int64_t)((r << 2) + (C_)) * nnb * 64 + (int64_t)(P0_) * pstride;  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 18; ++i_) BQ[i_] = ub_[i_ * pstride];                            \
+    const f32x4w* __restrict__ ub_ = Ufw + (int64_t)((r << 1) + (C_)) * nnb * 64 + (int64_t)(P0_) * pstride;  \
+    W4C_NOB_GUARD _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) BQ[i_] = ub_[i_ * pstride];               \
   }
 #define W4C_MUL6(BQ, C_, P0_, I0_)                                                                            \
   {                                                                                                           \
@@ -859,36 +869,39 @@ __global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in
       acc[(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][3], BQ[(I0_) + i_][3], acc[(P0_) + (I0_) + i_], 0, 0, 0); \
     }                                                                                                         \
   }
-#define W4C_MUL(BQ, C_, P0_) { W4C_MUL6(BQ, C_, P0_, 0) W4C_MUL6(BQ, C_, P0_, 6) W4C_MUL6(BQ, C_, P0_, 12) }
+#define W4C_MUL(BQ, C_, P0_) W4C_MUL6(BQ, C_, P0_, 0)
   constexpr float AT[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
   int item = blockIdx.x, r = 0;
+#ifdef W4C_NOB
+  bool nob_first = true;
+#endif
   while (item < nitems) {
     const int tg = item / ny, n0 = (item - tg * ny) << 6;
     const f32x4w* __restrict__ Ufw = reinterpret_cast<const f32x4w*>(Uf) + (int64_t)((n0 >> 4) + wv) * 64 + lane;
     W4C_T(0)
     // ---- transform: patch -> V chunk wv (everyone is done with the LDS of the previous step: barrier at its end)
-    f32x4w d[6][6];
+    f32x2w d[6][6];
     W4C_PATCH(item, r, false);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const bool inside = ((rmask >> a) & (cmask >> c) & 1u) != 0u;
-        f32x4w v = d[a][c];
+        f32x2w v = d[a][c];
         if (BN) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 2; ++e) {
             const float o = fmaf(v[e], sc[e], sh[e]);
             v[e] = o > 0.f ? o : o * 0.f;
           }
         }
-        d[a][c] = inside ? v : zero4;
+        d[a][c] = inside ? v : zero2;
       }
     asm volatile("" :: "v"(pf_sink));   // (the touch loads of the previous step were issued before this patch: they have landed)
     W4C_T(1)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)
-      const f32x4w d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+      const f32x2w d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
       d[0][c] = 4.f * d0 - 5.f * d2 + d4;
       d[1][c] = -4.f * (d1 + d2) + d3 + d4;
       d[2][c] = 4.f * (d1 - d2) - d3 + d4;
@@ -897,30 +910,53 @@ __global__ __launch_bounds__(256) void k_wino4_conv(const float* __restrict__ in
       d[5][c] = 4.f * d1 - 5.f * d3 + d5;
     }
     {
-      f32x4w* __restrict__ lw = lds + (wv * 36) * 64 + tx_ + 16 * qx_;
+      f32x2w* __restrict__ lw = reinterpret_cast<f32x2w*>(w4c_lds) + (((wv >> 1) * 36) * 64 + tx_ + 16 * qq_) * 2 + hh_;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {   // (.) B
-        const f32x4w d0 = d[a][0], d1 = d[a][1], d2 = d[a][2], d3 = d[a][3], d4 = d[a][4], d5 = d[a][5];
-        lw[(a * 6 + 0) * 64] = 4.f * d0 - 5.f * d2 + d4;
-        lw[(a * 6 + 1) * 64] = -4.f * (d1 + d2) + d3 + d4;
-        lw[(a * 6 + 2) * 64] = 4.f * (d1 - d2) - d3 + d4;
-        lw[(a * 6 + 3) * 64] = -2.f * d1 - d2 + 2.f * d3 + d4;
-        lw[(a * 6 + 4) * 64] = 2.f * d1 - d2 - 2.f * d3 + d4;
-        lw[(a * 6 + 5) * 64] = 4.f * d1 - 5.f * d3 + d5;
+        const f32x2w d0 = d[a][0], d1 = d[a][1], d2 = d[a][2], d3 = d[a][3], d4 = d[a][4], d5 = d[a][5];
+        lw[(a * 6 + 0) * 128] = 4.f * d0 - 5.f * d2 + d4;
+        lw[(a * 6 + 1) * 128] = -4.f * (d1 + d2) + d3 + d4;
+        lw[(a * 6 + 2) * 128] = 4.f * (d1 - d2) - d3 + d4;
+        lw[(a * 6 + 3) * 128] = -2.f * d1 - d2 + 2.f * d3 + d4;
+        lw[(a * 6 + 4) * 128] = 2.f * d1 - d2 - 2.f * d3 + d4;
+        lw[(a * 6 + 5) * 128] = 4.f * d1 - 5.f * d3 + d5;
       }
     }
     W4C_LOADB(bA, 0, 0);
-    W4C_LOADB(bB, 0, 18);
+    W4C_LOADB(bB, 0, 6);
     const bool last_round = r + 1 == nround;
     const int nitem = last_round ? item + (int)gridDim.x : item, nr = last_round ? 0 : r + 1;
     W4C_T(2)
     __syncthreads();   // V is complete
     W4C_T(3)
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {   // (a loop, not 8 units of straight-line code: the scheduler would hoist every weight load)
-      W4C_MUL(bA, c, 0);   if (c < 3) W4C_LOADB(bA, c + 1, 0);
-      W4C_MUL(bB, c, 18);  if (c < 3) W4C_LOADB(bB, c + 1, 18);
+    if (Vout && n0 == 0) {
+      // training forward: V[36][T][Cin] goes to HBM as a by-product (the weight gradient multiplies it again) -- written once, not read
+      // by this layer.  A point is 16 tiles x 32 channels = two 1-KiB wave stores of whole 128-byte (tile, channel block) rows.
+      const int c8 = lane & 7, vt = lane >> 3;   // float4 c8 of the step's 32 channels = chunk c8 / 4, quad c8 % 4
+#pragma unroll 3
+      for (int k = 0; k < 9; ++k) {
+        const int p = wv + 4 * k;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int tl = vt + 8 * hf;
+          const f32x4w v = lds[((c8 >> 2) * 36 + p) * 64 + tl + 16 * (c8 & 3)];
+          if ((tg << 4) + tl < T)
+            *reinterpret_cast<f32x4w*>(Vout + ((int64_t)p * T + (tg << 4) + tl) * Cin + (r << 5) + 4 * c8) = v;
+        }
+      }
     }
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {   // (a loop, not 12 units of straight-line code: the scheduler would hoist every weight load)
+      W4C_MUL(bA, c, 0);   W4C_LOADB(bA, c, 12);
+      W4C_MUL(bB, c, 6);   W4C_LOADB(bB, c, 18);
+      W4C_MUL(bA, c, 12);  W4C_LOADB(bA, c, 24);
+      W4C_MUL(bB, c, 18);  W4C_LOADB(bB, c, 30);
+      W4C_MUL(bA, c, 24);  if (c < 1) W4C_LOADB(bA, c + 1, 0);
+      W4C_MUL(bB, c, 30);  if (c < 1) W4C_LOADB(bB, c + 1, 6);
+    }
+#ifdef W4C_NOB
+    nob_first = false;
+#endif
     W4C_T(4)
     __syncthreads();   // everyone is done reading V
     W4C_T(5)
@@ -1007,18 +1043,20 @@ MOPA_API int mopa_wino4_weight_f(const float* weight, int32_t O, int32_t I, int3
 // ld_out % 4 == 0.
 // stats != null: `in` is a BatchNorm's input, stats = [n_groups][4][Cin] (mopa_bn_act_fwd_groups with y == null), the B images are
 // n_groups equal consecutive groups and relu(batchnorm(in)) is what is convolved (as mopa_wino4_input_bn).
+// V != null: the transformed input [36][T][Cin] (what mopa_wino4_input would write: the same bits) is stored as a by-product -- the
+// forward pass of a training step keeps it for mopa_wino4_bwd_weight.
 MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, const float* bias, float* out, int32_t ld_out, int32_t B,
                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, const float* stats, int32_t n_groups,
-                             void* stream) {
+                             float* V, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || ld_in < Cin || (ld_in & 3) || ld_out < Cout ||
-      (ld_out & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+      (ld_out & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)V & 15))
     return MOPA_ERR_ARG;
   if (stats && (n_groups < 1 || B % n_groups)) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   const int64_t T = (int64_t)B * th * tw;
   const int64_t nitems = cdiv64(T, 16) * (Cout / 64);
   if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
-  const size_t ldsb = (size_t)4 * 36 * 64 * 16;
+  const size_t ldsb = (size_t)2 * 36 * 64 * 16;   // 72 KB: two workgroups per CU
   static bool attr[2] = {false, false};
   static int ncu = 0;
   if (!ncu) {
@@ -1033,15 +1071,15 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return MOPA_ERR_LAUNCH;
     attr[v] = true;
   }
-  const unsigned nblk = (unsigned)(nitems < ncu ? nitems : ncu);   // persistent: one workgroup per CU (144 KB of LDS each)
+  const unsigned nblk = (unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu);   // persistent: two workgroups per CU
 #ifdef W4C_PROFILE
   static long long* prof = nullptr;
   if (!prof) hipMallocManaged(&prof, 128);
   k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                             nullptr, 1, (int)nitems, prof);
+                                                             nullptr, 1, (int)nitems, V, prof);
   hipStreamSynchronize((hipStream_t)stream);
   {
-    const double n_ = (double)nitems / nblk * (Cin / 64);
+    const double n_ = (double)nitems / nblk * (Cin / 32);
     printf("[w4c profile] block 100 wave 0, cycles per step: loop head %.0f | patch wait + apply %.0f | transform, lds write, B + patch issue %.0f | "
            "barrier %.0f | multiply %.0f | barrier %.0f | fold + store %.0f   (steps per block %.1f)\n",
            prof[0] / n_, prof[1] / n_, prof[2] / n_, prof[3] / n_, prof[4] / n_, prof[5] / n_, prof[6] / n_, n_);
@@ -1049,10 +1087,10 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
 #else
   if (stats)
     k_wino4_conv<true><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                              stats, B / n_groups, (int)nitems);
+                                                              stats, B / n_groups, (int)nitems, V);
   else
     k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                               nullptr, 1, (int)nitems);
+                                                               nullptr, 1, (int)nitems, V);
 #endif
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

@@ -204,19 +204,24 @@ def wino4_fused(cin, cout, B, H, W):
 
 # F(4x4) layers that run as ONE kernel (mopa_wino4_conv: input transform, 36 GEMMs and output transform; neither V nor M reaches
 # HBM): 64-aligned channels on both sides and at least MOPA_WINO4_DIRECT_MIN_TILES tiles.  MOPA_WINO4_DIRECT=0 switches it off.
-WINO4_DIRECT = os.environ.get("MOPA_WINO4_DIRECT", "0") != "0"
+WINO4_DIRECT = os.environ.get("MOPA_WINO4_DIRECT", "1") != "0"
 WINO4_DIRECT_MIN_TILES = int(os.environ.get("MOPA_WINO4_DIRECT_MIN_TILES", "16384"))
 WINO4_DIRECT_MAX_CIN = int(os.environ.get("MOPA_WINO4_DIRECT_MAX_CIN", "128"))
+# Roles: "dgrad" (backward-data), "fwd_eval" (a forward pass that keeps nothing), "fwd" (the forward pass of a training step: it wants
+# V again for the weight gradient, the kernel stores it as a by-product and only a READ of V is saved -- measured neutral in the joint
+# step, 342 either way against 337 without the kernel, so it stays on the two-kernel path by default).
+WINO4_DIRECT_ROLES = tuple(r for r in os.environ.get("MOPA_WINO4_DIRECT_ROLES", "fwd_eval,dgrad").split(",") if r)
 
 
-def wino4_direct(cin, cout, B, H, W):
+def wino4_direct(cin, cout, B, H, W, role="fwd"):
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    return WINO4_DIRECT and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN and T >= WINO4_DIRECT_MIN_TILES
+    return (WINO4_DIRECT and role in WINO4_DIRECT_ROLES and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN
+            and T >= WINO4_DIRECT_MIN_TILES)
 
 
-def wino4_layout(cin, cout, B, H, W):
+def wino4_layout(cin, cout, B, H, W, role="fwd"):
     """Weight form of an F(4x4) layer: 2 = fragments (one-kernel convolution), 1 = transposed (fused GEMM + output transform), 0."""
-    return 2 if wino4_direct(cin, cout, B, H, W) else int(wino4_fused(cin, cout, B, H, W))
+    return 2 if wino4_direct(cin, cout, B, H, W, role) else int(wino4_fused(cin, cout, B, H, W))
 
 
 def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
@@ -263,7 +268,7 @@ def wino_eligible(cin, cout, k, s, p, B, H, W):
     return wino_tile(cin, cout, k, s, p, B, H, W) != 0
 
 
-def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2, bn_in=None):
+def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2, bn_in=None, role="fwd", want_v=True):
     """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform.
     U: wino_weight_cached(w, dgrad, F, transposed=(F == 4 and wino4_fused(cin, cout, B, H, W))).
     bn_in = (stats, G) (F = 4 only): x is a BatchNorm's input and relu(batchnorm(x)) is what gets convolved (LazyImg)."""
@@ -271,12 +276,14 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     th, tw = (H + F - 1) // F, (W + F - 1) // F
     T, NP = B * th * tw, (F + 2) ** 2
     sfx = "" if F == 2 else "4"
-    if F == 4 and wino4_direct(cin, cout, B, H, W):
+    if F == 4 and wino4_direct(cin, cout, B, H, W, role):
         if tuple(U.shape) != (36, cin, cout):
             raise RuntimeError("wino_conv: the one-kernel F(4x4) path takes the fragment weight form")
+        V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev) if want_v else None   # (a by-product, for the weight gradient)
         call("mopa_wino4_conv", x_p, ld_in, ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
-             int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1, stream())
-        return None   # no V: the weight gradient transforms the input itself
+             int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1,
+             ptr(V) if V is not None else None, stream())
+        return V
     V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
     if bn_in is not None:
         if F != 4:
@@ -422,13 +429,15 @@ class ConvOp:
     def forward(self, x: Img, out: Img, keep_v: bool = False):
         """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
         F = wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "fwd")
+        drole = "fwd" if keep_v else "fwd_eval"
         lazy = getattr(x, "bn", None)
         if lazy is not None and not self.takes_lazy(x.B, x.H, x.W, keep_v):
             raise RuntimeError("ConvOp.forward: this layer cannot consume a deferred BatchNorm (ask takes_lazy first)")
         if F:
             V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O,
-                          wino_weight_cached(self.w, False, F, wino4_layout(self.I, self.O, x.B, x.H, x.W) if F == 4 else 0), self.b, out.p, out.ld,
-                          F=F, bn_in=lazy)
+                          wino_weight_cached(self.w, False, F, wino4_layout(self.I, self.O, x.B, x.H, x.W, drole) if F == 4 else 0), self.b, out.p,
+                          out.ld, F=F, bn_in=lazy, role=drole, want_v=keep_v and F == 4 and wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad") == 4
+                          and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W))
             same = F == wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad")   # V serves the weight gradient
             return V if V is not None and keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
@@ -458,8 +467,8 @@ class ConvOp:
         F = wino_tile(self.O, self.I, k, s, p, x.B, x.H, x.W, "dgrad")   # backward-data of a stride-1 3x3 conv is one, too
         if F:
             wino_conv(dout.p, dout.ld, x.B, x.H, x.W, self.O, self.I,
-                      wino_weight_cached(self.w, True, F, wino4_layout(self.O, self.I, x.B, x.H, x.W) if F == 4 else 0), None, dx.p, dx.ld, acc_dx,
-                      F=F)
+                      wino_weight_cached(self.w, True, F, wino4_layout(self.O, self.I, x.B, x.H, x.W, "dgrad") if F == 4 else 0), None, dx.p,
+                      dx.ld, acc_dx, F=F, role="dgrad", want_v=False)
             return
         wt = relayout_cached(self.w, (k, k, self.O, self.I), self.O, self.I, k, k, 1)
         if s == 1:

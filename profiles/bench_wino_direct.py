@@ -27,6 +27,8 @@ def timed(fn, reps=6):
 
 
 dense2d.WINO4_DIRECT_MAX_CIN = 1 << 30
+dense2d.WINO4_DIRECT = True
+dense2d.WINO4_DIRECT_ROLES = ("fwd", "fwd_eval", "dgrad")
 for name, cin, cout, H, W in shapes:
     x = torch.randn(B * H * W, cin, device="cuda")
     w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05

@@ -882,6 +882,8 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
     O, I = (cin, cout) if dgrad else (cout, cin)
     outs = []
     for direct in (True, False):
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT", True)
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT_ROLES", ("fwd", "fwd_eval", "dgrad"))
         monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 0 if direct else 1 << 62)
         monkeypatch.setattr(dense2d, "WINO4_FUSED_MIN_BLOCKS", 0)
         assert dense2d.wino4_direct(cin, cout, B, H, W) == direct
@@ -889,8 +891,54 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
         call("mopa_wino4_weight_f" if direct else "mopa_wino4_weight_t", ptr(w), O, I, int(dgrad), ptr(U), stream())
         out = prev.clone() if acc else torch.full((B * H * W, cout), float("nan"), device="cuda")
         V = dense2d.wino_conv(xin.p, xin.ld, B, H, W, cin, cout, U, None if acc else bias, ptr(out), cout, accumulate=acc, F=4,
-                              bn_in=(stats, G) if G else None)
-        assert (V is None) == direct
+                              bn_in=(stats, G) if G else None, want_v=not acc)
+        if direct and not acc:   # the by-product: the bits mopa_wino4_input writes for the tensor the convolution sees
+            Vr = torch.empty_like(V)
+            xs = x.reshape(B * H * W, cin).contiguous()
+            call("mopa_wino4_input", ptr(xs), cin, B, H, W, cin, ptr(Vr), stream())
+            assert torch.equal(V, Vr)
+        assert (V is None) == (direct and acc)
         _close(out, ref.float().numpy(), rtol=1e-4, atol=3e-5)
         outs.append(out)
     _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
+
+
+def test_one_kernel_convolution_network_level(monkeypatch):
+    """The whole network with mopa_wino4_conv forced on for every eligible layer and role (forward with the V by-product for the weight
+    gradient, deferred BatchNorm on the way in, backward-data) against the default algorithm choice at this size: logits to 1e-3,
+    parameter gradients like two algorithms agree on this small, badly conditioned input (5 % of each tensor's L2 norm; see
+    test_source_and_target_batch_in_one_pass_equal_two_calls), running statistics to fp32 round-off."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    batch = synth.make_batch(4, H=96, W=128)
+    batch["bn_groups"] = 2
+
+    def run(direct):
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT", direct)
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT_ROLES", ("fwd", "fwd_eval", "dgrad"))
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 0)
+        torch.manual_seed(5)
+        m = build_model_2d(default_cfg())[0].cuda().train()
+        m.output_all = True
+        o = m(batch)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        sum((o[k] * torch.randn(o[k].shape, device="cuda", generator=g)).sum() for k in ("seg_logit", "seg_logit2", "seg_logit_all")).backward()
+        torch.cuda.synchronize()
+        return o["seg_logit"].detach().clone(), [(n, p.grad.clone()) for n, p in m.named_parameters() if p.grad is not None], \
+            {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+
+    calls = []
+    inner = dense2d.call
+    monkeypatch.setattr(dense2d, "call", lambda name, *a: (calls.append(name), inner(name, *a))[1])
+    la, ga, ba = run(False)
+    assert calls.count("mopa_wino4_conv") == 0
+    lb, gb, bb = run(True)
+    assert calls.count("mopa_wino4_conv") >= 20, calls.count("mopa_wino4_conv")
+    _close(lb, la.cpu(), rtol=1e-3, atol=2e-4)
+    for k in ba:
+        _close(bb[k], ba[k].cpu(), rtol=1e-4, atol=1e-5)
+    floor = 1e-3 * max(float(g.norm()) for _, g in ga)
+    for (n, a), (_, b) in zip(ga, gb):
+        err = float((a - b).norm() / (a.norm() + floor))
+        assert err <= 5e-2, (n, err)
