@@ -156,15 +156,17 @@ class Conv2dTimer:
         inner_call = dense2d.call
 
         def wrapped_call(name, *a):   # the fused F(4x4) GEMM + output-transform kernel belongs to the same family
-            if not timer.enabled or name != "mopa_wino4_gemm_output":
+            if not timer.enabled or name not in ("mopa_wino4_gemm_output", "mopa_wino4_conv"):
                 return inner_call(name, *a)
-            B, H, W, cin, cout = a[5], a[6], a[7], a[8], a[9]
+            one = name == "mopa_wino4_conv"   # the one-kernel convolution: input transform + GEMMs + output transform (no V)
+            B, H, W, cin, cout = (a[6], a[7], a[8], a[9], a[10]) if one else (a[5], a[6], a[7], a[8], a[9])
             T = B * ((H + 3) // 4) * ((W + 3) // 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = inner_call(name, *a)
             e.record()
-            timer.records.append((s, e, 4 * (36 * T * cin + B * H * W * cout + 36 * cin * cout), 2 * 36 * T * cin * cout, 2 * 16 * T * cin * cout * 9))
+            in_bytes = B * H * W * cin if one else 36 * T * cin
+            timer.records.append((s, e, 4 * (in_bytes + B * H * W * cout + 36 * cin * cout), 2 * 36 * T * cin * cout, 2 * 16 * T * cin * cout * 9))
             return r
 
         dense2d.call = wrapped_call
@@ -175,6 +177,12 @@ class Conv2dTimer:
 def f4_roles():
     from mopa_amd import dense2d
     return tuple(dense2d.F4_ROLES)
+
+
+def one_kernel_roles():
+    """Passes whose eligible F(4x4) layers run as one kernel (mopa_wino4_conv: no V / M in HBM)."""
+    from mopa_amd import dense2d
+    return tuple(dense2d.WINO4_DIRECT_ROLES) if dense2d.WINO4_DIRECT else ()
 
 
 def dense2d_streams():
@@ -1071,14 +1079,14 @@ def main():
         tj = {}
         if joint and os.path.exists(tpath):                                      # of this same command (profiles/traffic.py)
             tj = json.load(open(tpath))
-            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out") if k in tj]
+            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv") if k in tj]
             if fam:
                 traffic = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": f"{os.path.relpath(tpath, ROOT)} at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
+                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out + k_wino4_conv (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
@@ -1126,6 +1134,7 @@ def main():
                        "allreduces_per_step": round(sum(o.n_collectives for o in opts) / max(1, steps_run[0]), 2),
                        "gradient_buckets_2d_bytes": bucket_bytes,
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
+                       "winograd_f4_one_kernel_roles": (",".join(one_kernel_roles()) or None) if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
                        else "python walk (MOPA_SCN_NATIVE=0)",
                        "net3d_pass": (None if not joint else "source + target scans as ONE sparse tensor (Net3DSeg bn_group_points: BatchNorm per domain "

@@ -847,15 +847,10 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
         else d[a_][c_] = *reinterpret_cast<const f32x2w*>(src_);                                              \
       }                                                                                                       \
   }
-#ifdef W4C_NOB   /* timing probe (wrong results): the weight fragments are loaded once per block */
-#define W4C_NOB_GUARD if (nob_first)
-#else
-#define W4C_NOB_GUARD
-#endif
 #define W4C_LOADB(BQ, C_, P0_)                                                                                \
   {                                                                                                           \
     const f32x4w* __restrict__ ub_ = Ufw + (int64_t)((r << 1) + (C_)) * nnb * 64 + (int64_t)(P0_) * pstride;  \
-    W4C_NOB_GUARD _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) BQ[i_] = ub_[i_ * pstride];               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) BQ[i_] = ub_[i_ * pstride];                             \
   }
 #define W4C_MUL6(BQ, C_, P0_, I0_)                                                                            \
   {                                                                                                           \
@@ -872,9 +867,6 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
 #define W4C_MUL(BQ, C_, P0_) W4C_MUL6(BQ, C_, P0_, 0)
   constexpr float AT[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
   int item = blockIdx.x, r = 0;
-#ifdef W4C_NOB
-  bool nob_first = true;
-#endif
   while (item < nitems) {
     const int tg = item / ny, n0 = (item - tg * ny) << 6;
     const f32x4w* __restrict__ Ufw = reinterpret_cast<const f32x4w*>(Uf) + (int64_t)((n0 >> 4) + wv) * 64 + lane;
@@ -954,9 +946,6 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
       W4C_MUL(bA, c, 24);  if (c < 1) W4C_LOADB(bA, c + 1, 0);
       W4C_MUL(bB, c, 30);  if (c < 1) W4C_LOADB(bB, c + 1, 6);
     }
-#ifdef W4C_NOB
-    nob_first = false;
-#endif
     W4C_T(4)
     __syncthreads();   // everyone is done reading V
     W4C_T(5)
