@@ -105,6 +105,8 @@ SIGNATURES = {
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),
     "mopa_wino4_input_bn": ("i", "piiiiipipp"),
+    "mopa_bn_bwd_sums_groups": ("i", "pipiiiiiipfipippippzp"),
+    "mopa_stem_bwd_weight_bn": ("i", "ppipippiippipzp"),
     "mopa_wino4_output": ("i", "piiiippiip"),
     "mopa_wino4_dout": ("i", "piiiiipp"),
     "mopa_wino4_wgrad_workspace_bytes": ("z", "iii"),

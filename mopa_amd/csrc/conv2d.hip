@@ -678,12 +678,26 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_mfma(const float* __restri
 // 14 taps over a slice of the pixels, so the output-gradient tile is read once (the per-filter-row blocks of the generic kernel
 // read it 7 times: that kernel is bound by those 2 GB, not by its FMAs).  GEMM rows = (tap, ci) = 224 = 7 row tiles of 32 (one
 // filter row each), 2 column tiles; wave w: column tile w & 1, row tiles (w >> 1), +2, +4(, +6).
+// BNB: dy is the gradient of relu(batchnorm(conv)) -- the gradient w.r.t. the convolution's output, dx = scale * (dz - mean(dz) -
+// xhat * mean(dz * xhat)) with dz = dy where the BatchNorm output was positive (the expressions of k_bn_bwd_apply), is formed while the
+// tile is staged, from dy, the BatchNorm's input xbn, its stats[G][4][64] and coef[G][2][64] (mopa_bn_bwd_sums_groups): the stem's
+// BatchNorm backward needs no apply pass (read dy + x, write dx: 1.8 GB at 16 images) and dx is never stored.
 #define STEM_ROWS 224
+struct StemBn { const float* xbn; const float* stats; const float* coef; int ld_x, ld_dy, imgs_per_group, n_groups, training; };
+template <bool BNB>
 __global__ __launch_bounds__(256) void k_stem_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
-                                                          float* __restrict__ slabs, const ConvGeom g, int m_per_split) {
+                                                          float* __restrict__ slabs, const ConvGeom g, int m_per_split, const StemBn bn) {
   __shared__ __attribute__((aligned(16))) float As[2][WBK][STEM_ROWS + 4];
   __shared__ __attribute__((aligned(16))) float Bs[2][WBK][64 + 4];
+  __shared__ __attribute__((aligned(16))) float cst[BNB ? 3 : 1][6][BNB ? 64 : 4];   // per group: scale, shift, mean, invstd, coef0, coef1
   const int t = threadIdx.x;
+  if (BNB) {
+    for (int i = t; i < bn.n_groups * 6 * 64; i += 256) {
+      const int gi = i / 384, k = (i - gi * 384) >> 6, c = i & 63;
+      cst[gi][k][c] = k < 4 ? bn.stats[(gi * 4 + k) * 64 + c] : bn.coef[(gi * 2 + (k - 4)) * 64 + c];
+    }
+    __syncthreads();
+  }
   const int M = g.B * g.OHl * g.OWl, ohw = g.OHl * g.OWl;
   const int mbeg = blockIdx.x * m_per_split, mend = min(M, mbeg + m_per_split);
   const int lane = t & 63, wv = t >> 6;
@@ -703,7 +717,8 @@ __global__ __launch_bounds__(256) void k_stem_wgrad_mfma(const float* __restrict
     aq[j] = idx - apx[j] * 56;
   }
   const int bpx = t >> 4, bq = t & 15;
-  float4 ra[4], rb;
+  float4 ra[4], rb, rx;
+  int rgi = 0;
   // pixel (b, oy, ox) of each of this thread's 5 loads in the NEXT chunk: decomposed once, then advanced by WBK pixels per chunk
   int pb[5], py[5], px[5];
 #pragma unroll
@@ -734,8 +749,12 @@ __global__ __launch_bounds__(256) void k_stem_wgrad_mfma(const float* __restrict
         }
       } else {
         rb = z;
-        if (mb + bpx < mend)
-          rb = *reinterpret_cast<const float4*>(dy + ((int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX) * g.ld_out + bq * 4);
+        if (BNB) { rx = z; rgi = b / bn.imgs_per_group; }
+        if (mb + bpx < mend) {
+          const int64_t pix = (int64_t)(b * g.OHa + oy * g.OS + g.OOY) * g.OWa + ox * g.OS + g.OOX;
+          rb = *reinterpret_cast<const float4*>(dy + pix * (BNB ? bn.ld_dy : g.ld_out) + bq * 4);
+          if (BNB) rx = *reinterpret_cast<const float4*>(bn.xbn + pix * bn.ld_x + bq * 4);
+        } else if (BNB) rgi = -1;
       }
     }
   };
@@ -743,6 +762,24 @@ __global__ __launch_bounds__(256) void k_stem_wgrad_mfma(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (t + 256 * j < 896) *reinterpret_cast<float4*>(&As[buf][apx[j]][aq[j] * 4]) = ra[j];
+    if (BNB && rgi >= 0) {
+      const float gs[4] = {rb.x, rb.y, rb.z, rb.w}, xs[4] = {rx.x, rx.y, rx.z, rx.w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = bq * 4 + j;
+        const float sc = cst[rgi][0][c], sh = cst[rgi][1][c], mean = cst[rgi][2][c], inv = cst[rgi][3][c], c0 = cst[rgi][4][c], c1 = cst[rgi][5][c];
+        const float yv = fmaf(xs[j], sc, sh);
+        const float dz = yv > 0.f ? gs[j] : gs[j] * 0.f;
+        if (bn.training) {
+          const float xhat = (xs[j] - mean) * inv;
+          o[j] = sc * (dz - c0 - xhat * c1);
+        } else {
+          o[j] = sc * dz;
+        }
+      }
+      rb = make_float4(o[0], o[1], o[2], o[3]);
+    }
     *reinterpret_cast<float4*>(&Bs[buf][bpx][bq * 4]) = rb;
   };
   int buf = 0;
@@ -890,7 +927,7 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
       k_conv2d_wgrad<64, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
     }
   } else if (stem_wgrad_mfma(g)) {
-    k_stem_wgrad_mfma<<<ns, 256, 0, st>>>(in, dy, slabs, g, mps);
+    k_stem_wgrad_mfma<false><<<ns, 256, 0, st>>>(in, dy, slabs, g, mps, StemBn{});
   } else if (wgrad_ntap(g) == 2) {
     dim3 grid(g.TH * g.TW / 2, g.Cout / 64, ns);
     k_conv2d_wgrad<16, 2><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
@@ -898,6 +935,33 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
     dim3 grid(g.TH * g.TW, g.Cout / 64, ns);
     k_conv2d_wgrad<16, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
   }
+  const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
+  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// The stem's weight gradient with its BatchNorm's backward apply folded into the load of dy (k_stem_wgrad_mfma<true>): `dy` is the
+// gradient of relu(batchnorm(conv)) (row stride ld_dy), xbn the BatchNorm's input = the convolution's output (row stride ld_x),
+// stats = [n_groups][4][64] of the forward pass, coef = [n_groups][2][64] from mopa_bn_bwd_sums_groups; the B images are n_groups equal
+// consecutive groups.  Same geometry, flags and workspace as mopa_conv2d_bwd_weight; the 7x7 / 16-wide-tap stem only.
+MOPA_API int mopa_stem_bwd_weight_bn(const float* in, const float* dy, int32_t ld_dy, const float* xbn, int32_t ld_x, const float* stats,
+                                     const float* coef, int32_t n_groups, int32_t training, float* dweight, const int32_t* geom_host,
+                                     int32_t flags, void* ws, size_t ws_bytes, void* stream) {
+  ConvGeom g;
+  memcpy(&g, geom_host, sizeof(g));
+  const int accumulate = flags & 1, oihw = (flags >> 1) & 1;
+  if (!stem_wgrad_mfma(g) || g.OS != 1 || g.OOY != 0 || g.OOX != 0 || n_groups < 1 || n_groups > 3 || g.B % n_groups || ld_dy < 64 ||
+      ld_x < 64 || ((ld_dy | ld_x | g.ld_in) & 3) || !xbn || !stats || !coef)
+    return MOPA_ERR_ARG;
+  if (oihw && (g.KS != 1 || g.KH0 != 0 || g.KW0 != 0 || g.KWF != g.TW)) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_conv2d_wgrad_workspace_bytes(geom_host)) return MOPA_ERR_WORKSPACE;
+  int ns, mps;
+  wgrad_split(g, &ns, &mps);
+  hipStream_t st = (hipStream_t)stream;
+  float* slabs = (float*)ws;
+  StemBn bn{xbn, stats, coef, ld_x, ld_dy, g.B / n_groups, n_groups, training};
+  k_stem_wgrad_mfma<true><<<ns, 256, 0, st>>>(in, dy, slabs, g, mps, bn);
   const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
   k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout);
   MOPA_CHECK_LAUNCH();

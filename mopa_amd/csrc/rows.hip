@@ -411,6 +411,27 @@ MOPA_API int mopa_bn_act_bwd_groups(const float* dy, int32_t ld_dy, const float*
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
+// The reduction half of mopa_bn_act_bwd_groups alone: parameter gradients and coef_out[n_groups][2][C] = (mean(dz), mean(dz * xhat)) per
+// group -- for a consumer that applies dx = scale * (dz - coef0 - xhat * coef1) while it reads (dy, x) itself (mopa_stem_bwd_weight_bn:
+// the stem's BatchNorm gradient is read once, by the stem's weight gradient, and never written).
+MOPA_API int mopa_bn_bwd_sums_groups(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, int32_t num_rows, int32_t C,
+                                     int32_t n_groups, int32_t split1, int32_t split2, const float* stats, float leak, int32_t act,
+                                     const float* ymask, int32_t ld_ym, float* dgamma, float* dbeta, int32_t accumulate_param_grads,
+                                     float* coef_out, void* ws, size_t ws_bytes, void* stream) {
+  if (num_rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ldx < C || ld_dy < C || ((ldx | ld_dy) & 3) || !coef_out) return MOPA_ERR_ARG;
+  if (ymask && (ld_ym < C || (ld_ym & 3))) return MOPA_ERR_ARG;
+  if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
+  BnGroups grp;
+  if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  const int RL = 256 / (C >> 2);
+  k_bn_bwd_partial<<<dim3(grp.nblk_max, grp.n), 256, (size_t)2 * RL * C * sizeof(float), st>>>(dy, ld_dy, x, ldx, C, stats, leak, ymask,
+                                                                                               ld_ym, act, grp, partial);
+  k_bn_bwd_finalize<<<C, 256, 0, st>>>(partial, grp, C, dgamma, dbeta, accumulate_param_grads, coef_out);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
 MOPA_API int mopa_bn_act_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ldx, float* dx, int32_t ld_dx,
                              int32_t num_rows, int32_t C, const float* stats, float leak, int32_t act,
                              const float* ymask, int32_t ld_ym, float* dres, int32_t ld_dres, int32_t accumulate_dres,

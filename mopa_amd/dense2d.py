@@ -536,6 +536,8 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
 GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the BatchNorm groups of one pass in one set of launches
 # A/B switch: bn1 of a ResNet block is applied inside conv2's input transform instead of being written out (LazyImg)
 DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
+# A/B switch: the stem BatchNorm's backward apply inside the stem's weight gradient (mopa_stem_bwd_weight_bn: dx is never written)
+STEM_BN_FUSED_BWD = os.environ.get("MOPA_STEM_BN_FUSED_BWD", "1") != "0"
 
 
 def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
@@ -763,9 +765,20 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
                 else:
                     dres = like(res)
                     gmap[k] = dres
+            (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
+            if (STEM_BN_FUSED_BWD and name == pre + "bn1" and not want_dimg and res is None and act == 1
+                    and all(gt is None for gt in gathered) and x.C == 64):
+                # the stem's BatchNorm: its input gradient has ONE reader, the stem's weight gradient, which forms it from (dy, x)
+                # itself -- sums + parameter gradients here, no apply pass, no dx tensor
+                n = x.rows // G
+                coef = torch.empty(G, 2, x.C, dtype=torch.float32, device=dev)
+                ws = _ws(query("mopa_bnrelu_rows_workspace_bytes", x.rows, x.C), dev)
+                call("mopa_bn_bwd_sums_groups", dy.p, dy.ld, x.p, x.ld, x.rows, x.C, G, n, 2 * n, ptr(stats), 0.0, int(act), None, 0,
+                     ptr(dg), ptr(db), int(pacc), ptr(coef), ptr(ws), ws.numel(), stream())
+                gmap[key(x)] = ("bn", dy, x, stats, coef)
+                continue
             dx = like(x)
             gmap[key(x)] = dx
-            (dg, db), pacc = sink.take(name + ".weight", name + ".bias")
             if G > 1 and GROUPED_BN and all(gt is None for gt in gathered):
                 bn_bwd_groups(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, training, dg, db, G, acc_params=pacc)
             else:
@@ -816,9 +829,16 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             _, x4, c1, g = rec
             dout = gmap.pop(key(c1))
             (dw,), pacc = sink.take(pre + "conv1.weight")
-            with _on(wgrad_stream(dev), dout.t):
+            lazy = dout if isinstance(dout, tuple) else None   # ("bn", dy, x, stats, coef): the BatchNorm above left its apply to us
+            with _on(wgrad_stream(dev), (lazy[1] if lazy else dout).t):
                 dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
-                wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
+                if lazy:
+                    _, bdy, bx, bstats, bcoef = lazy
+                    ws = _ws(query("mopa_conv2d_wgrad_workspace_bytes", ctypes.addressof(g)), dev)
+                    call("mopa_stem_bwd_weight_bn", ptr(x4), bdy.p, bdy.ld, bx.p, bx.ld, ptr(bstats), ptr(bcoef), G, int(training), ptr(dwl),
+                         ctypes.addressof(g), 0, ptr(ws), ws.numel(), stream())
+                else:
+                    wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
                 call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
             if want_dimg:   # gradient w.r.t. the image itself (not asked for by MoPA's training)
                 dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)

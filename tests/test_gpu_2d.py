@@ -942,3 +942,42 @@ def test_one_kernel_convolution_network_level(monkeypatch):
     for (n, a), (_, b) in zip(ga, gb):
         err = float((a - b).norm() / (a.norm() + floor))
         assert err <= 5e-2, (n, err)
+
+
+@pytest.mark.parametrize("groups,training", [(1, True), (2, True), (1, False)])
+def test_stem_batchnorm_backward_inside_the_stem_weight_gradient(groups, training, monkeypatch):
+    """STEM_BN_FUSED_BWD: the stem BatchNorm's backward is sums + parameter gradients only, the stem's weight gradient forms dx from
+    (dy, x, stats, coef) while it stages its tiles (mopa_bn_bwd_sums_groups + mopa_stem_bwd_weight_bn) -- against the apply pass + plain
+    weight gradient: every parameter gradient of the network (conv1.weight and bn1 are the ones that could move) to 1e-6 of its scale,
+    logits identical; also in eval mode (running statistics, dx = scale * dz) and with two BatchNorm groups."""
+    from mopa_amd import dense2d, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_2d
+    batch = synth.make_batch(2 * groups, H=80, W=112)
+    if groups > 1:
+        batch["bn_groups"] = groups
+
+    def run(fused):
+        monkeypatch.setattr(dense2d, "STEM_BN_FUSED_BWD", fused)
+        torch.manual_seed(9)
+        m = build_model_2d(default_cfg())[0].cuda()
+        m = m.train() if training else m.eval()
+        o = m(batch)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        sum((o[k] * torch.randn(o[k].shape, device="cuda", generator=g)).sum() for k in ("seg_logit", "seg_logit2")).backward()
+        torch.cuda.synchronize()
+        return o["seg_logit"].detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    calls = []
+    inner = dense2d.call
+    monkeypatch.setattr(dense2d, "call", lambda name, *a: (calls.append(name), inner(name, *a))[1])
+    la, ga = run(False)
+    assert "mopa_stem_bwd_weight_bn" not in calls
+    lb, gb = run(True)
+    assert calls.count("mopa_stem_bwd_weight_bn") == 1 and calls.count("mopa_bn_bwd_sums_groups") == 1
+    assert torch.equal(la, lb)
+    for n in ga:
+        scale = float(ga[n].abs().max()) + 1e-20
+        err = float((ga[n] - gb[n]).abs().max()) / scale
+        assert err <= 1e-6, (n, err)
+    assert float(gb["net_2d.conv1.weight"].abs().max()) > 0
