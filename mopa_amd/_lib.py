@@ -100,11 +100,11 @@ SIGNATURES = {
     "mopa_wino4_weight": ("i", "piiipp"),
     "mopa_wino4_weight_t": ("i", "piiipp"),
     "mopa_wino4_weight_f": ("i", "piiipp"),
-    "mopa_wino4_conv": ("i", "pipppiiiiiiipipp"),
+    "mopa_wino4_conv": ("i", "pipppiiiiiiipiipp"),
     "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),
-    "mopa_wino4_input_bn": ("i", "piiiiipipp"),
+    "mopa_wino4_input_bn": ("i", "piiiiipiipp"),
     "mopa_bn_bwd_sums_groups": ("i", "pipiiiiiipfipippippzp"),
     "mopa_stem_bwd_weight_bn": ("i", "ppipippiippipzp"),
     "mopa_wino4_output": ("i", "piiiippiip"),

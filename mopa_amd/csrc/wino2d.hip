@@ -207,14 +207,25 @@ MOPA_API int mopa_wino_dout(const float* dy, int32_t ld, int32_t B, int32_t H, i
 // fp32 error is about 10x that of the direct sum (still ~1e-6 relative per layer); used where it pays (dense2d.wino_tile).
 // Thread = (tile, channel): consecutive lanes are consecutive channels, every access is a coalesced 256-byte run.  (2 or 4
 // channels per thread were measured: the same times within 3 % -- the transforms move 3.25x the tensor and sit at 4.3-4.7 TB/s.)
-__device__ __forceinline__ void w4_bt(const float d[6], float t[6]) {   // t = B^T d
-  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+// t = B^T d with every multiply-add written as ONE fused operation: the scalar instantiation (k_wino4_in, with or without the BatchNorm
+// on the way in) and the vector ones (k_wino4_conv) then round alike whatever the compiler would have contracted in each context --
+// "V has the same bits on every path" is a tested property (15 operations).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float w4_fma(float a, float x, float y) { return fmaf(a, x, y); }
+__device__ __forceinline__ f32x2v w4_fma(float a, f32x2v x, f32x2v y) { return __builtin_elementwise_fma((f32x2v)(a), x, y); }
+__device__ __forceinline__ f32x4v w4_fma(float a, f32x4v x, f32x4v y) { return __builtin_elementwise_fma((f32x4v)(a), x, y); }
+template <class T>
+__device__ __forceinline__ void w4_bt6(T d0, T d1, T d2, T d3, T d4, T d5, T& t0, T& t1, T& t2, T& t3, T& t4, T& t5) {
+  const T e42 = d4 - d2;
+  t0 = w4_fma(4.f, d0, w4_fma(-5.f, d2, d4));
+  t1 = w4_fma(-4.f, d1 + d2, d3 + d4);
+  t2 = w4_fma(4.f, d1 - d2, d4 - d3);
+  t3 = w4_fma(2.f, d3 - d1, e42);
+  t4 = w4_fma(2.f, d1 - d3, e42);
+  t5 = w4_fma(4.f, d1, w4_fma(-5.f, d3, d5));
 }
+__device__ __forceinline__ void w4_bt(const float d[6], float t[6]) { w4_bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[0], t[1], t[2], t[3], t[4], t[5]); }
 __device__ __forceinline__ void w4_at(const float m[6], float y[4]) {   // y = A^T m
   const float a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
   y[0] = m[0] + a + c;
@@ -246,7 +257,7 @@ __global__ void k_wino4_w(const float* __restrict__ w, int O, int I, int dgrad, 
 // expression of k_bn_relu_apply, so V is bit-identical to transforming the materialised y; the zero padding stays zero.
 template <bool BN>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, int ld_in, int B, int H, int W, int C, int th, int tw,
-                                                   float* __restrict__ V, const float* __restrict__ stats, int imgs_per_group) {
+                                                   float* __restrict__ V, const float* __restrict__ stats, int imgs_per_group, int c0) {
   const int64_t T = (int64_t)B * th * tw;
   const int64_t total = T * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -256,9 +267,12 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, 
     const int rt = (int)(t - (int64_t)b * th * tw);
     const int ty = rt / tw, tx = rt - ty * tw;
     float sc = 1.f, sh = 0.f;
-    if (BN) {
-      const float* __restrict__ sg = stats + (int64_t)(b / imgs_per_group) * 4 * C;
-      sc = sg[ch]; sh = sg[C + ch];
+    // channels [c0, C) are the BatchNorm's (stats rows of C - c0 values); channels below c0 -- the skip half of a decoder join buffer,
+    // already relu(batchnorm(.)) -- are left alone (a wave's 64 lanes are 64 consecutive channels: the branch is uniform for c0 % 64 == 0)
+    const bool bn_ch = BN && ch >= c0;
+    if (bn_ch) {
+      const float* __restrict__ sg = stats + (int64_t)(b / imgs_per_group) * 4 * (C - c0);
+      sc = sg[ch - c0]; sh = sg[C - c0 + ch - c0];
     }
     float m[6][6];
 #pragma unroll
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ in, 
         const int y = 4 * ty - 1 + a;
         const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         d[a] = inside ? in[((int64_t)(b * H + y) * W + x) * ld_in + ch] : 0.f;
-        if (BN && inside) {
+        if (bn_ch && inside) {
           const float o = fmaf(d[a], sc, sh);
           d[a] = o > 0.f ? o : o * 0.f;
         }
@@ -381,18 +395,20 @@ MOPA_API int mopa_wino4_weight(const float* weight, int32_t O, int32_t I, int32_
 MOPA_API int mopa_wino4_input(const float* in, int32_t ld_in, int32_t B, int32_t H, int32_t W, int32_t C, float* V, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
-  k_wino4_in<false><<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V, nullptr, 1);
+  k_wino4_in<false><<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V, nullptr, 1, 0);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
 // V of relu(batchnorm(in)): `in` is the BatchNorm's INPUT, stats = [n_groups][4][C] as mopa_bn_act_fwd_groups wrote it (scale, shift,
 // mean, invstd), the B images are n_groups equal consecutive groups.  Bit-identical to mopa_wino4_input on the applied tensor.
+// bn_c0 > 0: only channels [bn_c0, C) belong to the BatchNorm (stats = [n_groups][4][C - bn_c0]); the channels below are a tensor that is
+// non-negative already and pass through -- a decoder join buffer [skip | raw up-convolution] whose second half is normalised on the way in.
 MOPA_API int mopa_wino4_input_bn(const float* in, int32_t ld_in, int32_t B, int32_t H, int32_t W, int32_t C, const float* stats,
-                                 int32_t n_groups, float* V, void* stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C || !stats || n_groups < 1 || B % n_groups) return MOPA_ERR_ARG;
+                                 int32_t n_groups, int32_t bn_c0, float* V, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_in < C || !stats || n_groups < 1 || B % n_groups || bn_c0 < 0 || bn_c0 >= C) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   k_wino4_in<true><<<stream_grid((int64_t)B * th * tw * C, 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, B, H, W, C, th, tw, V, stats,
-                                                                                              B / n_groups);
+                                                                                              B / n_groups, bn_c0);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -775,7 +791,7 @@ MOPA_API int mopa_wino4_gemm_output(const float* V, const float* Ut, const float
 //              channels] (over V, behind a barrier), stored as whole 256-byte pixel rows (dwordx4, optional accumulate).  The lines
 //              of the NEXT step's patch are touched in front of it (into L2).
 // BN: the input is a BatchNorm's input and relu(x * scale + shift) is convolved (LazyImg, as k_wino4_in<true>).
-template <bool BN>
+template <bool BN, bool VOUT>   // (VOUT a template parameter: its few registers cost the others five spills at the 256-register limit)
 __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__ in, int ld_in, const float* __restrict__ Uf,
                                                      const float* __restrict__ bias, float* __restrict__ out, int ld_out, int B, int H,
                                                      int W, int th, int tw, int Cin, int Cout, int accumulate,
@@ -834,9 +850,15 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
     if (!(PF_)) {                                                                                             \
       rmask = rm_; cmask = cm_;                                                                               \
       if (BN) {                                                                                               \
-        const float* __restrict__ sg_ = stats + (int64_t)(tb_ / imgs_per_group) * 4 * Cin + ch0_;            \
-        sc = *reinterpret_cast<const f32x2w*>(sg_);                                                           \
-        sh = *reinterpret_cast<const f32x2w*>(sg_ + Cin);                                                     \
+        /* imgs_per_group = images per BatchNorm group | bn_c0 << 16 (one kernel argument more costs this kernel its register budget); */ \
+        /* channels below bn_c0 pass through (see mopa_wino4_input_bn) */                                     \
+        const int bc0_ = imgs_per_group >> 16;                                                                \
+        sc = (f32x2w){1.f, 1.f}; sh = zero2;                                                                  \
+        if (ch0_ >= bc0_) {                                                                                   \
+          const float* __restrict__ sg_ = stats + (int64_t)(tb_ / (imgs_per_group & 0xffff)) * 4 * (Cin - bc0_) + ch0_ - bc0_; \
+          sc = *reinterpret_cast<const f32x2w*>(sg_);                                                         \
+          sh = *reinterpret_cast<const f32x2w*>(sg_ + Cin - bc0_);                                            \
+        }                                                                                                     \
       }                                                                                                       \
     }                                                                                                         \
     _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_)                                                          \
@@ -894,24 +916,20 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)
       const f32x2w d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
-      d[0][c] = 4.f * d0 - 5.f * d2 + d4;
-      d[1][c] = -4.f * (d1 + d2) + d3 + d4;
-      d[2][c] = 4.f * (d1 - d2) - d3 + d4;
-      d[3][c] = -2.f * d1 - d2 + 2.f * d3 + d4;
-      d[4][c] = 2.f * d1 - d2 - 2.f * d3 + d4;
-      d[5][c] = 4.f * d1 - 5.f * d3 + d5;
+      w4_bt6(d0, d1, d2, d3, d4, d5, d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
     }
     {
       f32x2w* __restrict__ lw = reinterpret_cast<f32x2w*>(w4c_lds) + (((wv >> 1) * 36) * 64 + tx_ + 16 * qq_) * 2 + hh_;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {   // (.) B
-        const f32x2w d0 = d[a][0], d1 = d[a][1], d2 = d[a][2], d3 = d[a][3], d4 = d[a][4], d5 = d[a][5];
-        lw[(a * 6 + 0) * 128] = 4.f * d0 - 5.f * d2 + d4;
-        lw[(a * 6 + 1) * 128] = -4.f * (d1 + d2) + d3 + d4;
-        lw[(a * 6 + 2) * 128] = 4.f * (d1 - d2) - d3 + d4;
-        lw[(a * 6 + 3) * 128] = -2.f * d1 - d2 + 2.f * d3 + d4;
-        lw[(a * 6 + 4) * 128] = 2.f * d1 - d2 - 2.f * d3 + d4;
-        lw[(a * 6 + 5) * 128] = 4.f * d1 - 5.f * d3 + d5;
+        f32x2w v0, v1, v2, v3, v4, v5;
+        w4_bt6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5], v0, v1, v2, v3, v4, v5);
+        lw[(a * 6 + 0) * 128] = v0;
+        lw[(a * 6 + 1) * 128] = v1;
+        lw[(a * 6 + 2) * 128] = v2;
+        lw[(a * 6 + 3) * 128] = v3;
+        lw[(a * 6 + 4) * 128] = v4;
+        lw[(a * 6 + 5) * 128] = v5;
       }
     }
     W4C_LOADB(bA, 0, 0);
@@ -921,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
     W4C_T(2)
     __syncthreads();   // V is complete
     W4C_T(3)
-    if (Vout && n0 == 0) {
+    if (VOUT && n0 == 0) {
       // training forward: V[36][T][Cin] goes to HBM as a by-product (the weight gradient multiplies it again) -- written once, not read
       // by this layer.  A point is 16 tiles x 32 channels = two 1-KiB wave stores of whole 128-byte (tile, channel block) rows.
       const int c8 = lane & 7, vt = lane >> 3;   // float4 c8 of the step's 32 channels = chunk c8 / 4, quad c8 % 4
@@ -1031,22 +1049,21 @@ MOPA_API int mopa_wino4_weight_f(const float* weight, int32_t O, int32_t I, int3
 // mopa_wino4_gemm_output without V.  Uf: mopa_wino4_weight_f.  Cin % 64 == 0, Cout % 64 == 0; `in` / `out` 16-byte aligned, ld_in % 4 ==
 // ld_out % 4 == 0.
 // stats != null: `in` is a BatchNorm's input, stats = [n_groups][4][Cin] (mopa_bn_act_fwd_groups with y == null), the B images are
-// n_groups equal consecutive groups and relu(batchnorm(in)) is what is convolved (as mopa_wino4_input_bn).
+// n_groups equal consecutive groups and relu(batchnorm(in)) is what is convolved (as mopa_wino4_input_bn, bn_c0 likewise).
 // V != null: the transformed input [36][T][Cin] (what mopa_wino4_input would write: the same bits) is stored as a by-product -- the
 // forward pass of a training step keeps it for mopa_wino4_bwd_weight.
 MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, const float* bias, float* out, int32_t ld_out, int32_t B,
                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, const float* stats, int32_t n_groups,
-                             float* V, void* stream) {
+                             int32_t bn_c0, float* V, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || ld_in < Cin || (ld_in & 3) || ld_out < Cout ||
       (ld_out & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)V & 15))
     return MOPA_ERR_ARG;
-  if (stats && (n_groups < 1 || B % n_groups)) return MOPA_ERR_ARG;
+  if (stats && (n_groups < 1 || B % n_groups || B / n_groups > 0xffff || bn_c0 < 0 || bn_c0 >= Cin || (bn_c0 & 1))) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   const int64_t T = (int64_t)B * th * tw;
   const int64_t nitems = cdiv64(T, 16) * (Cout / 64);
   if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
   const size_t ldsb = (size_t)2 * 36 * 64 * 16;   // 72 KB: two workgroups per CU
-  static bool attr[2] = {false, false};
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -1054,18 +1071,27 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOPA_ERR_LAUNCH;
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int v = stats ? 1 : 0;
-  const void* kern = stats ? reinterpret_cast<const void*>(k_wino4_conv<true>) : reinterpret_cast<const void*>(k_wino4_conv<false>);
+  const int v = (stats ? 1 : 0) | (V ? 2 : 0);
+  typedef void (*kern_t)(const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, int,
+                         int, float*
+#ifdef W4C_PROFILE
+                         , long long*
+#endif
+                         );
+  static const kern_t kerns[4] = {k_wino4_conv<false, false>, k_wino4_conv<true, false>, k_wino4_conv<false, true>, k_wino4_conv<true, true>};
+  static bool attr[4] = {false, false, false, false};
   if (!attr[v]) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return MOPA_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+      return MOPA_ERR_LAUNCH;
     attr[v] = true;
   }
   const unsigned nblk = (unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu);   // persistent: two workgroups per CU
+  const int ipg = stats ? (B / n_groups) | (bn_c0 << 16) : 1;
 #ifdef W4C_PROFILE
   static long long* prof = nullptr;
   if (!prof) hipMallocManaged(&prof, 128);
-  k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                             nullptr, 1, (int)nitems, V, prof);
+  kerns[v]<<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
+                                                  (int)nitems, V, prof);
   hipStreamSynchronize((hipStream_t)stream);
   {
     const double n_ = (double)nitems / nblk * (Cin / 32);
@@ -1074,12 +1100,8 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
            prof[0] / n_, prof[1] / n_, prof[2] / n_, prof[3] / n_, prof[4] / n_, prof[5] / n_, prof[6] / n_, n_);
   }
 #else
-  if (stats)
-    k_wino4_conv<true><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                              stats, B / n_groups, (int)nitems, V);
-  else
-    k_wino4_conv<false><<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate,
-                                                               nullptr, 1, (int)nitems, V);
+  kerns[v]<<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
+                                                  (int)nitems, V);
 #endif
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

@@ -46,9 +46,11 @@ class LazyImg(Img):
 
     __slots__ = ("bn",)
 
-    def __init__(self, x: Img, stats, G):
+    def __init__(self, x: Img, stats, G, c0=0):
+        """c0 > 0: only channels [c0, C) of x are the BatchNorm's input (stats: (G, 4, C - c0)); the channels below are a tensor that
+        is non-negative already (the skip half of a decoder join buffer) and pass through."""
         super().__init__(x.t, x.B, x.H, x.W, x.col, x.C)
-        self.bn = (stats, G)
+        self.bn = (stats, G, c0)
 
 
 def new_img(B, H, W, C, dev, ld=None, zero=False):
@@ -271,7 +273,7 @@ def wino_eligible(cin, cout, k, s, p, B, H, W):
 def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate=False, F=2, bn_in=None, role="fwd", want_v=True):
     """out = conv3x3(x) (+ bias) through the input transform -> (F+2)^2 batched GEMMs -> the output transform.
     U: wino_weight_cached(w, dgrad, F, transposed=(F == 4 and wino4_fused(cin, cout, B, H, W))).
-    bn_in = (stats, G) (F = 4 only): x is a BatchNorm's input and relu(batchnorm(x)) is what gets convolved (LazyImg)."""
+    bn_in = (stats, G, c0) (F = 4 only): x is a BatchNorm's input and relu(batchnorm(x)) is what gets convolved (LazyImg)."""
     dev = U.device
     th, tw = (H + F - 1) // F, (W + F - 1) // F
     T, NP = B * th * tw, (F + 2) ** 2
@@ -282,13 +284,13 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
         V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev) if want_v else None   # (a by-product, for the weight gradient)
         call("mopa_wino4_conv", x_p, ld_in, ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
              int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1,
-             ptr(V) if V is not None else None, stream())
+             bn_in[2] if bn_in is not None else 0, ptr(V) if V is not None else None, stream())
         return V
     V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
     if bn_in is not None:
         if F != 4:
             raise RuntimeError("wino_conv: a deferred BatchNorm needs the F(4x4) input transform")
-        call("mopa_wino4_input_bn", x_p, ld_in, B, H, W, cin, ptr(bn_in[0]), bn_in[1], ptr(V), stream())
+        call("mopa_wino4_input_bn", x_p, ld_in, B, H, W, cin, ptr(bn_in[0]), bn_in[1], bn_in[2], ptr(V), stream())
     else:
         call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     if F == 4 and wino4_fused(cin, cout, B, H, W):
@@ -323,7 +325,7 @@ def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
     if V is None:
         V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev)
         if hasattr(x, "bn"):   # a deferred BatchNorm (LazyImg): applied on the way in, as the forward pass did
-            call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, cin, ptr(x.bn[0]), x.bn[1], ptr(V), stream())
+            call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, cin, ptr(x.bn[0]), x.bn[1], x.bn[2], ptr(V), stream())
         else:
             call(f"mopa_wino{sfx}_input", x.p, x.ld, B, H, W, cin, ptr(V), stream())
     call(f"mopa_wino{sfx}_dout", dout.p, dout.ld, B, H, W, cout, ptr(dM), stream())
@@ -536,6 +538,7 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
 GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the BatchNorm groups of one pass in one set of launches
 # A/B switch: bn1 of a ResNet block is applied inside conv2's input transform instead of being written out (LazyImg)
 DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
+DEFER_UP_BN = os.environ.get("MOPA_DEFER_UP_BN", "1") != "0"   # ... and the decoder's up-convolution BatchNorms inside the join's consumer
 # A/B switch: the stem BatchNorm's backward apply inside the stem's weight gradient (mopa_stem_bwd_weight_bn: dx is never written)
 STEM_BN_FUSED_BWD = os.environ.get("MOPA_STEM_BN_FUSED_BWD", "1") != "0"
 
@@ -647,9 +650,9 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
         tape.append(("conv", name, op, x, out, V))
         return out
 
-    def convT(name, x):
+    def convT(name, x, out=None):
         op = ConvTOp(P[name + ".weight"], P[name + ".bias"])
-        out = new_img(x.B, 2 * x.H, 2 * x.W, op.O, dev)
+        out = out if out is not None else new_img(x.B, 2 * x.H, 2 * x.W, op.O, dev)
         op.forward(x, out)
         tape.append(("convT", name, op, x, out))
         return out
@@ -708,16 +711,28 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
     # ---- decoder (:165-182): ConvT+BN+ReLU into the right half of the join buffer, conv3x3 on [skip | up]
     for stage, lvl in (("5", 3), ("4", 2), ("3", 1), ("2", 0)):
         tname = f"{pre}dec_t_conv_stage{stage}."
-        up_raw = convT(tname + "0", x)
         cj = J[lvl].shape[1] // 2
-        bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
-        joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
-        tape.append(("join", lvl, cj))
+        cname = pre + "dec_conv_stage1" if lvl == 0 else f"{pre}dec_conv_stage{int(stage) - 1}.0"
+        # The up-convolution's BatchNorm + ReLU on the way INTO the decoder convolution (DEFER_BN): the transposed convolution writes
+        # its raw output into the right half of the join buffer, the BatchNorm computes statistics only, and the convolution's F(4x4)
+        # input transform normalises channels [cj, 2 cj) while it reads the buffer (the skip half is non-negative already: it passes
+        # through relu(1 x + 0) unchanged) -- no apply pass over the up-sampled tensor (598 MB read + written at 16 x 304 x 480).
+        lazy_up = (DEFER_BN and DEFER_UP_BN and not (training and syncbn.active())
+                   and ConvOp(P[cname + ".weight"], None, 3, 1, 1).takes_lazy(x.B, 2 * x.H, 2 * x.W, training))
+        if lazy_up:
+            right = Img(J[lvl], x.B, 2 * x.H, 2 * x.W, cj, cj)
+            up_raw = convT(tname + "0", x, out=right)
+            ylazy = bn(tname + "1", up_raw, defer=True)
+            joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), ylazy.bn[0], G, c0=cj)
+        else:
+            up_raw = convT(tname + "0", x)
+            bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
+            joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
+        tape.append(("join", lvl, cj, lazy_up))
         if lvl == 0:
             x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
         else:
-            cname = f"{pre}dec_conv_stage{int(stage) - 1}."
-            x = bn(cname + "1", conv(cname + "0", joined, 3, 1, 1, bias=True))
+            x = bn(cname[:-1] + "1", conv(cname, joined, 3, 1, 1, bias=True))
     if nbt:
         torch._foreach_add_(nbt, G)
     return x, tape, J   # x: (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
@@ -803,13 +818,14 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
             op.backward(x, dout, dx, dw, db, acc_params=pacc, wgrad_side=True)
         elif kind == "join":
-            _, lvl, cj = rec
-            full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj))
+            _, lvl, cj, lazy_up = rec
+            lz = (1,) if lazy_up else ()   # (the join was consumed as a LazyImg: see key())
+            full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj) + lz)
             dJ[lvl] = full
             if DEBUG is not None:
                 DEBUG[f"dJ{lvl}"] = full.t.clone()
             gmap[(J[lvl].data_ptr(), 0, cj)] = Img(full.t, full.B, full.H, full.W, 0, cj)
-            gmap[(J[lvl].data_ptr(), cj, cj)] = Img(full.t, full.B, full.H, full.W, cj, cj)
+            gmap[(J[lvl].data_ptr(), cj, cj) + lz] = Img(full.t, full.B, full.H, full.W, cj, cj)
         elif kind == "dropout":
             _, site, x, y, p = rec
             dy = gmap.pop(key(y))

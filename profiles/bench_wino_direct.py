@@ -40,7 +40,8 @@ for name, cin, cout, H, W in shapes:
         U = torch.empty(36, cout, cin, device="cuda") if lay == 1 else torch.empty(36, cin, cout, device="cuda")
         call(("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f")[lay], ptr(w), cout, cin, 0, ptr(U), stream())
         o = torch.zeros(B * H * W, cout, device="cuda")
-        res.append(timed(lambda: dense2d.wino_conv(ptr(x), cin, B, H, W, cin, cout, U, bias, ptr(o), cout, F=4)))
+        # want_v=False: the backward-data role (the default use of the one-kernel path) keeps no V
+        res.append(timed(lambda: dense2d.wino_conv(ptr(x), cin, B, H, W, cin, cout, U, bias, ptr(o), cout, F=4, want_v=not direct)))
         outs.append(o)
     err = float((outs[0] - outs[1]).abs().max()) / float(outs[0].abs().max())
     T = B * ((H + 3) // 4) * ((W + 3) // 4)

@@ -804,7 +804,7 @@ def test_input_transform_with_batchnorm_applied_on_the_way_in(G, B, C, H, W):
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
     Va, Vb = torch.empty(36 * T * C, device="cuda"), torch.full((36 * T * C,), 7.0, device="cuda")
     call("mopa_wino4_input", y.p, y.ld, B, H, W, C, ptr(Va), stream())
-    call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, C, ptr(sb), G, ptr(Vb), stream())
+    call("mopa_wino4_input_bn", x.p, x.ld, B, H, W, C, ptr(sb), G, 0, ptr(Vb), stream())
     assert torch.equal(Va, Vb)
     assert float((y.t < 0).sum()) == 0 and float((y.t == 0).float().mean()) > 0.1   # (the ReLU did cut something)
 
@@ -891,7 +891,7 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
         call("mopa_wino4_weight_f" if direct else "mopa_wino4_weight_t", ptr(w), O, I, int(dgrad), ptr(U), stream())
         out = prev.clone() if acc else torch.full((B * H * W, cout), float("nan"), device="cuda")
         V = dense2d.wino_conv(xin.p, xin.ld, B, H, W, cin, cout, U, None if acc else bias, ptr(out), cout, accumulate=acc, F=4,
-                              bn_in=(stats, G) if G else None, want_v=not acc)
+                              bn_in=(stats, G, 0) if G else None, want_v=not acc)
         if direct and not acc:   # the by-product: the bits mopa_wino4_input writes for the tensor the convolution sees
             Vr = torch.empty_like(V)
             xs = x.reshape(B * H * W, cin).contiguous()
@@ -981,3 +981,38 @@ def test_stem_batchnorm_backward_inside_the_stem_weight_gradient(groups, trainin
         err = float((ga[n] - gb[n]).abs().max()) / scale
         assert err <= 1e-6, (n, err)
     assert float(gb["net_2d.conv1.weight"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("G,one_kernel", [(1, False), (2, False), (2, True)])
+def test_join_buffer_with_the_up_convolution_batchnorm_applied_on_the_way_in(G, one_kernel, monkeypatch):
+    """bn_c0: a decoder join buffer [skip (already relu(batchnorm(.)): non-negative, with exact zeros) | raw up-convolution]; the
+    BatchNorm of the second half is statistics only and the consumer normalises channels [c0, C) while it reads -- mopa_wino4_input_bn
+    and, in one kernel with the convolution, mopa_wino4_conv -- against the buffer whose second half was written out by the apply pass:
+    V identical bits; the convolution's output identical to the same kernel on the materialised buffer."""
+    from mopa_amd import dense2d
+    from mopa_amd._lib import call, ptr, stream
+    from mopa_amd.dense2d import Img, bn_fwd_groups
+    rng = np.random.Generator(np.random.PCG64(77 + G))
+    B, H, W, cj = 2 * G, 14, 19, 64
+    raw = torch.from_numpy(rng.standard_normal((B * H * W, 2 * cj)).astype(np.float32)).cuda()
+    raw[:, :cj] = torch.relu(raw[:, :cj])                     # the skip half
+    mat = raw.clone()
+    P = {"bn.weight": torch.linspace(0.5, 1.5, cj).cuda(), "bn.bias": torch.linspace(-1, 1, cj).cuda(),
+         "bn.running_mean": torch.zeros(cj, device="cuda"), "bn.running_var": torch.ones(cj, device="cuda")}
+    stats = torch.empty(G, 4, cj, device="cuda")
+    bn_fwd_groups(Img(raw, B, H, W, cj, cj), Img(mat, B, H, W, cj, cj), P, "bn", 1, None, True, stats, G)   # mat = [skip | applied]
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    if not one_kernel:
+        Va, Vb = torch.empty(36 * T * 2 * cj, device="cuda"), torch.empty(36 * T * 2 * cj, device="cuda")
+        call("mopa_wino4_input", ptr(mat), 2 * cj, B, H, W, 2 * cj, ptr(Va), stream())
+        call("mopa_wino4_input_bn", ptr(raw), 2 * cj, B, H, W, 2 * cj, ptr(stats), G, cj, ptr(Vb), stream())
+        assert torch.equal(Va, Vb)
+        return
+    w = torch.from_numpy((rng.standard_normal((64, 2 * cj, 3, 3)) * 0.05).astype(np.float32)).cuda()
+    U = torch.empty(36, 2 * cj, 64, device="cuda")
+    call("mopa_wino4_weight_f", ptr(w), 64, 2 * cj, 0, ptr(U), stream())
+    oa, ob = torch.empty(B * H * W, 64, device="cuda"), torch.empty(B * H * W, 64, device="cuda")
+    Va, Vb = torch.empty(36 * T * 2 * cj, device="cuda"), torch.empty(36 * T * 2 * cj, device="cuda")
+    call("mopa_wino4_conv", ptr(mat), 2 * cj, ptr(U), None, ptr(oa), 64, B, H, W, 2 * cj, 64, 0, None, 1, 0, ptr(Va), stream())
+    call("mopa_wino4_conv", ptr(raw), 2 * cj, ptr(U), None, ptr(ob), 64, B, H, W, 2 * cj, 64, 0, ptr(stats), G, cj, ptr(Vb), stream())
+    assert torch.equal(oa, ob) and torch.equal(Va, Vb)
