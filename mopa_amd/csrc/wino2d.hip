@@ -1001,25 +1001,31 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
 #pragma unroll
       for (int p = 0; p < 36; ++p) acc[p] = zero4;
       const float bvv = bias ? bias[n0 + (wv << 4) + t] : 0.f;
-      float* __restrict__ ot = w4c_lds + (wv << 4) + t;   // [tile 16][pixel 16][channel 64]
+      // [tile 16][pixel 16][channel 64] with 4 floats between tiles (the four lane groups q write tiles 4 apart: 2-way instead of 4-way
+      // bank conflicts)
+      float* __restrict__ ot = w4c_lds + (wv << 4) + t;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ot[((4 * q + i) * 16 + e) * 64] = o[i][e] + bvv;
+        for (int e = 0; e < 16; ++e) ot[(4 * q + i) * 1028 + e * 64] = o[i][e] + bvv;
       __syncthreads();
-      // whole pixel rows: thread = (pixel wv * 4 + q of the tile, channel quad t); one tile per iteration (uniform coordinates)
+      // whole pixel rows: thread = (pixel wv * 4 + q of the tile, channel quad t); one tile per iteration, its coordinates are uniform and
+      // stepped, not divided
+      {
+        int otile = tg << 4;
+        int ob = otile / tt, ort = otile - ob * tt;
+        int oty = ort / tw, otx = ort - oty * tw;
+        const f32x4w* __restrict__ sp = reinterpret_cast<const f32x4w*>(w4c_lds + (wv * 4 + q) * 64 + 4 * t);
 #pragma unroll 4
-      for (int k = 0; k < 16; ++k) {
-        const int otile = (tg << 4) + k;
-        if (otile >= T) break;
-        const int b = otile / tt, rt = otile - b * tt;
-        const int ty = rt / tw, tx = rt - ty * tw;
-        const int y = 4 * ty + wv, x = 4 * tx + q;
-        if (y < H && x < W) {
-          f32x4w v = *reinterpret_cast<const f32x4w*>(w4c_lds + ((k * 16 + wv * 4 + q) * 64 + 4 * t));
-          f32x4w* gp = reinterpret_cast<f32x4w*>(out + ((int64_t)(b * H + y) * W + x) * ld_out + n0 + 4 * t);
-          if (accumulate) v += *gp;
-          *gp = v;
+        for (int k = 0; k < 16 && otile < T; ++k, ++otile) {
+          const int y = 4 * oty + wv, x = 4 * otx + q;
+          if (y < H && x < W) {
+            f32x4w v = sp[k * 257];   // (1028 floats per tile)
+            f32x4w* gp = reinterpret_cast<f32x4w*>(out + ((int64_t)(ob * H + y) * W + x) * ld_out + n0 + 4 * t);
+            if (accumulate) v += *gp;
+            *gp = v;
+          }
+          if (++otx == tw) { otx = 0; if (++oty == th) { oty = 0; ++ob; } }
         }
       }
       __syncthreads();   // the tile has been read: the next step may write V over it
