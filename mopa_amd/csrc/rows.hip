@@ -805,6 +805,7 @@ __global__ __launch_bounds__(256) void k_output_heads_bwd_rows(const float* __re
 // channel quad); block partials [nblk][NC][M+1] then an ordered reduction (deterministic).
 #define HEAD_PTS_PER_BLOCK 1024
 #define HEAD_MAXNC 32
+template <int NCM>   // NCM: compile-time bound of the class count (8 or NCM): the accumulators are NCM x 4 registers
 __global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restrict__ dl, const float* __restrict__ feats, int N,
                                                              int M, int NC, float* __restrict__ partial) {
   extern __shared__ float red[];  // [PL][NC][M+1]
@@ -814,15 +815,37 @@ __global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restr
   const int PL = 256 / MQP;
   const int cq = threadIdx.x % MQP, pl = cq < MQ ? threadIdx.x / MQP : PL;
   const int p0 = blockIdx.x * HEAD_PTS_PER_BLOCK, p1 = min(N, p0 + HEAD_PTS_PER_BLOCK);
-  float acc[HEAD_MAXNC][4];
-  float accb[HEAD_MAXNC];
+  float acc[NCM][4];
+  float accb[NCM];
 #pragma unroll
-  for (int k = 0; k < HEAD_MAXNC; ++k) { acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f; accb[k] = 0.f; }
-  if (pl < PL)
-    for (int p = p0 + pl; p < p1; p += PL) {
+  for (int k = 0; k < NCM; ++k) { acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f; accb[k] = 0.f; }
+  if (pl < PL) {
+    // four points in flight per thread (their loads are independent; the sums keep the order p, p + PL, ...): one point per trip was a
+    // chain of 64 dependent load latencies per thread, 260 us per call on 558,080 points
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+      float4 v[4];
+      float g[4][NCM];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(feats + (int64_t)(p + u * PL) * M + cq * 4);
+#pragma unroll
+        for (int k = 0; k < NCM; ++k) g[u][k] = k < NC ? dl[(int64_t)(p + u * PL) * NC + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NCM; ++k)
+          if (k < NC) {
+            acc[k][0] = fmaf(g[u][k], v[u].x, acc[k][0]); acc[k][1] = fmaf(g[u][k], v[u].y, acc[k][1]);
+            acc[k][2] = fmaf(g[u][k], v[u].z, acc[k][2]); acc[k][3] = fmaf(g[u][k], v[u].w, acc[k][3]);
+            if (cq == 0) accb[k] += g[u][k];
+          }
+    }
+    for (; p < p1; p += PL) {
       const float4 v = *reinterpret_cast<const float4*>(feats + (int64_t)p * M + cq * 4);
 #pragma unroll
-      for (int k = 0; k < HEAD_MAXNC; ++k)
+      for (int k = 0; k < NCM; ++k)
         if (k < NC) {
           const float g = dl[(int64_t)p * NC + k];
           acc[k][0] = fmaf(g, v.x, acc[k][0]); acc[k][1] = fmaf(g, v.y, acc[k][1]);
@@ -830,10 +853,11 @@ __global__ __launch_bounds__(256) void k_head_wgrad_partial(const float* __restr
           if (cq == 0) accb[k] += g;
         }
     }
+  }
   const int stride = NC * (M + 1);
   if (pl < PL) {
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXNC; ++k)
+    for (int k = 0; k < NCM; ++k)
       if (k < NC) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[pl * stride + k * (M + 1) + cq * 4 + j] = acc[k][j];
@@ -888,11 +912,13 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
   const size_t hsh = (size_t)(256 / mqp) * num_classes * (M + 1) * sizeof(float);
   if (hsh > 64 * 1024) return MOPA_ERR_ARG;
   if (dl1 && dw1) {
-    k_head_wgrad_partial<<<nblk, 256, hsh, st>>>(dl1, feats, n_points, M, num_classes, partial);
+    if (num_classes <= 8) k_head_wgrad_partial<8><<<nblk, 256, hsh, st>>>(dl1, feats, n_points, M, num_classes, partial);
+    else k_head_wgrad_partial<HEAD_MAXNC><<<nblk, 256, hsh, st>>>(dl1, feats, n_points, M, num_classes, partial);
     k_head_wgrad_reduce<<<16, 256, 0, st>>>(partial, nblk, M, num_classes, dw1, db1, accumulate);
   }
   if (dl2 && dw2) {
-    k_head_wgrad_partial<<<nblk, 256, hsh, st>>>(dl2, feats, n_points, M, num_classes, partial);
+    if (num_classes <= 8) k_head_wgrad_partial<8><<<nblk, 256, hsh, st>>>(dl2, feats, n_points, M, num_classes, partial);
+    else k_head_wgrad_partial<HEAD_MAXNC><<<nblk, 256, hsh, st>>>(dl2, feats, n_points, M, num_classes, partial);
     k_head_wgrad_reduce<<<16, 256, 0, st>>>(partial, nblk, M, num_classes, dw2, db2, accumulate);
   }
   MOPA_CHECK_LAUNCH();
