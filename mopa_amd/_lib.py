@@ -118,6 +118,7 @@ SIGNATURES = {
     "mopa_img_to_nhwc4": ("i", "piiiiipp"),
     "mopa_stem_dgrad_image": ("i", "piiiiiippp"),
     "mopa_maxpool3x3s2_fwd": ("i", "piiiiipipp"),
+    "mopa_maxpool3x3s2_fwd_bn": ("i", "piiiiipipipp"),
     "mopa_maxpool3x3s2_bwd": ("i", "pipiiiipiip"),
     "mopa_dropout_rows": ("i", "pipiliflp"),
     "mopa_dropout_rows_dseed": ("i", "pipilifpip"),

@@ -10,8 +10,12 @@
 // ------------------------------------------------------------------------------------------ maxpool 3x3 s2 p1
 // y[b][oy][ox][c] = max over the 3x3 window (first maximum in (ky,kx) scan order wins, like torch); idx stores the
 // winning tap 0..8 (uint8) for the backward.  x may be a channel slice (ldx) of a wider buffer.
+// BN: x is a BatchNorm's input and the pooled tensor is relu(x * scale + shift) (stats[G][4][C] of mopa_bn_act_fwd_groups with y ==
+// null; the expression of k_bn_relu_apply, so values and winners are those of pooling the materialised tensor).
+template <bool BN>
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int ldx, int B, int H, int W, int C,
-                                                      float* __restrict__ y, int ldy, unsigned char* __restrict__ idx) {
+                                                      float* __restrict__ y, int ldy, unsigned char* __restrict__ idx,
+                                                      const float* __restrict__ stats, int imgs_per_group) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2, CQ = C >> 2;
   const int64_t total = (int64_t)B * OH * OW * CQ;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -21,6 +25,12 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
     const int oy = (int)(r % OH), b = (int)(r / OH);
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0, 0, 0, 0};
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BN) {
+      const float* __restrict__ sg = stats + (int64_t)(b / imgs_per_group) * 4 * C + cq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sc[j] = sg[j]; sh[j] = sg[C + j]; }
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -28,7 +38,14 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
         const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
         const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * H + iy) * W + ix) * ldx + cq * 4);
-        const float vs[4] = {v.x, v.y, v.z, v.w};
+        float vs[4] = {v.x, v.y, v.z, v.w};
+        if (BN) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float o = fmaf(vs[j], sc[j], sh[j]);
+            vs[j] = o > 0.f ? o : o * 0.f;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (vs[j] > best[j] || vs[j] != vs[j]) { best[j] = vs[j]; bi[j] = ky * 3 + kx; }
@@ -95,7 +112,19 @@ MOPA_API int mopa_maxpool3x3s2_fwd(const float* x, int32_t ldx, int32_t B, int32
                                    int32_t ldy, uint8_t* argmax, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ldx < C || ldy < C || ((ldx | ldy) & 3)) return MOPA_ERR_ARG;
   const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 2);
-  k_maxpool_fwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, ldx, B, H, W, C, y, ldy, argmax);
+  k_maxpool_fwd<false><<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, ldx, B, H, W, C, y, ldy, argmax, nullptr, 1);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+// The same pooling of relu(batchnorm(x)) read from the BatchNorm's input x: stats = [n_groups][4][C] (scale, shift, ...) of
+// mopa_bn_act_fwd_groups with y == null, the B images are n_groups equal consecutive groups.  Values and argmax are those of
+// mopa_maxpool3x3s2_fwd on the applied tensor (the stem's BatchNorm never writes its output: dense2d, MOPA_DEFER_STEM_BN).
+MOPA_API int mopa_maxpool3x3s2_fwd_bn(const float* x, int32_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, const float* stats,
+                                      int32_t n_groups, float* y, int32_t ldy, uint8_t* argmax, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ldx < C || ldy < C || ((ldx | ldy) & 3) || !stats || n_groups < 1 || B % n_groups)
+    return MOPA_ERR_ARG;
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 2);
+  k_maxpool_fwd<true><<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, ldx, B, H, W, C, y, ldy, argmax, stats, B / n_groups);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

@@ -539,6 +539,7 @@ GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the B
 # A/B switch: bn1 of a ResNet block is applied inside conv2's input transform instead of being written out (LazyImg)
 DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
 DEFER_UP_BN = os.environ.get("MOPA_DEFER_UP_BN", "1") != "0"   # ... and the decoder's up-convolution BatchNorms inside the join's consumer
+DEFER_STEM_BN = os.environ.get("MOPA_DEFER_STEM_BN", "1") != "0"   # ... and the stem's inside its two readers (max-pool, full-resolution join)
 # A/B switch: the stem BatchNorm's backward apply inside the stem's weight gradient (mopa_stem_bwd_weight_bn: dx is never written)
 STEM_BN_FUSED_BWD = os.environ.get("MOPA_STEM_BN_FUSED_BWD", "1") != "0"
 
@@ -670,18 +671,28 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
     call("mopa_img_to_nhwc4", ptr(imgc), B, H, W, Hp, Wp, ptr(x4), stream())
     w1 = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
     call("mopa_conv2d_stem_relayout", ptr(P[pre + "conv1.weight"]), ptr(w1), 64, 0, 0, stream())
-    c1 = new_img(B, Hp, Wp, 64, dev)
-    stem_g = _geom(B=B, IH=Hp + 6, IW=Wp + 8, OHl=Hp, OWl=Wp, OHa=Hp, OWa=Wp, IDX=4, TH=7, TW=2, KWF=2, Cin=16,
-                   Cout=64, ld_in=4, ld_out=64)
-    igemm(ptr(x4), w1, None, c1.p, stem_g)
-    tape.append(("stem", x4, c1, stem_g))
     J = {}  # join buffers: [skip | upsampled]
     J[0] = torch.empty(B * Hp * Wp, 128, dtype=torch.float32, device=dev)
-    skip0 = bn(pre + "bn1", c1, out=Img(J[0], B, Hp, Wp, 0, 64))
+    # The stem's BatchNorm + ReLU has two readers, the max-pool and the full-resolution decoder convolution (through the join buffer).
+    # When that convolution normalises on the way in (see the decoder below) the stem convolution writes its RAW output into the left
+    # half of the join buffer, the BatchNorm computes statistics only and the max-pool applies them to its windows: no apply pass over
+    # the largest activation of the network (598 MB read + written at 16 x 304 x 480), no second copy of it.
+    lazy_stem = (DEFER_BN and DEFER_UP_BN and DEFER_STEM_BN and not (training and syncbn.active())
+                 and ConvOp(P[pre + "dec_conv_stage1.weight"], None, 3, 1, 1).takes_lazy(B, Hp, Wp, training))
+    c1 = Img(J[0], B, Hp, Wp, 0, 64) if lazy_stem else new_img(B, Hp, Wp, 64, dev)
+    stem_g = _geom(B=B, IH=Hp + 6, IW=Wp + 8, OHl=Hp, OWl=Wp, OHa=Hp, OWa=Wp, IDX=4, TH=7, TW=2, KWF=2, Cin=16,
+                   Cout=64, ld_in=4, ld_out=c1.ld)
+    igemm(ptr(x4), w1, None, c1.p, stem_g)
+    tape.append(("stem", x4, c1, stem_g))
     H2, W2 = Hp // 2, Wp // 2
     x = new_img(B, H2, W2, 64, dev)
     amax = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)
-    call("mopa_maxpool3x3s2_fwd", skip0.p, skip0.ld, B, Hp, Wp, 64, x.p, x.ld, ptr(amax), stream())
+    if lazy_stem:
+        skip0 = bn(pre + "bn1", c1, defer=True)
+        call("mopa_maxpool3x3s2_fwd_bn", c1.p, c1.ld, B, Hp, Wp, 64, ptr(skip0.bn[0]), G, x.p, x.ld, ptr(amax), stream())
+    else:
+        skip0 = bn(pre + "bn1", c1, out=Img(J[0], B, Hp, Wp, 0, 64))
+        call("mopa_maxpool3x3s2_fwd", skip0.p, skip0.ld, B, Hp, Wp, 64, x.p, x.ld, ptr(amax), stream())
     tape.append(("maxpool", skip0, x, amax))
     # ---- encoder stages
     for li, (lname, c, nblocks, stride) in enumerate(LAYERS):
@@ -723,12 +734,15 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
             right = Img(J[lvl], x.B, 2 * x.H, 2 * x.W, cj, cj)
             up_raw = convT(tname + "0", x, out=right)
             ylazy = bn(tname + "1", up_raw, defer=True)
-            joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), ylazy.bn[0], G, c0=cj)
+            if lvl == 0 and lazy_stem:   # both halves are raw: [stem conv | up-convolution], one statistics tensor over the 128 channels
+                joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), torch.cat([skip0.bn[0], ylazy.bn[0]], dim=2), G)
+            else:
+                joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), ylazy.bn[0], G, c0=cj)
         else:
             up_raw = convT(tname + "0", x)
             bn(tname + "1", up_raw, out=Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, cj, cj))
             joined = Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj)
-        tape.append(("join", lvl, cj, lazy_up))
+        tape.append(("join", lvl, cj, lazy_up, lvl == 0 and lazy_stem))
         if lvl == 0:
             x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
         else:
@@ -818,13 +832,13 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             (dw, db), pacc = sink.take(name + ".weight", name + ".bias")
             op.backward(x, dout, dx, dw, db, acc_params=pacc, wgrad_side=True)
         elif kind == "join":
-            _, lvl, cj, lazy_up = rec
+            _, lvl, cj, lazy_up, lazy_left = rec
             lz = (1,) if lazy_up else ()   # (the join was consumed as a LazyImg: see key())
             full = gmap.pop((J[lvl].data_ptr(), 0, 2 * cj) + lz)
             dJ[lvl] = full
             if DEBUG is not None:
                 DEBUG[f"dJ{lvl}"] = full.t.clone()
-            gmap[(J[lvl].data_ptr(), 0, cj)] = Img(full.t, full.B, full.H, full.W, 0, cj)
+            gmap[(J[lvl].data_ptr(), 0, cj) + ((1,) if lazy_left else ())] = Img(full.t, full.B, full.H, full.W, 0, cj)
             gmap[(J[lvl].data_ptr(), cj, cj) + lz] = Img(full.t, full.B, full.H, full.W, cj, cj)
         elif kind == "dropout":
             _, site, x, y, p = rec
@@ -854,6 +868,9 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
                     call("mopa_stem_bwd_weight_bn", ptr(x4), bdy.p, bdy.ld, bx.p, bx.ld, ptr(bstats), ptr(bcoef), G, int(training), ptr(dwl),
                          ctypes.addressof(g), 0, ptr(ws), ws.numel(), stream())
                 else:
+                    if g[24] != dout.ld:   # (forward wrote into a wider buffer; the gradient tensor has its own row stride)
+                        g = (ctypes.c_int32 * 25)(*g)
+                        g[24] = dout.ld
                     wgrad(ptr(x4), dout.p, ptr(dwl), g, dev)
                 call("mopa_conv2d_stem_relayout", ptr(dwl), ptr(dw), 64, 1, int(pacc), stream())
             if want_dimg:   # gradient w.r.t. the image itself (not asked for by MoPA's training)
