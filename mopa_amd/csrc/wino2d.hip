@@ -943,16 +943,16 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
       // training forward: V[36][T][Cin] goes to HBM as a by-product (the weight gradient multiplies it again) -- written once, not read
       // by this layer.  A point is 16 tiles x 32 channels = two 1-KiB wave stores of whole 128-byte (tile, channel block) rows.
       const int c8 = lane & 7, vt = lane >> 3;   // float4 c8 of the step's 32 channels = chunk c8 / 4, quad c8 % 4
-#pragma unroll 3
-      for (int k = 0; k < 9; ++k) {
-        const int p = wv + 4 * k;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const int tl = vt + 8 * hf;
-          const f32x4w v = lds[((c8 >> 2) * 36 + p) * 64 + tl + 16 * (c8 & 3)];
-          if ((tg << 4) + tl < T)
-            *reinterpret_cast<f32x4w*>(Vout + ((int64_t)p * T + (tg << 4) + tl) * Cin + (r << 5) + 4 * c8) = v;
-        }
+      // (running pointers, a rolled loop: this block must not cost the multiplication its registers)
+      const f32x4w* __restrict__ lp = lds + ((c8 >> 2) * 36 + wv) * 64 + vt + 16 * (c8 & 3);
+      float* __restrict__ vp = Vout + ((int64_t)wv * T + (tg << 4) + vt) * Cin + (r << 5) + 4 * c8;
+      const int64_t vstep = (int64_t)4 * T * Cin;
+      const bool ok0 = (tg << 4) + vt < T, ok1 = (tg << 4) + vt + 8 < T;
+#pragma unroll 1
+      for (int k = 0; k < 9; ++k, lp += 4 * 64, vp += vstep) {
+        const f32x4w v0 = lp[0], v1 = lp[8];
+        if (ok0) *reinterpret_cast<f32x4w*>(vp) = v0;
+        if (ok1) *reinterpret_cast<f32x4w*>(vp + 8 * Cin) = v1;
       }
     }
 #pragma unroll 1
