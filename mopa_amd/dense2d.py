@@ -860,7 +860,8 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
             dout = gmap.pop(key(c1))
             (dw,), pacc = sink.take(pre + "conv1.weight")
             lazy = dout if isinstance(dout, tuple) else None   # ("bn", dy, x, stats, coef): the BatchNorm above left its apply to us
-            with _on(wgrad_stream(dev), (lazy[1] if lazy else dout).t):
+            # (the weight-gradient stream reads dy and, fused, the small coef tensor: both are dropped here before the streams are joined)
+            with _on(wgrad_stream(dev), (lazy[1] if lazy else dout).t, *((lazy[4],) if lazy else ())):
                 dwl = torch.empty(7, 2, 16, 64, dtype=torch.float32, device=dev)
                 if lazy:
                     _, bdy, bx, bstats, bcoef = lazy
