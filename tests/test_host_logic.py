@@ -144,8 +144,26 @@ def test_conv_algorithm_choice(monkeypatch):
     assert dense2d.wino4_fused(128, 64, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 304, 480) and dense2d.wino4_fused(64, 128, B, 152, 240)
     assert dense2d.wino4_fused(64, 64, B, 152, 240) and not dense2d.wino4_fused(128, 64, B, 152, 240)   # one K chunk per point: one round suffices
     assert not dense2d.wino4_fused(64, 64, B, 76, 120) and not dense2d.wino4_fused(512, 512, B, 19, 30) and not dense2d.wino4_fused(48, 128, B, 304, 480)
+    # the one-kernel F(4x4) convolution (round 4): 64-aligned channels, Cin <= 128, >= 16,384 tiles; by default for backward-data
+    # and for a forward pass that keeps nothing, not for the forward pass of a training step (it wants V again)
+    monkeypatch.setattr(dense2d, "F4_ROLES", ("fwd", "dgrad", "wgrad"))
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT", True)
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT_ROLES", ("fwd_eval", "dgrad"))
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 16384)
+    d = dense2d.wino4_direct
+    assert d(64, 64, 16, 152, 240, "dgrad") and d(64, 128, 16, 304, 480, "dgrad") and d(128, 64, 16, 304, 480, "fwd_eval")
+    assert not d(128, 64, 16, 304, 480, "fwd") and not d(128, 128, 16, 76, 120, "dgrad") and not d(256, 256, 16, 152, 240, "dgrad")
+    assert not d(64, 64, 4, 152, 240, "dgrad")   # (9,120 tiles)
+    assert dense2d.wino4_layout(64, 64, 16, 152, 240, "dgrad") == 2 and dense2d.wino4_layout(64, 64, 16, 152, 240, "fwd") == 1
+    # a deferred BatchNorm needs an F(4x4) consumer (and, in training, its transform-domain weight gradient)
+    import torch
+    op = dense2d.ConvOp(torch.empty(64, 128, 3, 3), None, 3, 1, 1)
+    assert op.takes_lazy(16, 304, 480, True) and op.takes_lazy(2, 96, 128, False)
+    assert not dense2d.ConvOp(torch.empty(64, 48, 3, 3), None, 3, 1, 1).takes_lazy(16, 304, 480, True)      # ragged input channels
+    assert not dense2d.ConvOp(torch.empty(128, 64, 3, 3), None, 3, 2, 1).takes_lazy(16, 152, 240, True)     # strided
     monkeypatch.setattr(dense2d, "WINOGRAD", False)   # (MOPA_WINOGRAD=0 at import)
     assert t(256, 256, 3, 1, 1, B, 38, 60, "dgrad") == 0
+    assert not op.takes_lazy(16, 304, 480, True)
 
 
 def test_parameter_list_cache_follows_module_surgery():
