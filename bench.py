@@ -93,6 +93,24 @@ class ConvTimer:
                 timer.records.append((s, e, nbytes, 2 * R * x.C * out.C))
 
         sparse3d.spconv_launch = wrapped
+        inner_run = sparse3d.spconv_launch_run
+
+        def wrapped_run(runs, K, x, w, out, w_flip):   # the offset-major path of the same family (gather-GEMM + ordered reduce: csrc/sprun.hip)
+            if not timer.enabled:
+                return inner_run(runs, K, x, w, out, w_flip)
+            A_out = out.rows
+            R = timer.rules.get((K, A_out, x.rows))
+            if R is None:
+                R = max(A_out, x.rows) if K == 8 else int(runs[0][32:32 + K].sum().item())   # (the rulebook's header holds the rule counts)
+                timer.rules[(K, A_out, x.rows)] = R
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            inner_run(runs, K, x, w, out, w_flip)
+            e.record()
+            nbytes = R * x.C * 4 + A_out * out.C * 4 + R * 8 + K * x.C * out.C * 4   # the same algorithmic bytes: the slab is not work
+            timer.records.append((s, e, nbytes, 2 * R * x.C * out.C))
+
+        sparse3d.spconv_launch_run = wrapped_run
 
     def summary(self):
         if not self.records:
@@ -1001,7 +1019,7 @@ def main():
         sp = None
         if ks:
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk (sparse conv fwd + bwd-data)",
+                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk / k_spconv_run + k_run_reduce (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2),
                   # the family is not HBM-bound on every level: from level 3 down (128 -> 64 channels and wider, few rows) a launch's

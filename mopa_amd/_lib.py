@@ -47,6 +47,14 @@ SIGNATURES = {
     "mopa_spconv_pack_weights_batched": ("i", "pip"),
     "mopa_spconv_wgrad_workspace_bytes": ("z", "iiii"),
     "mopa_spconv_bwd_weight": ("i", "piipiipiipipzp"),
+    # ---- sparse conv, offset-major (sprun.hip)
+    "mopa_rulebook_runs_bytes": ("z", "ii"),
+    "mopa_rulebook_runs_build_batched": ("i", "pip"),
+    "mopa_spconv_run_pack_weight": ("i", "piiiipp"),
+    "mopa_spconv_run_wanted": ("i", "iiiii"),
+    "mopa_spconv_run_form": ("i", "ii"),
+    "mopa_spconv_run_workspace_bytes": ("z", "iii"),
+    "mopa_spconv_fwd_run": ("i", "piipiipiipiipzp"),
     # ---- native executor of the 3D layer program (scn_exec.hip)
     "mopa_scn_workspace_bytes": ("z", "pipii"),
     "mopa_scn_forward": ("i", "pippppppzp"),

@@ -19,6 +19,9 @@ SECTIONS = [
  *   mopa/models/scn_unet.py:27-28 (SubmanifoldConvolution K=27; scn.UNet Convolution / Deconvolution K=8)
  * forward / backward-data: mopa_spconv_fwd (backward-data = same call on the reversed table with transposed weights);
  * backward-weight: mopa_spconv_bwd_weight."""),
+    ("sprun.hip", """The same convolutions, offset-major: run-major rulebook (the rules of one filter offset are one contiguous run of slots),
+ * per-offset gather-GEMM with the weight slice resident in LDS, products into a partial slab, one ordered per-row sum -- for the
+ * launches the matrix pipe bounds (same reference call sites as spconv.hip; SURVEY A.8 "gather-GEMM-scatter")."""),
     ("scn_exec.hip", """Native executor of the 3D branch: the whole UNetSCN forward / backward (scn.Sequential of mopa/models/scn_unet.py:25-30
  * with scn.UNet unrolled + the linear heads of mopa/models/xmuda_arch.py:114-126) as ONE call each over host-side tables
  * (layer program, parameter pointers, rule tables, buffer addresses); table layouts: scn_exec.hip / mopa_amd/sparse3d.py."""),

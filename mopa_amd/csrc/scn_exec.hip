@@ -29,7 +29,9 @@ enum { C_SUBM = 0, C_DOWN = 1, C_UP = 2, C_NIN = 3 };
 //             then per level l at 8 + 8 l: rows A_l, nbr27, its grp_start, ch (rows A_{l+1}), its grp_start, up (rows A_l), its grp_start,
 //             split_l (0: one BatchNorm group; s: rows [0, s) and [s, A_l) are groups of scans whose BatchNorm statistics, running
 //             updates and gradients are computed separately, first group first -- mopa_amd/sparse3d.py::Geometry3D.split);
-//             behind the L + 1 level rows: a tail of 8 values, tail[l] = second split of level l (0: none) -- three groups
+//             behind the L + 1 level rows: a tail of 8 values, tail[l] = second split of level l (0: none) -- three groups;
+//             behind the tail: 3 values per level l (up to 8 levels), the run-major rulebooks (sprun.hip) of nbr27 / ch / up at that
+//             level, 0 = none built (the offset-major path then does not run on that table)
 enum { G_L = 0, G_NPTS, G_PROW, G_RSTART, G_RPTS, G_GO, G_GI, G_GOUT, G_LEVELS = 8, G_LW = 8 };
 enum { GL_A = 0, GL_NBR, GL_NBR_GS, GL_CH, GL_CH_GS, GL_UP, GL_UP_GS, GL_SPLIT };
 // bufs_host   int64 [nbufs][2]: base pointer, row stride (floats) of the activation (or gradient) buffers
@@ -84,24 +86,31 @@ static inline int n_bn_groups(const int64_t* geom) {
   return n;
 }
 
-struct Table { const int32_t* nbr; const int32_t* gs; int K; int rows_out; };
+struct Table { const int32_t* nbr; const int32_t* gs; int K; int rows_out; const int32_t* runs; int one; };
+static inline const int32_t* runs_of(const int64_t* geom, int l, int which) {   // which: 0 nbr27, 1 ch, 2 up
+  return (const int32_t*)geom[G_LEVELS + G_LW * ((int)geom[G_L] + 1) + 8 + 3 * l + which];
+}
 // the rule table a convolution of `ckind` between levels runs on (forward), or its reverse (backward-data)
 static inline Table table_of(const int64_t* geom, int ckind, int l, bool reversed) {
   const int64_t* g = geom + G_LEVELS + G_LW * l;
   Table t;
   const int A_l = (int)g[GL_A], A_c = (int)g[G_LW + GL_A];   // (A_c is only read for down / up, where level l + 1 exists)
-  if (ckind == C_SUBM) { t.nbr = (const int32_t*)g[GL_NBR]; t.gs = (const int32_t*)g[GL_NBR_GS]; t.K = 27; t.rows_out = A_l; }
+  t.runs = nullptr; t.one = 0;
+  if (ckind == C_SUBM) { t.nbr = (const int32_t*)g[GL_NBR]; t.gs = (const int32_t*)g[GL_NBR_GS]; t.K = 27; t.rows_out = A_l; t.runs = runs_of(geom, l, 0); }
   else if (ckind == C_NIN) { t.nbr = (const int32_t*)g[GL_NBR] + (int64_t)13 * A_l; t.gs = nullptr; t.K = 1; t.rows_out = A_l; }
-  else if ((ckind == C_DOWN) != reversed) { t.nbr = (const int32_t*)g[GL_CH]; t.gs = (const int32_t*)g[GL_CH_GS]; t.K = 8; t.rows_out = A_c; }
-  else { t.nbr = (const int32_t*)g[GL_UP]; t.gs = (const int32_t*)g[GL_UP_GS]; t.K = 8; t.rows_out = A_l; }
+  else if ((ckind == C_DOWN) != reversed) { t.nbr = (const int32_t*)g[GL_CH]; t.gs = (const int32_t*)g[GL_CH_GS]; t.K = 8; t.rows_out = A_c; t.runs = runs_of(geom, l, 1); }
+  else { t.nbr = (const int32_t*)g[GL_UP]; t.gs = (const int32_t*)g[GL_UP_GS]; t.K = 8; t.rows_out = A_l; t.runs = runs_of(geom, l, 2); t.one = 1; }   // every fine row has one parent
   return t;
 }
 
 // Which weight form the convolution kernel of (table, cin -> cout) wants: > 0 packed for column groups of that many 16-column
-// tiles, 0 = the plain [K][cin][cout] weight of the convolution to run.  Mirrors mopa_amd/sparse3d.py::spconv_fwd.
+// tiles, 0 = the plain [K][cin][cout] weight of the convolution to run, SCN_RUN_FORM + nt = the run layout of the offset-major
+// kernel (sprun.hip; nt = its column-group width).  Mirrors mopa_amd/sparse3d.py::spconv_fwd.
+#define SCN_RUN_FORM 100
 static inline int wanted_ntw(const Table& t, int cin, int cout, int ld_in) {
-  if (!t.gs) return 0;
   if ((int64_t)t.rows_out * 8 * ld_in * 4 >= (1ll << 32)) return 0;
+  if (t.runs && mopa_spconv_run_wanted(t.K, t.rows_out, cin, cout, t.one)) return SCN_RUN_FORM + mopa_spconv_run_form(cin, cout);
+  if (!t.gs) return 0;
   return mopa_spconv_grouped_wants_packed(t.K, t.rows_out, cin, cout);
 }
 
@@ -144,7 +153,8 @@ static int refresh_forms(const int32_t* prog, int n_ops, const int64_t* params, 
     if (!f[0]) return MOPA_ERR_ARG;
     int64_t* r = rows + n * 6;
     r[0] = params[op * 4]; r[1] = f[0]; r[2] = t.K; r[3] = cin_w; r[4] = cout_w;
-    r[5] = ntw > 0 ? ((pass == 1 ? 1 : 0) | (ntw << 8)) : 1;       // ntw 0 (backward-data only): plain per-offset transpose
+    if (ntw >= SCN_RUN_FORM) r[5] = (pass == 1 ? 1 : 0) | ((ntw - SCN_RUN_FORM) << 8) | 0x10000;   // the run layout
+    else r[5] = ntw > 0 ? ((pass == 1 ? 1 : 0) | (ntw << 8)) : 1;  // ntw 0 (backward-data only): plain per-offset transpose
     f[1] = ntw; f[2] = epoch;
     if (++n == 64) { const int rc = flush(); if (rc) return rc; }
   }
@@ -158,6 +168,8 @@ static int run_conv(const Table& t, const View& x, const float* wk, int ntw, con
   const int32_t* gi = (const int32_t*)geom[G_GI];
   const int32_t* gout = (const int32_t*)geom[G_GOUT];
   const int64_t tiles = cdiv64(t.rows_out, 64);
+  if (ntw >= SCN_RUN_FORM)
+    return mopa_spconv_fwd_run(t.runs, t.K, t.rows_out, x.p, x.ld, x.C, wk, out.C, w_flip, out.p, out.ld, t.one, ws, ws_bytes, st);
   if (ntw > 0)
     return mopa_spconv_fwd_grouped(t.gs, go, gi, gout, t.K, t.rows_out, x.p, x.ld, x.C, wk, out.C, w_flip | 2, out.p, out.ld, nullptr, 0, st);
   if (t.gs && tiles < (t.K == 27 ? 1500 : 200)) {
@@ -184,6 +196,9 @@ MOPA_API size_t mopa_scn_workspace_bytes(const int32_t* prog_host, int32_t n_ops
         const Table t = table_of(geom_host, o[OP_CKIND], l, rev);
         const int cout = rev ? o[OP_SC] : o[OP_DC];
         need = max_sz(need, mopa_spconv_grouped_workspace_bytes(t.K, t.rows_out, cout));
+        const int cin = rev ? o[OP_DC] : o[OP_SC];
+        if (t.runs && !t.one && mopa_spconv_run_wanted(t.K, t.rows_out, cin, cout, 0))
+          need = max_sz(need, mopa_spconv_run_workspace_bytes(t.K, t.rows_out, cout));
       }
       const Table t = table_of(geom_host, o[OP_CKIND], l, false);
       need = max_sz(need, mopa_spconv_wgrad_workspace_bytes(t.K, t.rows_out, o[OP_SC], o[OP_DC]));

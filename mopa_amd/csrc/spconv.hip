@@ -14,6 +14,7 @@
 // Data layout: features row-major [rows][ld] fp32 (ld >= C lets a layer read/write a channel slice of a wider
 // JoinTable buffer); weights [K][Cin][Cout] fp32.
 #include "common.h"
+#include "sprun_pack.h"
 #ifdef MOPA_EXP_RING   // round-4 experiment (profiles/experiments/spconv_ring.hip, build_ring.sh): not in the shipped library
 #include "spconv_ring.h"
 #endif
@@ -423,7 +424,8 @@ MOPA_API int mopa_spconv_pack_weight(const float* w, int32_t K, int32_t cin, int
 // 50 launches at the ~5 us floor each, on a host-paced step).  desc_host [n][6] int64: source, destination, K, cin, cout (of the
 // layer weight [K][cin][cout]), flags: bit 0 = the convolution to run is the per-offset transpose (backward-data), bits 8-15 =
 // ntw (column groups of ntw 16-column tiles, as mopa_spconv_pack_weight) or 0 = plain per-offset transpose
-// (mopa_spconv_transpose_weight).  n <= 64 per call; the array travels as a kernel argument.
+// (mopa_spconv_transpose_weight); bit 16 = the run layout of the offset-major kernel (mopa_spconv_run_pack_weight; bits 8-15 then
+// hold ITS column-group width, mopa_spconv_run_form).  n <= 64 per call; the array travels as a kernel argument.
 #define PW_MAX 64
 struct PackDescs { int64_t src[PW_MAX], dst[PW_MAX]; int32_t K[PW_MAX], cin[PW_MAX], cout[PW_MAX], flags[PW_MAX]; };
 __global__ void k_pack_w_batched(const PackDescs d) {
@@ -432,6 +434,10 @@ __global__ void k_pack_w_batched(const PackDescs d) {
   float* __restrict__ wp = reinterpret_cast<float*>(d.dst[e]);
   const int K = d.K[e], cin_w = d.cin[e], cout_w = d.cout[e], transpose = d.flags[e] & 1, ntw = (d.flags[e] >> 8) & 0xff;
   const int n = K * cin_w * cout_w;
+  if (d.flags[e] & 0x10000) {   // the run layout of sprun.hip (bits 8-15: its column-group width)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) run_pack_elem(w, wp, i, K, cin_w, cout_w, transpose, ntw);
+    return;
+  }
   if (ntw == 0) {   // wt[o][co][ci] = w[o][ci][co]
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const int ci = i % cin_w, t = i / cin_w;
@@ -465,7 +471,9 @@ MOPA_API int mopa_spconv_pack_weights_batched(const int64_t* desc_host, int32_t 
     const int transpose = flags & 1, ntw = (flags >> 8) & 0xff;
     const int cin_c = transpose ? cout : cin, cout_c = transpose ? cin : cout;
     if (!r[0] || !r[1] || K <= 0 || cin <= 0 || cout <= 0 || (int64_t)K * cin * cout >= (1ll << 31)) return MOPA_ERR_ARG;
-    if (ntw && (cin_c % 16 || cout_c % 16 || ntw > 4 || (cout_c / 16) % ntw)) return MOPA_ERR_ARG;
+    const bool run = (flags & 0x10000) != 0;
+    if (run && (ntw == 0 || ntw != run_nt(cin_c, cout_c))) return MOPA_ERR_ARG;
+    if (!run && ntw && (cin_c % 16 || cout_c % 16 || ntw > 4 || (cout_c / 16) % ntw)) return MOPA_ERR_ARG;
     if (!ntw && !transpose) return MOPA_ERR_ARG;
     d.src[e] = r[0]; d.dst[e] = r[1]; d.K[e] = K; d.cin[e] = cin; d.cout[e] = cout; d.flags[e] = flags;
     const int64_t ne = (int64_t)K * cin * cout;

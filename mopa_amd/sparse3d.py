@@ -25,6 +25,8 @@ BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
 BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
 LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
 BATCHED_REPACK = os.environ.get("MOPA_BATCHED_REPACK", "1") != "0"   # A/B switch: one launch for all stale weight forms
+RUN_PATH = os.environ.get("MOPA_SPCONV_RUN", "1") != "0"             # the offset-major convolution (csrc/sprun.hip); 0 = round-4 kernels only
+RUN_MAX_ROWS = int(os.environ.get("MOPA_SPCONV_RUN_TABLE_ROWS", "220000"))   # 27-offset tables above this get no run-major rulebook
 
 
 def _ws(nbytes, device):
@@ -144,6 +146,21 @@ class Geometry3D:
         call("mopa_rulebook_groups_fill_batched", desc_h.data_ptr(), len(tables), ntile, ptr(gs), ptr(go), ptr(gi), ptr(gout), st)
         for i, t in enumerate(tables):
             self._rb[t.data_ptr()] = (gs[tile0[i]:tile0[i + 1] + 1], go, gi, gout)
+        # run-major rulebooks (csrc/sprun.hip: the rules of one filter offset as one contiguous run of slots) for the tables the
+        # offset-major convolution can take -- every deconvolution table (one rule per output row: products go straight to the
+        # output) and the 27-offset tables up to RUN_MAX_ROWS rows (above, the partial slab's bytes cost more than the fuller MFMA
+        # groups return: mopa_spconv_run_wanted) -- all in three launches, sized from the bound K * rows (no host round trip)
+        self._runs = {}
+        rt = [t for t in self.up] + [t for t in self.nbr27 if t.shape[1] <= RUN_MAX_ROWS] if RUN_PATH else []
+        for i in range(0, len(rt), 24):
+            rows = []
+            for t in rt[i:i + 24]:
+                K, Ao = t.shape
+                buf = torch.empty(query("mopa_rulebook_runs_bytes", K, Ao) // 4, **i32)
+                self._runs[t.data_ptr()] = buf
+                rows.append((t.data_ptr(), K, Ao, buf.data_ptr()))
+            rdesc = np.asarray(rows, dtype=np.int64)
+            call("mopa_rulebook_runs_build_batched", rdesc.ctypes.data, len(rows), st)
         self.row_start = torch.empty(A[0] + 1, **i32)
         self.row_points = torch.empty(N, **i32)
         wsb = query("mopa_points_csr_workspace_bytes", A[0])
@@ -156,7 +173,7 @@ class Geometry3D:
         d = getattr(self, "_desc", None)
         if d is None:
             L = self.num_levels
-            d = np.zeros(8 + 8 * (L + 1) + 8, np.int64)   # header, L + 1 level rows, tail (second group boundary per level)
+            d = np.zeros(8 + 8 * (L + 1) + 8 + 24, np.int64)   # header, L + 1 level rows, tail (second group boundary per level), run rulebooks
             gs0, go, gi, gout = self._rb[self.nbr27[0].data_ptr()]
             d[0:8] = (L, self.n_points, self.point_row.data_ptr(), self.row_start.data_ptr(), self.row_points.data_ptr(),
                       go.data_ptr(), gi.data_ptr(), gout.data_ptr())
@@ -166,6 +183,10 @@ class Geometry3D:
                 if l < L - 1:
                     r[3], r[4] = self.ch[l].data_ptr(), self._rb[self.ch[l].data_ptr()][0].data_ptr()
                     r[5], r[6] = self.up[l].data_ptr(), self._rb[self.up[l].data_ptr()][0].data_ptr()
+                rbase = 8 + 8 * (L + 1) + 8 + 3 * l
+                d[rbase] = self._run_ptr(self.nbr27[l])
+                if l < L - 1:
+                    d[rbase + 1], d[rbase + 2] = self._run_ptr(self.ch[l]), self._run_ptr(self.up[l])
                 if self.split is not None:
                     r[7] = self.split[l][0]
                     if len(self.split[l]) > 1:
@@ -187,6 +208,18 @@ class Geometry3D:
     def rulebook(self, table: torch.Tensor):
         return self._rb.get(table.data_ptr())
 
+    def runs(self, table: torch.Tensor):
+        """(run-major rulebook of the table, 1 if every output row has exactly one rule -- the deconvolution tables -- else 0),
+        or None when none was built."""
+        buf = self._runs.get(table.data_ptr())
+        if buf is None:
+            return None
+        return buf, int(any(table is u for u in self.up))
+
+    def _run_ptr(self, table):
+        buf = self._runs.get(table.data_ptr())
+        return 0 if buf is None else buf.data_ptr()
+
     def tensors(self):
         """Every device tensor this geometry owns."""
         out = [self.point_row, self.row_start, self.row_points]
@@ -194,6 +227,7 @@ class Geometry3D:
             out += list(lst)
         for rb in self._rb.values():
             out += list(rb)
+        out += list(self._runs.values())
         return out
 
     def record_stream(self, stream):
@@ -240,14 +274,20 @@ def new_view(rows, C, device, ld=None):
 
 
 def spconv_fwd(nbr: torch.Tensor, x: View, w: torch.Tensor, out: View, w_flip: bool = False, rb=None,
-               w_transposed: bool = False):
+               w_transposed: bool = False, runs=None):
     """out = sum_o x[nbr[o]] @ Wc[o] with Wc = w ([K][Cin][Cout]) or, for backward-data (`w_transposed`), the
     per-offset transpose of the layer weight w ([K][Cout][Cin]).  `rb` = the table's grouped rulebook
     (Geometry3D.rulebook(nbr)) selects the prefetching kernels; without it the kernel compacts the dense table on the
-    fly.  The weight is re-laid out per call as the chosen kernel wants it (packed / transposed): one tiny kernel."""
+    fly; `runs` = (the table's run-major rulebook, one-rule-per-row flag) (Geometry3D.runs(nbr)) lets the offset-major kernel take
+    the shapes it wins on.  The weight is re-laid out per call as the chosen kernel wants it (packed / transposed): one tiny kernel."""
     K, A_out = nbr.shape
     cin, cout = x.C, out.C
     assert out.rows == A_out and w.shape == ((K, cout, cin) if w_transposed else (K, cin, cout)), (nbr.shape, cin, cout, w.shape)
+    if runs is not None and A_out * 8 * x.ld * 4 < 1 << 32 and query("mopa_spconv_run_wanted", K, A_out, cin, cout, runs[1]):
+        # offset-major: per-offset GEMM into a partial slab + ordered per-row sum (csrc/sprun.hip); same rule as scn_exec.hip
+        wk = _weight_form(w, ("run", int(w_transposed), query("mopa_spconv_run_form", cin, cout)))
+        spconv_launch_run(runs, K, x, wk, out, w_flip)
+        return
     ntw = query("mopa_spconv_grouped_wants_packed", K, A_out, cin, cout) if rb is not None else 0
     if A_out * 8 * x.ld * 4 >= 1 << 32:   # the pipelined kernels use 32-bit byte offsets into the input rows
         ntw = 0
@@ -283,7 +323,7 @@ def _refresh_stale_forms(st):
         if tag == new_tag:
             continue
         form = key[1]
-        flags = (form[1] | (form[2] << 8)) if form[0] == "pack" else 1
+        flags = (form[1] | (form[2] << 8)) if form[0] == "pack" else (form[1] | (form[2] << 8) | 0x10000) if form[0] == "run" else 1
         rows.append((w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1], w.shape[2], flags))
         hits.append((key, new_tag, t, wref))
     for i in range(0, len(rows), 64):
@@ -314,6 +354,9 @@ def _weight_form(w: torch.Tensor, form: tuple) -> torch.Tensor:
     if form[0] == "pack":
         t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
         call("mopa_spconv_pack_weight", ptr(w), K, w.shape[1], w.shape[2], form[1], form[2], ptr(t), stream())
+    elif form[0] == "run":
+        t = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
+        call("mopa_spconv_run_pack_weight", ptr(w), K, w.shape[1], w.shape[2], form[1], ptr(t), stream())
     else:
         t = spconv_transpose_weight(w)
     if len(_weight_cache) > 4096:
@@ -340,6 +383,14 @@ def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_fli
              int(w_flip), out.p, out.ld, ptr(ws), ws.numel(), stream())
     else:
         call("mopa_spconv_fwd", ptr(nbr), K, A_out, x.p, x.ld, cin, ptr(wk), cout, int(w_flip), out.p, out.ld, stream())
+
+
+def spconv_launch_run(runs, K: int, x: View, wk: torch.Tensor, out: View, w_flip: bool):
+    """The offset-major convolution launch (gather-GEMM + ordered reduce) on a weight in the run layout (bench.py times this)."""
+    buf, one = runs
+    ws = None if one else _ws(query("mopa_spconv_run_workspace_bytes", K, out.rows, out.C), wk.device)
+    call("mopa_spconv_fwd_run", ptr(buf), K, out.rows, x.p, x.ld, x.C, ptr(wk), out.C, int(w_flip), out.p, out.ld, one,
+         ptr(ws), 0 if ws is None else ws.numel(), stream())
 
 
 def spconv_transpose_weight(w: torch.Tensor) -> torch.Tensor:
@@ -872,7 +923,7 @@ class SCNNetFunction(torch.autograd.Function):
                 t = table(kind, l)
                 if kind == "nin":   # NetworkInNetwork == a one-offset convolution on the identity rule (the centre offset's row)
                     w = w.view(1, w.shape[0], w.shape[1])
-                spconv_fwd(t, view(src), w, view(dst), rb=geom.rulebook(t))
+                spconv_fwd(t, view(src), w, view(dst), rb=geom.rulebook(t), runs=geom.runs(t))
             else:
                 _, a, b, dst = op
                 va, vb, vd = view(a), view(b), view(dst)
@@ -964,12 +1015,12 @@ class SCNNetFunction(torch.autograd.Function):
                     continue
                 dx = gview(dx_ref)
                 if kind == "subm":        # nbr[o][i]=j <=> nbr[26-o][j]=i : same table, flipped offsets
-                    spconv_fwd(t, dout, w, dx, w_flip=True, rb=geom.rulebook(t), w_transposed=True)
+                    spconv_fwd(t, dout, w, dx, w_flip=True, rb=geom.rulebook(t), w_transposed=True, runs=geom.runs(t))
                 elif kind == "nin":
                     spconv_fwd(t, dout, w, dx, rb=geom.rulebook(t), w_transposed=True)
                 else:                     # rules reversed: conv <-> deconv swap tables
                     rt = geom.up[l] if kind == "down" else geom.ch[l]
-                    spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True)
+                    spconv_fwd(rt, dout, w, dx, rb=geom.rulebook(rt), w_transposed=True, runs=geom.runs(rt))
         dfeat_in = None
         if ctx.feats_needs_grad:
             cin = spec.in_channels

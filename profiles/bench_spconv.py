@@ -8,6 +8,7 @@ and prints us per launch, the time 40 % of the HBM roofline would take at SURVEY
 
 Usage: python profiles/bench_spconv.py [levels=7] [reps=20]     (MOPA_SPCONV_PATH=1|2 forces pipe|block kernel)
 """
+import os
 import sys
 import torch
 
@@ -38,14 +39,28 @@ def main():
     torch.manual_seed(0)
     m = 16
     print(f"{'level':>5} {'table':>6} {'rows':>8} {'rules':>9} {'cin':>4} {'cout':>4} {'wave us':>9} {'grouped us':>10} "
-          f"{'t40 us':>7} {'frac':>6} {'TF/s':>6} same  max|diff|  checksum(grouped)")
-    tot_t, tot_b = 0.0, 0.0
+          f"{'t40 us':>7} {'frac':>6} {'TF/s':>6} same  max|diff|  checksum(grouped) | run us (gemm + reduce)  TF/s  rel.err  run2==run")
+    tot_t, tot_b, tot_r, tot_best = 0.0, 0.0, 0.0, 0.0
+    bwd = os.environ.get("BENCH_BWD", "0") != "0"     # backward-data shapes: Cout -> Cin on the reversed table
+    runs = {}
+
+    def run_book(tab):
+        key = tab.data_ptr()
+        if key not in runs:
+            K, Ao = tab.shape
+            buf = torch.empty(s3.query("mopa_rulebook_runs_bytes", K, Ao) // 4, dtype=torch.int32, device="cuda")
+            desc = torch.tensor([tab.data_ptr(), K, Ao, buf.data_ptr()], dtype=torch.int64)
+            call("mopa_rulebook_runs_build_batched", desc.data_ptr(), 1, stream())
+            runs[key] = buf
+        return runs[key]
     for l in range(L):
         C = m * (l + 1)
         cases = [("subm", g.nbr27[l], C, C), ("subm", g.nbr27[l], 2 * C, C)]
         if l + 1 < L:
             cases.append(("down", g.ch[l], C, C + m))      # Convolution k2s2: out rows = level l+1
             cases.append(("up", g.up[l], C + m, C))        # Deconvolution k2s2: out rows = level l
+        if bwd:   # the convolution backward-data runs: transposed weight on the reversed table
+            cases = [(n, (t if n == "subm" else (g.up[l] if n == "down" else g.ch[l])), co, ci) for n, t, ci, co in cases]
         for name, tab, cin, cout in cases:
             K, Ao = tab.shape
             Ain = int(tab.max().item()) + 1
@@ -80,9 +95,32 @@ def main():
             chk = int((bits * (torch.arange(bits.numel(), device="cuda").view_as(bits) % 8191 + 1)).sum().item()) & 0xffffffffffff
             tot_t += tg
             tot_b += alg
-            print(f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {t40:>7.1f} {alg / tg / 8e6:>6.3f} "
-                  f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e} {chk:012x}", flush=True)
-    print(f"forward family: {tot_t:.1f} us for {tot_b / 1e6:.1f} MB algorithmic = {tot_b / tot_t / 8e6:.3f} of 8 TB/s")
+            line = (f"{l:>5} {name:>6} {Ao:>8} {rules:>9} {cin:>4} {cout:>4} {tw:>9.1f} {tg:>10.1f} {t40:>7.1f} {alg / tg / 8e6:>6.3f} "
+                    f"{2 * rules * cin * cout / tg / 1e6:>6.1f} {same} {err:.2e} {chk:012x}")
+            # offset-major path (sprun.hip): one rule per output row <=> the deconvolution-shaped table (every fine row has one parent)
+            one = 1 if (K == 8 and rules == Ao) else 0
+            tr = float("nan")
+            if cin % 16 == 0 and cout % 16 == 0 and Ao * 8 * xv.ld * 4 < (1 << 32):
+                rbuf = run_book(tab)
+                wr = torch.empty_like(w)
+                call("mopa_spconv_run_pack_weight", ptr(w), K, cin, cout, 0, ptr(wr), stream())
+                wsr = torch.empty(max(256, 0 if one else s3.query("mopa_spconv_run_workspace_bytes", K, Ao, cout)), dtype=torch.uint8, device="cuda")
+                o3 = s3.new_view(Ao, cout, "cuda")
+
+                def run():
+                    call("mopa_spconv_fwd_run", ptr(rbuf), K, Ao, xv.p, xv.ld, cin, ptr(wr), cout, 0, o3.p, o3.ld, one, ptr(wsr), wsr.numel(), stream())
+
+                tr = timed(run, reps)
+                first = o3.t.clone()
+                o3.t.fill_(float("nan"))
+                run()
+                rel = float((o3.t - o1.t).abs().max() / o1.t.abs().max())
+                line += f" | {tr:>8.1f} {2 * rules * cin * cout / tr / 1e6:>6.1f} {rel:.1e} {torch.equal(first, o3.t)}"
+                tot_r += tr
+            tot_best += min(tg, tr) if tr == tr else tg
+            print(line, flush=True)
+    print(f"forward family: {tot_t:.1f} us for {tot_b / 1e6:.1f} MB algorithmic = {tot_b / tot_t / 8e6:.3f} of 8 TB/s"
+          f" | best of (grouped, run) per layer: {tot_best:.1f} us = {tot_b / tot_best / 8e6:.3f}")
 
 
 if __name__ == "__main__":
