@@ -257,6 +257,7 @@ class GradSink:
         self.ret = {k: None for k in self.order}
         self.direct = os.environ.get("MOPA_DIRECT_GRADS", "1") != "0"
         self._pending = []   # attached parameters handed out by the previous take(): their kernels are enqueued when the next one starts
+        self._loose = set()  # ids of parameters whose gradient went to a fresh tensor (autograd accumulates it after the pass)
 
     def _attached(self, p):
         g = p.grad
@@ -272,6 +273,9 @@ class GradSink:
             if GRAD_DONE_HOOKS and not self.defer_hooks:
                 self._pending = ps
             return [p.grad for p in ps], True
+        # not written in place: autograd adds the returned tensor to .grad AFTER this backward pass -- such a parameter is never
+        # reported "done" from here (a bucket holding it stays for all_reduce() after backward)
+        self._loose.update(id(p) for p in ps)
         ts = []
         for n, p in zip(names, ps):
             if self.ret[n] is None:
@@ -289,7 +293,7 @@ class GradSink:
 
     def returned(self):
         if GRAD_DONE_HOOKS:   # end of the backward pass: every parameter of this network is final, taken or not (a head without a loss)
-            self._pending = list(self.params.values())
+            self._pending = [p for p in self.params.values() if id(p) not in self._loose]   # ... unless autograd still has to add it
             self.flush(final=True)
         return tuple(self.ret[k] for k in self.order)
 

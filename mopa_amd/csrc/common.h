@@ -28,6 +28,26 @@ static inline int stream_grid(int64_t work_items, int block) {
   return (int)g;
 }
 
+// CU count of the CURRENT device (cached per device: a process may drive several GPUs), 0 on error.
+#include <atomic>
+static inline int mopa_device_index() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : -1;
+}
+static inline int mopa_cu_count() {
+  static std::atomic<int> cus[64];
+  const int dev = mopa_device_index();
+  if (dev < 0) return 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 #define WAVE 64
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -396,6 +396,9 @@ MOPA_API int mopa_bn_act_bwd_groups(const float* dy, int32_t ld_dy, const float*
   if (ws_bytes < mopa_bnrelu_rows_bwd_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   BnGroups grp;
   if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
+  // the partial slabs of all groups must fit in front of the coefficient block (rows per block stop growing at 1024, so groups of
+  // more than 2 M rows hold more blocks than the workspace's cap of 3 x 2048: the forward refuses the same case)
+  if ((size_t)grp.nblk_total * 2 * C * sizeof(float) > mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)ws;
   float* coef = (float*)((char*)ws + mopa_bnrelu_rows_workspace_bytes(num_rows, C));
@@ -423,6 +426,7 @@ MOPA_API int mopa_bn_bwd_sums_groups(const float* dy, int32_t ld_dy, const float
   if (ws_bytes < mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   BnGroups grp;
   if (!bn_make_groups(&grp, num_rows, n_groups, split1, split2)) return MOPA_ERR_ARG;
+  if ((size_t)grp.nblk_total * 2 * C * sizeof(float) > mopa_bnrelu_rows_workspace_bytes(num_rows, C)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)ws;
   const int RL = 256 / (C >> 2);

@@ -345,14 +345,14 @@ __global__ __launch_bounds__(256) void k_run_reduce(const int* __restrict__ pos,
 // against the output-stationary kernels at 8 and 16 scans (profiles/r5_spconv_run.md):
 //   * tables with one rule per output row (no slab, no reduce): always, from 32 input channels;
 //   * 27-offset tables: where the matrix pipe bounds the launch and the slab's bytes (2 x rules x cout x 4, written and read once)
-//     stay below what the fuller MFMA groups return -- cin >= 64, cout >= 48 and rows x cout <= 100,000 x cin (wins: 103k rows
+//     stay below what the fuller MFMA groups return -- cin >= 64, cout >= 48 and rows x cout <= 110,000 x cin (wins: 103k rows
 //     96 -> 48 0.78x, 49k 128 -> 64 0.71x, 98k 64 -> 64 0.97x, 39k 80 -> 160 0.86x; losses: 386k 64 -> 32 1.33x, 98k 64 -> 128 1.21x);
 //   * the 8-offset tables with several rules per row (Convolution k2s2 forward, Deconvolution backward-data): within 10 % either
 //     way on every level -- they stay on the output-stationary kernels.
 // MOPA_SPCONV_RUN=0 switches the path off, =2 forces it wherever the shape is supported (tuning / tests).
 MOPA_API int mopa_spconv_run_wanted(int32_t K, int32_t num_out, int32_t cin, int32_t cout, int32_t one_rule_per_row) {
   static const int mode = getenv("MOPA_SPCONV_RUN") ? atoi(getenv("MOPA_SPCONV_RUN")) : 1;
-  static const int64_t rows_per = getenv("MOPA_SPCONV_RUN_ROWS_PER") ? atoll(getenv("MOPA_SPCONV_RUN_ROWS_PER")) : 100000;
+  static const int64_t rows_per = getenv("MOPA_SPCONV_RUN_ROWS_PER") ? atoll(getenv("MOPA_SPCONV_RUN_ROWS_PER")) : 110000;
   if (mode == 0 || K <= 0 || K > 27 || num_out <= 0 || run_nt(cin, cout) == 0) return 0;
   if ((int64_t)num_out * 8 * 224 * 4 >= (1ll << 32)) return 0;   // 32-bit byte offsets into the input rows
   if (mode == 2) return 1;
@@ -373,18 +373,13 @@ MOPA_API size_t mopa_spconv_run_workspace_bytes(int32_t K, int32_t num_out, int3
 template <int NT, int RG>
 static int launch_run(const int* hdr, const int* run_in, const int* run_out, int K, int64_t slots_bound, const float* in, int ld_in, int cin,
                       const float* wr, int cout, int w_flip, float* dst, int ld_dst, bool scatter, hipStream_t st) {
-  static std::atomic<int> cus{0};
-  int ncu = cus.load(std::memory_order_relaxed);
-  if (ncu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOPA_ERR_LAUNCH;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    cus.store(ncu, std::memory_order_relaxed);
-  }
+  const int ncu = mopa_cu_count();   // of the current device
+  if (ncu <= 0) return MOPA_ERR_LAUNCH;
   const size_t lds = (size_t)cin * NT * 16 * sizeof(float);
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 4) per_cu = 4;
+  static const int cap_force = getenv("MOPA_SPCONV_RUN_PER_CU") ? atoi(getenv("MOPA_SPCONV_RUN_PER_CU")) : 0;   // tuning only
+  const int cap = cap_force ? cap_force : 4;
+  if (per_cu > cap) per_cu = cap;
   if (per_cu < 1) per_cu = 1;
   const int64_t items_bound = slots_bound / (64 * RG);
   int64_t gx = (int64_t)ncu * per_cu;
@@ -439,7 +434,7 @@ MOPA_API int mopa_spconv_fwd_run(const int32_t* runs, int32_t K, int32_t num_out
   const int rg = rg_force ? rg_force : rules_est / 128 < 400 ? 1 : 2;
   int rc;
 #define RUN_L(N, G) rc = launch_run<N, G>(hdr, run_in, run_out, K, cap, in, ld_in, cin, weight_run, cout, w_flip & 1, dst, ld_dst, one_rule_per_row != 0, st)
-#define RUN_N(N) if (rg == 1) RUN_L(N, 1); else RUN_L(N, 2);
+#define RUN_N(N) if (rg == 1) RUN_L(N, 1); else if (rg == 4 && N <= 5) RUN_L(N, 4); else RUN_L(N, 2);
   switch (nt) {
     case 1: RUN_N(1); break;
     case 2: RUN_N(2); break;

@@ -1070,13 +1070,9 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
   const int64_t nitems = cdiv64(T, 16) * (Cout / 64);
   if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
   const size_t ldsb = (size_t)2 * 36 * 64 * 16;   // 72 KB: two workgroups per CU
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOPA_ERR_LAUNCH;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int ncu = mopa_cu_count();   // of the current device
+  const int dev = mopa_device_index();
+  if (ncu <= 0 || dev < 0) return MOPA_ERR_LAUNCH;
   const int v = (stats ? 1 : 0) | (V ? 2 : 0);
   typedef void (*kern_t)(const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, int,
                          int, float*
@@ -1085,11 +1081,11 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
 #endif
                          );
   static const kern_t kerns[4] = {k_wino4_conv<false, false>, k_wino4_conv<true, false>, k_wino4_conv<false, true>, k_wino4_conv<true, true>};
-  static bool attr[4] = {false, false, false, false};
-  if (!attr[v]) {
+  static std::atomic<bool> attr[64][4];   // per device and variant: the attribute belongs to the device's code object
+  if (!attr[dev][v].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
       return MOPA_ERR_LAUNCH;
-    attr[v] = true;
+    attr[dev][v].store(true, std::memory_order_release);
   }
   const unsigned nblk = (unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu);   // persistent: two workgroups per CU
   const int ipg = stats ? (B / n_groups) | (bn_c0 << 16) : 1;

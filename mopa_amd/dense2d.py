@@ -183,6 +183,7 @@ def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: int = 0):
         u = torch.empty((F + 2) ** 2, (C if transposed == 1 else R), (R if transposed == 1 else C), dtype=torch.float32, device=w.device)
         name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f")[transposed]
         call(name, ptr(w), O, I, int(dgrad), ptr(u), stream())
+        u._mopa_wino_layout = (F, transposed)   # (layouts 0 and 2 have the same shape when R == C: wino_conv checks this tag)
         return u
     assert not (transposed and F != 4)
     return _cached_weight_form(w, ("wino", F, int(dgrad), transposed), build,
@@ -279,8 +280,8 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     T, NP = B * th * tw, (F + 2) ** 2
     sfx = "" if F == 2 else "4"
     if F == 4 and wino4_direct(cin, cout, B, H, W, role):
-        if tuple(U.shape) != (36, cin, cout):
-            raise RuntimeError("wino_conv: the one-kernel F(4x4) path takes the fragment weight form")
+        if tuple(U.shape) != (36, cin, cout) or getattr(U, "_mopa_wino_layout", (4, 2)) != (4, 2):
+            raise RuntimeError("wino_conv: the one-kernel F(4x4) path takes the fragment weight form (wino_weight_cached(..., transposed=2))")
         V = torch.empty(NP * T * cin, dtype=torch.float32, device=dev) if want_v else None   # (a by-product, for the weight gradient)
         call("mopa_wino4_conv", x_p, ld_in, ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
              int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1,
@@ -294,11 +295,13 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     else:
         call(f"mopa_wino{sfx}_input", x_p, ld_in, B, H, W, cin, ptr(V), stream())
     if F == 4 and wino4_fused(cin, cout, B, H, W):
-        if tuple(U.shape) != (36, cout, cin):
-            raise RuntimeError("wino_conv: the fused F(4x4) path takes the transposed weight transform")
+        if tuple(U.shape) != (36, cout, cin) or getattr(U, "_mopa_wino_layout", (4, 1)) != (4, 1):
+            raise RuntimeError("wino_conv: the fused F(4x4) path takes the transposed weight transform (wino_weight_cached(..., transposed=1))")
         call("mopa_wino4_gemm_output", ptr(V), ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
              int(accumulate), stream())
         return V
+    if getattr(U, "_mopa_wino_layout", (F, 0)) != (F, 0):
+        raise RuntimeError("wino_conv: the batched-GEMM path takes the plain weight transform")
     M = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
     g1 = _geom(B=1, IH=1, IW=T, OHl=1, OWl=T, OHa=1, OWa=T, TH=1, TW=1, KWF=1, Cin=cin, Cout=cout, ld_in=cin, ld_out=cout)
     igemm_batched(ptr(V), ptr(U), ptr(M), g1, NP, T * cin, cin * cout, T * cout)
@@ -999,9 +1002,10 @@ class Graph2D:
         if self.bwd is not None and gp != self.grad_ptrs:
             self.bwd = None      # the optimizer re-attached its gradient buffers elsewhere: record again
         if self.bwd is None:
-            try:
+            try:   # (recorded with a hook-free sink: FlatAdam's bucket hooks must not issue collectives inside the stream capture --
+                   #  the outer pass's sink reports the gradients once the replay is enqueued: ADVICE r4)
                 self.bwd, _ = self._record(
-                    lambda: _backbone_backward(P, GradSink(P, order), self.tape, self.J, self.feat, self.dfeat, self.training, 0,
+                    lambda: _backbone_backward(P, GradSink(P, order, defer_hooks=True), self.tape, self.J, self.feat, self.dfeat, self.training, 0,
                                                self.seed_t, False, self.H, self.W, self.groups), self.fwd.pool())
             except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
                 self.failed = True

@@ -160,6 +160,9 @@ class Net2DSeg(_CachedParams, nn.Module):
         groups = int(data_batch.get("bn_groups", 1))
         if groups < 1 or img.shape[0] % groups:
             raise ValueError(f"bn_groups={groups} does not divide the batch of {img.shape[0]} images")
+        if groups > 3:   # the grouped BatchNorm kernels hold three row ranges per launch (csrc/rows.hip::BN_MAX_GROUPS)
+            raise ValueError(f"bn_groups={groups}: at most 3 groups per pass (source, target and one more batch); call the network once per "
+                             "group, or in passes of up to three groups")
         # graphs: where dense2d keeps the recorded HIP graphs of the backbone (dropped with the cache when tensor objects change)
         spec = _Spec(order=order, num_classes=self.num_classes, dual_head=bool(self.dual_head), graphs=self._cache,
                      grad_enabled=torch.is_grad_enabled(), groups=groups)

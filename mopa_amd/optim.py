@@ -195,6 +195,11 @@ class FlatAdam(torch.optim.Optimizer):
         runs the source and the target half before the optimizer step, train_xmuda_mopa.py:342-427)."""
         if not self._buckets or not self._collectives_on():
             return False
+        if os.environ.get("MOPA_DIRECT_GRADS", "1") == "0":
+            # without in-place gradients autograd's AccumulateGrad adds a pass's gradients to .grad only AFTER Function.backward has
+            # returned -- after the bucket's all-reduce would have been enqueued: the collective would race with that add (ADVICE r4)
+            raise RuntimeError("FlatAdam.arm_buckets needs the gradients written in place (MOPA_DIRECT_GRADS=0 is set): "
+                               "use all_reduce() after backward instead")
         self._check_grads()
         self._checked = True
         self._armed = True

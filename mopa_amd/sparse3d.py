@@ -676,11 +676,11 @@ _IO = dict(TRAINING=0, EPOCH=1, FEATS=2, CIN=3, X0BUF=4, X0COL=5, OUTBUF=6, OUTC
 
 # The sparse weight gradients of the native backward pass on a second stream (csrc/scn_exec.hip, IO_WSTREAM): they need a layer's
 # input and output gradient only and nothing in the pass waits for them; the backward-data / BatchNorm chain they ran in front of
-# is a sequence of short launches that leaves most of the chip idle.  MOPA_SCN_WGRAD_STREAM=1 switches it on: 3D-only training
-# 1423 -> 1495 scans/s, bit-identical results, neutral inside the joint steps (the chip is full there).  OFF by default because
-# every kernel of the pass then shares the chip with a weight-gradient kernel: the sparse-conv family's launches take 51 instead
-# of 45 us each (rocprofv3), i.e. the per-kernel roofline figure this repository tracks gets WORSE while the step gets faster.
-SCN_WGRAD_STREAM = os.environ.get("MOPA_SCN_WGRAD_STREAM", "0") == "1"
+# is a sequence of short launches that leaves most of the chip idle.  3D-only training 1423 -> 1495 scans/s (round 3), bit-identical
+# results, neutral inside the joint steps (the chip is full there).  ON by default since round 5 (the product ships the faster
+# step); the sparse-conv roofline figure of bench.py is bracketed in passes of the Python walk, which has no second stream, so the
+# per-kernel figure is not measured beside a weight-gradient kernel.  MOPA_SCN_WGRAD_STREAM=0 switches it off.
+SCN_WGRAD_STREAM = os.environ.get("MOPA_SCN_WGRAD_STREAM", "1") == "1"
 _wgrad3 = {}   # (device index, consumer stream) -> (torch stream, "ready" event, "done" event)
 
 
