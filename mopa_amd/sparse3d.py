@@ -55,8 +55,12 @@ class Geometry3D:
         (three groups).  Rows are numbered in first-seen order and a voxel belongs to one scan, so the groups' rows are consecutive
         ranges at every level: `self.split[l]` = the boundaries.  BatchNorm then runs per group on row ranges (statistics, running
         updates, gradients: as separate calls of the network would), everything else sees one batch."""
+        if coords.dim() == 2 and coords.shape[1] == 3:
+            # scn.InputLayer takes N x (dimension + 1) or N x dimension coordinates; without the last column every point belongs to
+            # sample 0 -- the form of the reference's own call, mopa/models/xmuda_arch.py:171 (test_Net3DSeg)
+            coords = torch.cat([coords, torch.zeros_like(coords[:, :1])], 1)
         if coords.dim() != 2 or coords.shape[1] != 4:
-            raise RuntimeError(f"coords must be (N,4) [x,y,z,batch], got {tuple(coords.shape)}")
+            raise RuntimeError(f"coords must be (N,4) [x,y,z,batch] or (N,3) [x,y,z], got {tuple(coords.shape)}")
         device = torch.device(device if device is not None else "cuda")
         N = int(coords.shape[0])
         if N == 0:

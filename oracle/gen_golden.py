@@ -167,6 +167,43 @@ def gen_g1b():
     print("G1b", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_g1c():
+    """G1c: the reference's OWN call shape, scaled down: mopa/models/xmuda_arch.py:129-162 (test_Net2DSeg) builds
+    Net2DSeg(11 classes, dual head) and calls it with a (B, N / B, 2) index TENSOR on 2 x 3 x 225 x 400 -- the nuScenes resize of
+    config/xmuda.py:98 (225 -> pad 240, layer4 at 15 x 25).  Here the same aspect at 45 x 80 (pad 48 x 80: layer4 at 3 x 5), 11
+    classes, the index tensor form, train mode (dropout p = 0) and eval mode.  Stored: point outputs, a strided sample of
+    seg_logit_all, gradient norms of all parameters (train)."""
+    from mopa.models.xmuda_arch import Net2DSeg  # reference
+    from oracle.params import det_tensor
+
+    for train in (True, False):
+        rng = np.random.Generator(np.random.PCG64(4580 + int(train)))
+        shape = (2, 3, 45, 80)
+        img = torch.from_numpy(rng.random(shape, dtype=np.float32))
+        idx = torch.from_numpy(np.stack([rng.integers(0, 45, (2, 250)), rng.integers(0, 80, (2, 250))], 2).astype(np.int64))   # (B, N / B, 2)
+        net = Net2DSeg(num_classes=11, dual_head=True, backbone_2d="UNetResNet34", backbone_2d_kwargs={"pretrained": False}, output_all=True)
+        net.load_state_dict({k: det_tensor(k, v.shape) for k, v in net.state_dict().items()})
+        net.train(train)
+        net.net_2d.dropout.p = 0.0
+        out = net({"img": img, "img_indices": idx})
+        save = {"out_feats_s4": out["feats"][::4], "out_seg_logit": out["seg_logit"], "out_seg_logit2": out["seg_logit2"],
+                "out_seg_logit_all_s4": out["seg_logit_all"][:, ::4, ::4]}
+        tag = "train" if train else "eval"
+        if train:
+            g = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}
+            sum((out[k] * g[k]).sum() for k in out).backward()
+            named = dict(net.named_parameters())
+            for k in ("net_2d.conv1.weight", "linear.weight", "linear2.weight", "net_2d.dec_conv_stage1.bias"):
+                save["pgrad_" + k] = named[k].grad
+            for k in ("net_2d.bn1.running_mean", "net_2d.layer4.2.bn2.running_var"):
+                save["buf_" + k] = net.state_dict()[k]
+            norms = {k: [float(p.grad.double().sum()), float(p.grad.double().norm())] for k, p in named.items()}
+            with open(os.path.join(OUT, "g1c_net2dseg_45x80_c11_train_gradnorms.json"), "w") as f:
+                json.dump(norms, f, indent=0)
+        np.savez_compressed(os.path.join(OUT, f"g1c_net2dseg_45x80_c11_{tag}.npz"), **_np(save))
+        print("G1c", tag, {k: tuple(v.shape) for k, v in out.items()})
+
+
 # ----------------------------------------------------------------------------- G2
 def gen_g2():
     from mopa.common.utils.loss import mask_cons_loss  # reference
@@ -471,4 +508,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
     else:
-        gen_g1(), gen_g1b(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7(), gen_g8()
+        gen_g1(), gen_g1b(), gen_g1c(), gen_g2(), gen_g3(), gen_g4(), gen_g5(), gen_g6(), gen_g7(), gen_g8()

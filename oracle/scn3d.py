@@ -74,6 +74,8 @@ class Geometry:
 
     def __init__(self, coords: np.ndarray, num_levels: int = 7, full_scale: int = 4096):
         coords = np.asarray(coords, dtype=np.int64)
+        if coords.ndim == 2 and coords.shape[1] == 3:   # scn.InputLayer: N x dimension coordinates = every point in sample 0 (A.2;
+            coords = np.concatenate([coords, np.zeros((len(coords), 1), np.int64)], 1)   # mopa/models/xmuda_arch.py:171 calls it so)
         self.n_points = coords.shape[0]
         self.num_levels = num_levels
         keys = pack_keys(coords)

@@ -49,6 +49,42 @@ def test_g1_train_and_grads(golden_dir):
         assert abs(float(P[k].grad.double().norm()) - n) <= 2e-3 * n + 1e-5, k
 
 
+def _g1c_inputs(train):
+    """Inputs of fixture G1c, regenerated from the seed (oracle/gen_golden.py::gen_g1c): the index TENSOR form (B, N / B, 2) of the
+    reference's own call, mopa/models/xmuda_arch.py:129-162."""
+    rng = np.random.Generator(np.random.PCG64(4580 + int(train)))
+    img = torch.from_numpy(rng.random((2, 3, 45, 80), dtype=np.float32))
+    idx = torch.from_numpy(np.stack([rng.integers(0, 45, (2, 250)), rng.integers(0, 80, (2, 250))], 2).astype(np.int64))
+    return rng, img, idx
+
+
+def test_g1c_reference_call_shape_11_classes(golden_dir):
+    """The oracle against the reference's outputs at the reference's own call shape scaled down (45 x 80 = the 225 x 400 aspect, pad
+    48 x 80), 11 classes, train + eval, and the reference's parameter-gradient norms."""
+    for train in (True, False):
+        rng, img, idx = _g1c_inputs(train)
+        g = _load(golden_dir, f"g1c_net2dseg_45x80_c11_{'train' if train else 'eval'}.npz")
+        P = det_state(net2d.param_shapes(11, True))
+        P = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in P.items()}
+        out = net2d.net2dseg_forward(P, img, idx, training=train, dropout_p=0.0)
+        np.testing.assert_allclose(out["feats"][::4].detach().numpy(), g["out_feats_s4"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out["seg_logit"].detach().numpy(), g["out_seg_logit"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out["seg_logit2"].detach().numpy(), g["out_seg_logit2"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out["seg_logit_all"][:, ::4, ::4].detach().numpy(), g["out_seg_logit_all_s4"], rtol=1e-4, atol=2e-5)
+        if not train:
+            continue
+        gin = {k: torch.from_numpy(rng.standard_normal(tuple(out[k].shape), dtype=np.float32)) for k in ("feats", "seg_logit_all", "seg_logit2", "seg_logit")}
+        sum((out[k] * gin[k]).sum() for k in gin).backward()
+        for k, v in g.items():
+            if k.startswith("pgrad_"):
+                np.testing.assert_allclose(P[k[6:]].grad.numpy(), v, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(v).max()))
+            if k.startswith("buf_"):
+                np.testing.assert_allclose(P[k[4:]].numpy(), v, rtol=1e-5, atol=1e-6)
+        norms = json.load(open(os.path.join(golden_dir, "g1c_net2dseg_45x80_c11_train_gradnorms.json")))
+        for k, (s_, n) in norms.items():
+            assert abs(float(P[k].grad.double().norm()) - n) <= 5e-3 * n + 1e-5, k
+
+
 def test_g2_mask_cons(golden_dir):
     g = _load(golden_dir, "g2_mask_cons.npz")
     logits = torch.from_numpy(g["logits"]).requires_grad_(True)
