@@ -210,17 +210,21 @@ def dense2d_streams():
 
 
 def _cpu_passes(one_pass, seconds_budget, max_passes, what):
-    """Bounded CPU sample: one warm-up pass, then up to `max_passes` timed passes inside the time
-    budget; value = 1 / median pass time (min and count reported in `sample`)."""
+    """Bounded CPU sample: up to 3 warm-up passes (fewer only if one pass alone eats a third of the time
+    budget), then up to `max_passes` timed passes inside the budget; value = 1 / median pass time (min and count in `sample`)."""
     warm = one_pass()
+    n_warm = 1
+    while n_warm < 3 and (n_warm + 1) * warm < seconds_budget / 3:
+        warm = one_pass()
+        n_warm += 1
     times = []
-    while len(times) < max_passes and sum(times) + warm < seconds_budget:
+    while len(times) < max_passes and sum(times) + n_warm * warm < seconds_budget:
         times.append(one_pass())
     if not times:
         times = [warm]
     med = float(np.median(times))
     return dict(value=1.0 / med, unit="scans/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(times)} timed passes after 1 warm-up within a {seconds_budget:.0f} s budget, each = {what}; "
+                sample=f"{len(times)} timed passes after {n_warm} warm-up pass(es) within a {seconds_budget:.0f} s budget, each = {what}; "
                        f"median {med:.2f} s, min {min(times):.2f} s per scan")
 
 
@@ -476,6 +480,7 @@ def main():
     native_default = sparse3d_mod.NATIVE
     from mopa_amd import dense2d as dense2d_mod
     graph2d_default = dense2d_mod.GRAPH_2D
+    native2d_default = dense2d_mod.NATIVE_2D
     timer = ConvTimer()
     timer.install()
     timer2d = Conv2dTimer()
@@ -894,6 +899,7 @@ def main():
         # that every sparse-conv launch can be bracketed; all other steps run it as one native call per pass (csrc/scn_exec.hip)
         sparse3d_mod.NATIVE = native_default and not timer.enabled
         dense2d_mod.GRAPH_2D = graph2d_default and not timer2d.enabled   # same for the 2D backbone: brackets need the eager walk
+        dense2d_mod.NATIVE_2D = native2d_default and not timer2d.enabled
         # the bracketed steps run in the SAME stream configuration as every other step (weight-gradient stream and 3D side stream
         # on): the brackets then time each launch as it runs inside `value`'s step, sharing the chip with the other streams --
         # which is also what `rocprofv3 --kernel-trace --stats` of this command reports (profiles/r3_final_*)
@@ -925,6 +931,7 @@ def main():
     timer.enabled = timer2d.enabled = False
     sparse3d_mod.NATIVE = native_default
     dense2d_mod.GRAPH_2D = graph2d_default
+    dense2d_mod.NATIVE_2D = native2d_default
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1164,7 +1171,11 @@ def main():
                        "net2d_executor": (None if not joint else
                                           f"HIP-graph replay of the backbone ({dense2d_mod.GRAPH_STATS['forward_replays']} forward / "
                                           f"{dense2d_mod.GRAPH_STATS['backward_replays']} backward replays in this process; heads and "
-                                          "bracketed steps eager)" if graph2d_default else "eager (default; MOPA_GRAPH_2D=1 replays the backbone from HIP graphs)")},
+                                          "bracketed steps eager)" if graph2d_default else
+                                          f"native command list (csrc/exec2d.hip: the recorded backbone pass replayed in one C-ABI call; "
+                                          f"{dense2d_mod.GRAPH_STATS['forward_replays']} forward / {dense2d_mod.GRAPH_STATS['backward_replays']} backward "
+                                          "replays in this process; heads and bracketed steps walk it from Python)" if native2d_default else
+                                          "python walk (MOPA_NATIVE_2D=0)")},
             "iterations_per_s": round(world * args.steps / elapsed, 3),
             "value_with_host_inputs": None if host_value is None else round(host_value[0], 3),
             "value_two_calls_per_domain": None if two_call_value is None else round(two_call_value[0], 3),

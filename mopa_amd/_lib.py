@@ -83,6 +83,13 @@ SIGNATURES = {
     "mopa_bnrelu_rows_bwd_workspace_bytes": ("z", "ii"),
     "mopa_bnrelu_rows_bwd": ("i", "pipipiiipfippiipzp"),
     "mopa_rows_add": ("i", "pipipiiip"),
+    "mopa_zero_rows": ("i", "pilip"),
+    "mopa_copy_rows": ("i", "pipilip"),
+    "mopa_add_i64_many": ("i", "pilp"),
+    # ---- command-list executor (exec2d.hip)
+    "mopa_exec_fn_id": ("i", "p"),
+    "mopa_exec_fn_count": ("i", ""),
+    "mopa_exec_replay": ("i", "plp"),
     "mopa_input_layer_fwd": ("i", "pippipip"),
     "mopa_input_layer_bwd": ("i", "pippiipp"),
     "mopa_output_layer_heads_fwd": ("i", "pipiiipppppppp"),
@@ -193,10 +200,101 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+RECORDER = None   # a CommandList while a pass is being recorded (mopa_amd/dense2d.py::Graph2D), else None
+
+
 def call(name: str, *args):
+    if RECORDER is not None:
+        RECORDER.add(name, args)
     rc = getattr(_lib or load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc}")
+
+
+class CommandList:
+    """A recorded sequence of this library's entry points (+ event hand-overs between two streams) that mopa_exec_replay
+    (csrc/exec2d.hip) walks in ONE call: `words` = [op, nargs, args...]* as int64; integers and pointers as they are, float / double
+    as the bits of a double.  The stream arguments (always the last one) are kept as slots: `main` / `side` word indices that
+    replay() patches with the streams of the replaying pass.  Host arrays passed by pointer (HOST_ARGS: the 25-int geometry of the
+    implicit-GEMM calls, pointer tables) are copied into `blob`, which lives as long as the list."""
+
+    HOST_ARGS = {"mopa_conv2d_igemm": {4: 100}, "mopa_conv2d_igemm_batched": {3: 100}, "mopa_conv2d_bwd_weight": {3: 100},
+                 "mopa_add_i64_many": {0: 512}}
+    _ids = {}
+
+    def __init__(self, main_stream: int):
+        self.words, self.main, self.side, self.fix = [], [], [], []
+        self.rec_main, self.rec_side = main_stream, None
+        self.blob = bytearray()
+        self.n_calls = 0
+
+    def _stream_slot(self, handle, at):
+        if handle == self.rec_main:
+            self.main.append(at)
+        else:
+            if self.rec_side is None:
+                self.rec_side = handle
+            if handle != self.rec_side:
+                raise RuntimeError("CommandList: a third stream inside a recorded pass")
+            self.side.append(at)
+
+    def add(self, name, args):
+        import struct
+        fid = self._ids.get(name)
+        if fid is None:
+            fid = self._ids[name] = int((_lib or load()).mopa_exec_fn_id(name.encode()))
+        sig = SIGNATURES[name][1]
+        if fid < 0 or not sig.endswith("p") or len(sig) != len(args):
+            raise RuntimeError(f"CommandList: {name} cannot be recorded")
+        host = self.HOST_ARGS.get(name, {})
+        base = len(self.words)
+        self.words += [fid, len(args)]
+        for j, (t, a) in enumerate(zip(sig, args)):
+            if j in host:
+                n = host[j]
+                self.fix.append((base + 2 + j, len(self.blob)))
+                self.blob += ctypes.string_at(a, n)
+                self.blob += b"\0" * ((-len(self.blob)) % 16)
+                self.words.append(0)
+            elif t in ("f", "d"):
+                self.words.append(struct.unpack("<q", struct.pack("<d", float(a)))[0])
+            else:
+                self.words.append(0 if a is None else int(a))
+        self._stream_slot(0 if args[-1] is None else int(args[-1]), base + 2 + len(args) - 1)
+        self.n_calls += 1
+
+    def event_record(self, event_handle: int, stream_handle: int):
+        base = len(self.words)
+        self.words += [-1, 2, int(event_handle), 0]
+        self._stream_slot(int(stream_handle), base + 3)
+
+    def stream_wait(self, stream_handle: int, event_handle: int):
+        base = len(self.words)
+        self.words += [-2, 2, 0, int(event_handle)]
+        self._stream_slot(int(stream_handle), base + 2)
+
+    def finish(self):
+        import numpy as np
+        self.blob_np = np.frombuffer(bytes(self.blob) or b"\0", dtype=np.uint8).copy()
+        w = np.asarray(self.words, dtype=np.int64)
+        for at, off in self.fix:
+            w[at] = self.blob_np.ctypes.data + off
+        self.words_np = w
+        self.main_np, self.side_np = np.asarray(self.main, dtype=np.int64), np.asarray(self.side, dtype=np.int64)
+        self.fail = np.zeros(1, np.int64)
+        self.words = None
+        return self
+
+    def replay(self, main_stream: int, side_stream: int | None):
+        w = self.words_np
+        w[self.main_np] = main_stream
+        if len(self.side_np):
+            if side_stream is None:
+                raise RuntimeError("CommandList.replay: the recorded pass uses a second stream")
+            w[self.side_np] = side_stream
+        rc = (_lib or load()).mopa_exec_replay(w.ctypes.data, len(w), self.fail.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"mopa_exec_replay failed with code {rc} at word {int(self.fail[0])}")
 
 
 _query_cache = {}

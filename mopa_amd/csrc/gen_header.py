@@ -22,6 +22,9 @@ SECTIONS = [
     ("sprun.hip", """The same convolutions, offset-major: run-major rulebook (the rules of one filter offset are one contiguous run of slots),
  * per-offset gather-GEMM with the weight slice resident in LDS, products into a partial slab, one ordered per-row sum -- for the
  * launches the matrix pipe bounds (same reference call sites as spconv.hip; SURVEY A.8 "gather-GEMM-scatter")."""),
+    ("exec2d.hip", """Command-list executor: a recorded sequence of this library's own entry points (plus event record / wait between two
+ * streams) replayed in ONE call -- the 2D branch's forward / backward pass (mopa/models/resnet34_unet.py:131-191 behind
+ * mopa/models/xmuda_arch.py:49-79) without one interpreter round trip per launch; recorder: mopa_amd/dense2d.py::Graph2D."""),
     ("scn_exec.hip", """Native executor of the 3D branch: the whole UNetSCN forward / backward (scn.Sequential of mopa/models/scn_unet.py:25-30
  * with scn.UNet unrolled + the linear heads of mopa/models/xmuda_arch.py:114-126) as ONE call each over host-side tables
  * (layer program, parameter pointers, rule tables, buffer addresses); table layouts: scn_exec.hip / mopa_amd/sparse3d.py."""),
@@ -83,7 +86,53 @@ def protos(path):
     return out
 
 
+def gen_exec_table():
+    """csrc/exec_table.inc: one `case` per launching entry point (returns int, last parameter `void* stream`) for the command-list
+    executor of exec2d.hip -- arguments arrive as 64-bit slots (integers and pointers as int64, float / double as the bit pattern of
+    a double) and are cast back to the prototype's types.  Ids are positions in the sorted name list (mopa_exec_fn_id)."""
+    protos_all = []
+    for fname, _ in SECTIONS:
+        if fname == "exec2d.hip":
+            continue
+        protos_all += protos(os.path.join(HERE, fname))
+    fns = []
+    for sig in protos_all:
+        m = re.match(r"(\w[\w\s\*]*?)\s*(mopa_\w+)\((.*)\);$", sig)
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3)
+        if ret != "int" or not params.rstrip().endswith("void* stream"):
+            continue
+        types = []
+        for prm in params.split(","):
+            prm = re.sub(r"/\*.*?\*/", "", prm).strip()
+            t = prm[:prm.rindex(" ")].strip() if " " in prm else prm
+            if "*" in prm:
+                t = prm[:prm.rindex("*") + 1].strip()
+            types.append(t)
+        fns.append((name, types))
+    fns.sort()
+    lines = ["// GENERATED by gen_header.py::gen_exec_table from the MOPA_API prototypes; do not edit by hand.",
+             "static const char* const EXEC_NAMES[] = {"]
+    lines += [f'  "{n}",' for n, _ in fns]
+    lines += ["};", f"static const int EXEC_N = {len(fns)};",
+              "static int exec_dispatch(int id, const int64_t* a, int nargs) {", "  switch (id) {"]
+    for i, (n, types) in enumerate(fns):
+        args = []
+        for j, t in enumerate(types):
+            if "*" in t:
+                args.append(f"({t})(uintptr_t)a[{j}]")
+            elif t in ("float", "double"):
+                args.append(f"({t})slot_f(a[{j}])")
+            else:
+                args.append(f"({t})a[{j}]")
+        lines.append(f"    case {i}: return nargs == {len(types)} ? {n}({', '.join(args)}) : MOPA_ERR_ARG;")
+    lines += ["    default: return MOPA_ERR_ARG;", "  }", "}", ""]
+    with open(os.path.join(HERE, "exec_table.inc"), "w") as f:
+        f.write("\n".join(lines))
+    print("wrote exec_table.inc", len(fns), "entry points")
+
+
 def main():
+    gen_exec_table()
     parts = [HEAD]
     for fname, doc in SECTIONS:
         parts.append(f"\n/* ---- {fname}\n * {doc}\n */")

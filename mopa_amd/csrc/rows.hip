@@ -928,3 +928,32 @@ MOPA_API int mopa_output_layer_heads_bwd(const float* dfeats, const float* dl1, 
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Three byte movers so that a recorded pass (exec2d.hip) holds no launch that is not this library's own: zero a channel slice,
+// copy a channel slice, add a constant to up to 64 int64 scalars (BatchNorm2d.num_batches_tracked of every layer that ran).
+MOPA_API int mopa_zero_rows(float* x, int32_t ld, int64_t rows, int32_t C, void* stream) {
+  if (!x || rows <= 0 || C <= 0 || ld < C) return MOPA_ERR_ARG;
+  if (hipMemset2DAsync(x, (size_t)ld * 4, 0, (size_t)C * 4, (size_t)rows, (hipStream_t)stream) != hipSuccess) return MOPA_ERR_LAUNCH;
+  return MOPA_OK;
+}
+MOPA_API int mopa_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int64_t rows, int32_t C, void* stream) {
+  if (!src || !dst || rows <= 0 || C <= 0 || ld_src < C || ld_dst < C) return MOPA_ERR_ARG;
+  if (hipMemcpy2DAsync(dst, (size_t)ld_dst * 4, src, (size_t)ld_src * 4, (size_t)C * 4, (size_t)rows, hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+    return MOPA_ERR_LAUNCH;
+  return MOPA_OK;
+}
+struct I64Ptrs { int64_t* p[64]; };
+__global__ void k_add_i64_many(const I64Ptrs d, int n, int64_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) *d.p[i] += v;
+}
+MOPA_API int mopa_add_i64_many(const int64_t* ptrs_host, int32_t n, int64_t value, void* stream) {
+  if (!ptrs_host || n <= 0 || n > 64) return MOPA_ERR_ARG;
+  I64Ptrs d;
+  for (int i = 0; i < 64; ++i) d.p[i] = reinterpret_cast<int64_t*>(ptrs_host[i < n ? i : 0]);
+  k_add_i64_many<<<1, 64, 0, (hipStream_t)stream>>>(d, n, value);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import syncbn
+from . import _lib, syncbn
 from ._lib import GradSink, call, ptr, query, stream, workspace
 from .sparse3d import View
 
@@ -370,6 +370,7 @@ def wgrad_stream(dev):
 
 
 _on_events = {}   # side stream -> the event that orders it behind the consumer stream (re-recorded at every hand-over)
+_REC_EVENTS = (0, 0)   # while a command list is recorded: raw handles of its (fork, join) events (Graph2D._record)
 
 
 class _on:
@@ -385,6 +386,9 @@ class _on:
     def __enter__(self):
         if self.side is None:
             return
+        if _lib.RECORDER is not None:   # a pass is being recorded as a command list: the hand-over is a command too
+            _lib.RECORDER.event_record(_REC_EVENTS[0], stream())
+            _lib.RECORDER.stream_wait(self.side.cuda_stream, _REC_EVENTS[0])
         ev = _on_events.get(self.side)
         if ev is None:
             ev = _on_events[self.side] = torch.cuda.Event()
@@ -406,6 +410,9 @@ def join_wgrad_stream(dev):
     """Order the current stream behind the weight-gradient stream (end of a backward pass)."""
     ws = wgrad_stream(dev)
     if ws is not None:
+        if _lib.RECORDER is not None:
+            _lib.RECORDER.event_record(_REC_EVENTS[1], ws.cuda_stream)
+            _lib.RECORDER.stream_wait(stream(), _REC_EVENTS[1])
         torch.cuda.current_stream().wait_stream(ws)
 
 
@@ -483,7 +490,7 @@ class ConvOp:
             return
         assert s == 2
         if not acc_dx:
-            dx.dense().zero_() if dx.C != dx.ld else dx.t.zero_()
+            call("mopa_zero_rows", dx.p, dx.ld, dx.rows, dx.C, stream())   # (not a torch kernel: the pass may be a recorded command list)
         for ph in range(2):
             for pw in range(2):
                 khs = [kh for kh in range(k) if (ph + p - kh) % 2 == 0]
@@ -738,7 +745,10 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
             up_raw = convT(tname + "0", x, out=right)
             ylazy = bn(tname + "1", up_raw, defer=True)
             if lvl == 0 and lazy_stem:   # both halves are raw: [stem conv | up-convolution], one statistics tensor over the 128 channels
-                joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), torch.cat([skip0.bn[0], ylazy.bn[0]], dim=2), G)
+                st2 = torch.empty(G, 4, 2 * cj, dtype=torch.float32, device=dev)   # [stem | up-convolution] statistics side by side
+                for half, src in enumerate((skip0.bn[0], ylazy.bn[0])):
+                    call("mopa_copy_rows", ptr(src), cj, ptr(st2, half * cj), 2 * cj, G * 4, cj, stream())
+                joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), st2, G)
             else:
                 joined = LazyImg(Img(J[lvl], up_raw.B, up_raw.H, up_raw.W, 0, 2 * cj), ylazy.bn[0], G, c0=cj)
         else:
@@ -750,8 +760,10 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
             x = conv(pre + "dec_conv_stage1", joined, 3, 1, 1, bias=True)
         else:
             x = bn(cname[:-1] + "1", conv(cname, joined, 3, 1, 1, bias=True))
-    if nbt:
-        torch._foreach_add_(nbt, G)
+    for i in range(0, len(nbt), 64):   # one launch per 64 counters (43 BatchNorm layers: one)
+        tab = np.zeros(64, np.int64)
+        tab[:len(nbt[i:i + 64])] = [t.data_ptr() for t in nbt[i:i + 64]]
+        call("mopa_add_i64_many", tab.ctypes.data, len(nbt[i:i + 64]), G, stream())
     return x, tape, J   # x: (B, Hp, Wp, 64); the crop to (H, W) is implicit in the heads' indexing (:185-186)
 
 
@@ -916,6 +928,11 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
 # whose graph launch is cheap.  Training mode with gradients enabled only; not under synchronised BatchNorm (its collectives are
 # issued from Python between the kernels).
 GRAPH_2D = os.environ.get("MOPA_GRAPH_2D", "0") == "1"
+# Round 5: the same recording replayed as a COMMAND LIST instead of a hipGraph -- mopa_exec_replay (csrc/exec2d.hip) walks the
+# recorded entry points in one native call: the HIP runtime's launch cost per kernel (~3.5 us) instead of the interpreter's
+# (~16 us), no graph launch.  The capture is still made (it pins every address of the pass in a private pool and applies the
+# allocator's cross-stream rules), its hipGraph is simply never launched.  Default ON; MOPA_NATIVE_2D=0 = the Python walk.
+NATIVE_2D = os.environ.get("MOPA_NATIVE_2D", "1") != "0"   # (MOPA_GRAPH_2D=1 takes precedence: hipGraph replay)
 GRAPH_2D_MAX_KEYS = 4        # distinct (shape, mode, stream) keys recorded per network; further ones run eagerly
 GRAPH_STATS = {"recorded": 0, "forward_replays": 0, "backward_replays": 0, "eager_busy": 0, "eager_backward": 0, "dropped": 0}
 
@@ -941,17 +958,40 @@ class Graph2D:
 
     # -- recording
     def _record(self, fn, pool):
-        global _CAPTURE
+        global _CAPTURE, _REC_EVENTS
         g = torch.cuda.CUDAGraph()
         main = stream()
         _CAPTURE = main
+        rec = None
+        if NATIVE_2D and not GRAPH_2D:
+            if getattr(self, "events", None) is None:   # the command list's fork / join events between the two streams (created and
+                self.events = (torch.cuda.Event(), torch.cuda.Event())   # recorded once OUTSIDE the capture: that makes the handles)
+                for e in self.events:
+                    e.record()
+            rec = _lib.CommandList(self.side.cuda_stream)
+            _REC_EVENTS = tuple(e.cuda_event for e in self.events)
         try:
             # thread-local error mode: other threads (RCCL's watchdog polls events) must not invalidate the recording
             with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode="thread_local"):
-                out = fn()
+                _lib.RECORDER = rec
+                try:
+                    out = fn()
+                finally:
+                    _lib.RECORDER = None
         finally:
             _CAPTURE = None
-        return g, out
+        if rec is not None:
+            rec.finish()
+            GRAPH_STATS["native_lists"] = GRAPH_STATS.get("native_lists", 0) + 1
+        return (g, rec), out
+
+    def _replay(self, rec_pair):
+        g, rec = rec_pair
+        if rec is None:
+            g.replay()
+            return
+        ws = wgrad_stream(self.dev)
+        rec.replay(stream(), None if ws is None else ws.cuda_stream)
 
     def record_forward(self, P, flat, training, drop_p):
         self.side = torch.cuda.Stream(device=self.dev)   # the recording stream (replays run on the caller's)
@@ -977,7 +1017,7 @@ class Graph2D:
                 for g, sd in enumerate(seed):   # (fill kernels: a host -> device copy here would wait for the stream)
                     self.seed_t[g:g + 1].fill_(sd)
         _refresh_stale_forms(stream())   # every cached weight form of this stream that an update made stale: one launch
-        self.fwd.replay()
+        self._replay(self.fwd)
         self.generation += 1
         GRAPH_STATS["forward_replays"] += 1
 
@@ -1006,12 +1046,12 @@ class Graph2D:
                    #  the outer pass's sink reports the gradients once the replay is enqueued: ADVICE r4)
                 self.bwd, _ = self._record(
                     lambda: _backbone_backward(P, GradSink(P, order, defer_hooks=True), self.tape, self.J, self.feat, self.dfeat, self.training, 0,
-                                               self.seed_t, False, self.H, self.W, self.groups), self.fwd.pool())
+                                               self.seed_t, False, self.H, self.W, self.groups), self.fwd[0].pool())
             except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
                 self.failed = True
                 return False
             self.grad_ptrs = gp
-        self.bwd.replay()
+        self._replay(self.bwd)
         GRAPH_STATS["backward_replays"] += 1
         return True
 
@@ -1019,13 +1059,13 @@ class Graph2D:
 def _graph_for(spec, imgc, training, drop_p, flat, want_dimg):
     """-> (the Graph2D record of this pass's key or None, replay it?)."""
     holder = getattr(spec, "graphs", None)
-    if (not GRAPH_2D or holder is None or not training or not getattr(spec, "grad_enabled", False) or syncbn.active()
+    if (not (GRAPH_2D or NATIVE_2D) or holder is None or not training or not getattr(spec, "grad_enabled", False) or syncbn.active()
             or DEBUG is not None or want_dimg):
         return None, False
     graphs = holder.__dict__.setdefault("graphs2d", {})
     B, _, H, W = imgc.shape
     groups = getattr(spec, "groups", 1)
-    key = (B, H, W, groups, float(drop_p), spec.num_classes, stream(), F4_ROLES, WGRAD_STREAM)
+    key = (B, H, W, groups, float(drop_p), spec.num_classes, stream(), F4_ROLES, WGRAD_STREAM, NATIVE_2D and not GRAPH_2D)
     g = graphs.get(key)
     if g is None:
         if len(graphs) >= GRAPH_2D_MAX_KEYS:

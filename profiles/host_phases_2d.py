@@ -12,6 +12,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 H, W = 302, 480
 model, _ = build_model_2d(default_cfg(5, True))
 model = model.cuda().train()
+from mopa_amd.optim import FlatAdam
+opt = FlatAdam(model.parameters(), lr=1e-3)   # gradients attached to the flat buffer: what the replayed backward needs (as in training)
 rng = np.random.Generator(np.random.PCG64(0))
 img = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32)).cuda()
 idx = [np.stack([rng.integers(0, H, 34880), rng.integers(0, W, 34880)], 1) for _ in range(B)]
@@ -33,6 +35,7 @@ def phase(name, fn):
 
 
 def step():
+    opt.zero_grad()
     out = phase("fwd", lambda: model({"img": img, "point_pix_2d": pix, "img_indices": None}))
     loss = phase("loss", lambda: out["seg_logit"].square().mean() + out["seg_logit2"].square().mean())
     phase("bwd", loss.backward)
@@ -45,6 +48,8 @@ for k in ENQ:
 N = 10
 for _ in range(N):
     step()
+from mopa_amd import dense2d
+print(f"B={B}: 2D executor: {'hipGraph replay' if dense2d.GRAPH_2D else 'native command list' if dense2d.NATIVE_2D else 'python walk'}; {dense2d.GRAPH_STATS}")
 print(f"B={B}: phase  host enqueue ms   enqueue+device ms")
 for k in ENQ:
     print(f"{k:6s} {1e3 * ENQ[k] / N:10.2f} {1e3 * TOT[k] / N:14.2f}")

@@ -569,6 +569,17 @@ def test_net2dseg_well_conditioned_fixture_bounds_every_gradient_at_one_percent(
             assert float(np.abs(got - v).max()) <= 1e-2 * scale, k
 
 
+def _replay_mode(monkeypatch, mode):
+    """mode: False / None = the Python walk, True / "graph" = hipGraph replay (MOPA_GRAPH_2D=1), "native" = the recorded command
+    list replayed by csrc/exec2d.hip (the default since round 5)."""
+    from mopa_amd import dense2d
+    monkeypatch.setattr(dense2d, "GRAPH_2D", mode in (True, "graph"))
+    monkeypatch.setattr(dense2d, "NATIVE_2D", mode == "native")
+
+
+REPLAY_MODES = ["graph", "native"]
+
+
 def _graph_training_run(monkeypatch, graph, steps=4, pattern="alternate", seed_t=7):
     """`steps` iterations of (source batch fwd+bwd, target batch fwd+bwd, FlatAdam step) on 2 x 64 x 96 images with dropout 0.4
     and a different number of points per half.  -> logits of every pass, the final state_dict, dense2d.GRAPH_STATS."""
@@ -576,7 +587,7 @@ def _graph_training_run(monkeypatch, graph, steps=4, pattern="alternate", seed_t
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_2d
     from mopa_amd.optim import FlatAdam
-    monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+    _replay_mode(monkeypatch, graph)
     for k in dense2d.GRAPH_STATS:
         dense2d.GRAPH_STATS[k] = 0
     src, trg = synth.make_batch(2, H=64, W=96), synth.make_batch(2, first=5, H=64, W=96)
@@ -605,13 +616,15 @@ def _graph_training_run(monkeypatch, graph, steps=4, pattern="alternate", seed_t
     return outs, {k: v.detach().clone() for k, v in m.state_dict().items()}, dict(dense2d.GRAPH_STATS)
 
 
-def test_graph_replay_of_the_backbone_is_bit_identical_to_the_eager_pass(monkeypatch):
+@pytest.mark.parametrize("mode", REPLAY_MODES)
+def test_graph_replay_of_the_backbone_is_bit_identical_to_the_eager_pass(monkeypatch, mode):
     """dense2d.Graph2D: from the second pass of a shape on, the backbone's forward and backward launches are replayed from HIP
     graphs.  Same kernels, same order, same addresses: logits of every pass, every parameter, BatchNorm running statistics and
     num_batches_tracked after four iterations (dropout on, a new seed per pass, weight forms refreshed after each update) must
     equal the eager run bit for bit."""
     eo, es, est = _graph_training_run(monkeypatch, False)
-    go, gs, gst = _graph_training_run(monkeypatch, True)
+    go, gs, gst = _graph_training_run(monkeypatch, mode)
+    assert gst.get("native_lists", 0) == (2 if mode == "native" else 0)   # forward + backward, each recorded once
     assert est["forward_replays"] == 0 and gst["recorded"] == 1
     assert gst["forward_replays"] == 7 and gst["backward_replays"] == 7 and gst["eager_backward"] == 0   # 8 passes, the first eager
     for i, (a, b) in enumerate(zip(eo, go)):
@@ -621,7 +634,8 @@ def test_graph_replay_of_the_backbone_is_bit_identical_to_the_eager_pass(monkeyp
         assert torch.equal(es[k], gs[k]), k
 
 
-def test_graph_replay_of_a_grouped_pass(monkeypatch):
+@pytest.mark.parametrize("mode", REPLAY_MODES)
+def test_graph_replay_of_a_grouped_pass(monkeypatch, mode):
     """bn_groups = 2 under graph replay: one dropout seed per group in device memory, BatchNorm per group inside the graphs."""
     from mopa_amd import dense2d, synth
     from mopa_amd.config import default_cfg
@@ -631,7 +645,7 @@ def test_graph_replay_of_a_grouped_pass(monkeypatch):
     batch = {"img": torch.cat([src["img"], trg["img"]]), "img_indices": list(src["img_indices"]) + list(trg["img_indices"]), "bn_groups": 2}
 
     def run(graph):
-        monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+        _replay_mode(monkeypatch, graph)
         for k in dense2d.GRAPH_STATS:
             dense2d.GRAPH_STATS[k] = 0
         torch.manual_seed(9)
@@ -648,7 +662,7 @@ def test_graph_replay_of_a_grouped_pass(monkeypatch):
         return outs, {k: v.detach().clone() for k, v in m.state_dict().items()}, dict(dense2d.GRAPH_STATS)
 
     eo, es, _ = run(False)
-    go, gs, st = run(True)
+    go, gs, st = run(mode)
     assert st["forward_replays"] == 3 and st["backward_replays"] == 3, st
     for a, b in zip(eo, go):
         assert torch.equal(a, b)
@@ -656,11 +670,12 @@ def test_graph_replay_of_a_grouped_pass(monkeypatch):
         assert torch.equal(es[k], gs[k]), k
 
 
-def test_graph_replay_steps_aside_when_its_activations_are_still_in_use(monkeypatch):
+@pytest.mark.parametrize("mode", REPLAY_MODES)
+def test_graph_replay_steps_aside_when_its_activations_are_still_in_use(monkeypatch, mode):
     """Two forwards, then one backward through both: the second forward must not replay over the activations the first one's
     backward still needs -- it runs eagerly; results equal the all-eager run."""
     eo, es, _ = _graph_training_run(monkeypatch, False, steps=3, pattern="both")
-    go, gs, gst = _graph_training_run(monkeypatch, True, steps=3, pattern="both")
+    go, gs, gst = _graph_training_run(monkeypatch, mode, steps=3, pattern="both")
     assert gst["eager_busy"] >= 2 and gst["forward_replays"] >= 2
     for a, b in zip(eo, go):
         assert torch.equal(a, b)
@@ -668,7 +683,8 @@ def test_graph_replay_steps_aside_when_its_activations_are_still_in_use(monkeypa
         assert torch.equal(es[k], gs[k]), k
 
 
-def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monkeypatch):
+@pytest.mark.parametrize("mode", REPLAY_MODES)
+def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monkeypatch, mode):
     """(1) torch.optim.SGD with set_to_none: no attached .grad buffers -> the forward replays, the backward walks the recorded tape
     eagerly and autograd receives the gradient tensors.  (2) Re-pointing .data of a parameter drops the graphs (they hold raw
     addresses): the next passes run eagerly and record again."""
@@ -678,7 +694,7 @@ def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monk
     b = synth.make_batch(2, H=64, W=96)
 
     def run(graph):
-        monkeypatch.setattr(dense2d, "GRAPH_2D", graph)
+        _replay_mode(monkeypatch, graph)
         for k in dense2d.GRAPH_STATS:
             dense2d.GRAPH_STATS[k] = 0
         torch.manual_seed(3)
@@ -698,7 +714,7 @@ def test_graph_replay_without_attached_gradients_and_after_moved_parameters(monk
         return outs, dict(dense2d.GRAPH_STATS)
 
     eo, _ = run(False)
-    go, st = run(True)
+    go, st = run(mode)
     assert st["forward_replays"] >= 2 and st["eager_backward"] >= 2 and st["backward_replays"] == 0 and st["dropped"] == 1, st
     for a, c in zip(eo, go):
         assert torch.equal(a, c)
