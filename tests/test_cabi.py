@@ -63,3 +63,53 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmopa_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_command_list_executor_table_and_packing():
+    """csrc/exec2d.hip without a GPU: every launching entry point of the binding table has an id in the generated dispatch table,
+    the recorder packs arguments as the executor unpacks them (floats as the bits of a double, host arrays copied into the list's
+    own blob, the stream argument kept as a patchable slot), and a malformed list is refused."""
+    import struct
+    import numpy as np
+    from mopa_amd import _lib
+    lib = _lib.load()
+    launching = [n for n, (res, args) in _lib.SIGNATURES.items() if res == "i" and args.endswith("p") and not n.startswith("mopa_exec_")]
+    protos = _protos()
+    launching = [n for n in launching if protos[n][0] == "int"]
+    ids = {n: lib.mopa_exec_fn_id(n.encode()) for n in launching}
+    launching_with_stream = [n for n in launching if n not in ("mopa_spconv_grouped_wants_packed", "mopa_spconv_run_wanted", "mopa_spconv_run_form",
+                                                               "mopa_vgi_zslots", "mopa_exec_fn_id", "mopa_exec_fn_count", "mopa_exec_replay")]
+    assert all(ids[n] >= 0 for n in launching_with_stream), [n for n in launching_with_stream if ids[n] < 0]
+    assert len(set(ids[n] for n in launching_with_stream)) == len(launching_with_stream)
+    assert lib.mopa_exec_fn_count() >= len(launching_with_stream)
+    assert lib.mopa_exec_fn_id(b"mopa_no_such_entry") == -1 and lib.mopa_exec_fn_id(b"mopa_spconv_run_wanted") == -1
+    # an empty list replays; a truncated one and an unknown id are refused with the failing word reported
+    fail = np.full(1, -1, np.int64)
+    assert lib.mopa_exec_replay(np.zeros(1, np.int64).ctypes.data, 0, fail.ctypes.data) == 0
+    bad = np.asarray([0, 5, 1, 2], np.int64)
+    assert lib.mopa_exec_replay(bad.ctypes.data, len(bad), fail.ctypes.data) == -1
+    unknown = np.asarray([10_000, 0], np.int64)
+    assert lib.mopa_exec_replay(unknown.ctypes.data, len(unknown), fail.ctypes.data) == -1 and fail[0] == 0
+    # packing
+    rec = _lib.CommandList(main_stream=111)
+    geom = (ctypes.c_int32 * 25)(*range(25))
+    rec.add("mopa_conv2d_igemm", (1000, 2000, None, 3000, ctypes.addressof(geom), 1, 111))
+    rec.add("mopa_dropout_rows", (10, 4, 20, 4, 7, 64, 0.4, 99, 222))          # second stream 222 = the side stream
+    rec.event_record(555, 111)
+    rec.stream_wait(222, 555)
+    rec.finish()
+    w = rec.words_np
+    assert w[0] == ids["mopa_conv2d_igemm"] and w[1] == 7 and list(w[2:6]) == [1000, 2000, 0, 3000] and w[7] == 1
+    got = (ctypes.c_int32 * 25).from_address(int(w[6]))
+    assert list(got) == list(range(25)) and int(w[6]) != ctypes.addressof(geom)      # the geometry was copied
+    d0 = 9
+    assert w[d0] == ids["mopa_dropout_rows"] and struct.unpack("<d", struct.pack("<q", int(w[d0 + 2 + 6])))[0] == 0.4
+    assert list(rec.main_np) == [8, d0 + 14] and list(rec.side_np) == [d0 + 10, d0 + 17]
+    assert list(w[d0 + 11:d0 + 15]) == [-1, 2, 555, 0] and list(w[d0 + 15:d0 + 19]) == [-2, 2, 0, 555]
+    with pytest.raises(RuntimeError):
+        _lib.CommandList(1).add("mopa_spconv_run_wanted", (27, 10, 64, 64, 0))      # not a launching entry point
+    rec3 = _lib.CommandList(1)
+    rec3.add("mopa_zero_rows", (10, 4, 5, 4, 1))
+    rec3.add("mopa_zero_rows", (10, 4, 5, 4, 2))
+    with pytest.raises(RuntimeError):
+        rec3.add("mopa_zero_rows", (10, 4, 5, 4, 3))                                  # a third stream
