@@ -1039,11 +1039,11 @@ def main():
         # files carry the commit they were taken at (profiles/collect_final.py), the line says so
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
         def _prof(name):   # committed profile summaries: this round's if present, else the previous round's
-            for rnd in ("r4", "r3"):
+            for rnd in ("r5", "r4", "r3"):
                 q = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
                 if os.path.exists(q):
                     return q
-            return os.path.join(ROOT, "profiles", f"r4_{name}")
+            return os.path.join(ROOT, "profiles", f"r5_{name}")
 
         fam_path = _prof("rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
@@ -1053,9 +1053,10 @@ def main():
         t3 = _prof(f"{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
         if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
-            fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk") if k in d3]
+            fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run") if k in d3]
+            extra = [d3[k] for k in ("k_run_reduce",) if k in d3]   # (its bytes belong to the offset-major launches, it is not a launch of its own)
             if fam:
-                sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
+                sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam + extra) / sum(f["launches"] for f in fam))
                 sp["traffic_source"] = ("%s at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                         "`bench.py --workload %s`, per launch)" % (os.path.relpath(t3, ROOT), d3.get("_commit", "?"), t3_key))
         if sp and joint:
@@ -1098,6 +1099,13 @@ def main():
             # (a committed figure is never `frac`: the file cannot know whether the kernels changed since -- ADVICE r3)
             sp["rocprof_source"] = os.path.relpath(fam_path, ROOT)
         roof = sp
+        hbm_step = (None, None)
+        tall = _prof(f"{wl_key}_hbm_traffic.json")
+        if os.path.exists(tall):
+            tdat = json.load(open(tall))
+            if tdat.get("_hbm_GB_per_step") is not None:
+                hbm_step = (tdat["_hbm_GB_per_step"], f"{os.path.relpath(tall, ROOT)} at commit {tdat.get('_commit', '?')} (rocprofv3 --pmc FETCH_SIZE / "
+                            f"WRITE_SIZE passes of `bench.py --workload {wl_key}`, {tdat.get('_steps')} steps, guide's gfx950 corrections)")
         k2 = timer2d.summary() if joint else None
         traffic = None
         tpath = _prof(f"{wl_key}_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -1187,6 +1195,9 @@ def main():
                 "numpy arrays (the reference's collate output), uploaded on a copy stream beside the compute; not part of `value`"),
             "roofline": roof,
             "roofline_sparse_conv": sp,
+            # fabric-side bytes of ONE step, all kernels (Infinity-Cache hits included): the committed PMC passes of this workload's
+            # command (profiles/make_final.sh -> traffic.py), never measured in this run -- the file and its commit say which build
+            "hbm_GB_per_step": hbm_step[0], "hbm_GB_per_step_source": hbm_step[1],
             "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),   # caching-allocator high-water mark of this rank
         }
         print(f"[bench] timed {args.steps} steps in {elapsed:.3f}s (host enqueue {t_enqueued:.3f}s)", file=sys.stderr, flush=True)

@@ -172,7 +172,7 @@ static int run_conv(const Table& t, const View& x, const float* wk, int ntw, con
     return mopa_spconv_fwd_run(t.runs, t.K, t.rows_out, x.p, x.ld, x.C, wk, out.C, w_flip, out.p, out.ld, t.one, ws, ws_bytes, st);
   if (ntw > 0)
     return mopa_spconv_fwd_grouped(t.gs, go, gi, gout, t.K, t.rows_out, x.p, x.ld, x.C, wk, out.C, w_flip | 2, out.p, out.ld, nullptr, 0, st);
-  if (t.gs && tiles < (t.K == 27 ? 1500 : 200)) {
+  if (t.gs && x.C > 4 && tiles < (t.K == 27 ? 1500 : 200)) {   // (<= 4 input channels: the stem kernel inside mopa_spconv_fwd)
     const size_t need = mopa_spconv_grouped_workspace_bytes(t.K, t.rows_out, out.C);
     return mopa_spconv_fwd_grouped(t.gs, go, gi, gout, t.K, t.rows_out, x.p, x.ld, x.C, wk, out.C, w_flip, out.p, out.ld, ws,
                                    ws_bytes >= need ? ws_bytes : 0, st);

@@ -210,12 +210,73 @@ static int dispatch_fwd(const int* nbr, int K, int A_out, const float* in, int l
 #undef FW
 }
 
+// ----------------------------------------------------------------------------------------------
+// The stem: SubmanifoldConvolution(in_channels -> m) on the raw voxel features (mopa/models/scn_unet.py:27: 1 -> 16).  With one to
+// four input channels there is no GEMM: out[i][c] = sum_o sum_ci in[nbr[o][i]][ci] * W[o][ci][c] is 27 scalar gathers per row.  One
+// thread per output row keeps the row's COUT accumulators in registers, the table entries are coalesced loads, the weights are
+// wave-uniform (scalar loads).  Same order as the table kernel (offsets ascending, input channels ascending): the same bits for
+// one input channel.  The MFMA kernels spend 50 us per launch here (16-wide K padding, 16 columns per wave) on 3 MB of work.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_spconv_stem(const int* __restrict__ nbr, int K, int A_out, const float* __restrict__ in, int ld_in,
+                                                      const float* __restrict__ W, int w_flip, float* __restrict__ out, int ld_out) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= A_out) return;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  for (int o0 = 0; o0 < K; o0 += 9) {   // nine table entries (and their gathers) in flight at a time
+    int idx[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) idx[u] = o0 + u < K ? nbr[(int64_t)(o0 + u) * A_out + row] : -1;
+    float x[9][CIN];
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) x[u][ci] = idx[u] >= 0 ? in[(int64_t)idx[u] * ld_in + ci] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      if (o0 + u >= K) break;
+      const float* __restrict__ wo = W + (int64_t)(w_flip ? K - 1 - (o0 + u) : o0 + u) * CIN * COUT;   // wave-uniform
+      if (idx[u] >= 0) {   // the arithmetic of the table kernel: the offset's product (rounded: an MFMA chain from zero), then one add
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+          float d = __fmul_rn(x[u][0], wo[c]);
+#pragma unroll
+          for (int ci = 1; ci < CIN; ++ci) d = fmaf(x[u][ci], wo[ci * COUT + c], d);
+          acc[c] = __fadd_rn(acc[c], d);
+        }
+      }
+    }
+  }
+  float* __restrict__ op = out + (int64_t)row * ld_out;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) *reinterpret_cast<float4*>(op + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+}
+
+template <int CIN>
+static int launch_stem(const int* nbr, int K, int A_out, const float* in, int ld_in, const float* W, int cout, int w_flip, float* out,
+                       int ld_out, hipStream_t st) {
+  const unsigned nb = (unsigned)cdiv64(A_out, 256);
+  if (cout == 16) k_spconv_stem<CIN, 16><<<nb, 256, 0, st>>>(nbr, K, A_out, in, ld_in, W, w_flip, out, ld_out);
+  else k_spconv_stem<CIN, 32><<<nb, 256, 0, st>>>(nbr, K, A_out, in, ld_in, W, w_flip, out, ld_out);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
 // out[A_out][cout] (row stride ld_out) = sum_o in[nbr[o][.]] @ W[w_flip ? K-1-o : o]
 MOPA_API int mopa_spconv_fwd(const int32_t* nbr, int32_t K, int32_t num_out, const float* in, int32_t ld_in,
                              int32_t cin, const float* weight, int32_t cout, int32_t w_flip, float* out,
                              int32_t ld_out, void* stream) {
   if (K <= 0 || K > 27 || num_out <= 0 || cin <= 0 || cin > 192 || cout <= 0 || ld_in < cin || ld_out < cout) return MOPA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  static const int stem_on = getenv("MOPA_SPCONV_STEM") ? atoi(getenv("MOPA_SPCONV_STEM")) : 1;   // A/B switch
+  if (stem_on && cin <= 4 && (cout == 16 || cout == 32) && ld_out % 4 == 0 && ((uintptr_t)out & 15) == 0) {   // the stem: scalar gathers
+    switch (cin) {
+      case 1: return launch_stem<1>(nbr, K, num_out, in, ld_in, weight, cout, w_flip, out, ld_out, st);
+      case 2: return launch_stem<2>(nbr, K, num_out, in, ld_in, weight, cout, w_flip, out, ld_out, st);
+      case 3: return launch_stem<3>(nbr, K, num_out, in, ld_in, weight, cout, w_flip, out, ld_out, st);
+      default: return launch_stem<4>(nbr, K, num_out, in, ld_in, weight, cout, w_flip, out, ld_out, st);
+    }
+  }
   const bool aligned = (cin % 16 == 0) && (cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
                        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight) % 16 == 0);
   int ntw, tmr;
@@ -1503,6 +1564,63 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
   }
 }
 
+// The stem's weight gradient (1-4 input channels): dW[o][ci][c] = sum_i in[nbr[o][i]][ci] * dout[i][c] -- a reduction over the rows,
+// no GEMM.  Block = 256 threads = 64 rows x 4 quarter-rows of COUT / 4 channels; every thread keeps dout's channels of its row
+// quarter in registers and walks the K offsets; per offset the 64 rows of a wave column are summed with DPP-free shuffles and the
+// block's result goes to a slab [chunk][K][cin][cout] (summed in order by k_reduce_slabs: deterministic).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_spconv_stem_wgrad(const int* __restrict__ nbr, int K, int A_out, int rows_per_block,
+                                                            const float* __restrict__ in, int ld_in, const float* __restrict__ dout, int ld_do,
+                                                            float* __restrict__ slabs) {
+  constexpr int CQ = COUT / 4;               // channels per thread
+  __shared__ float red[4][27][CIN][COUT];    // one partial per wave
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int qc = lane & 3, rl = lane >> 2;   // quarter of the channels, row slot (16 rows per wave and pass)
+  float acc[27][CIN][CQ];
+#pragma unroll
+  for (int o = 0; o < 27; ++o)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) acc[o][ci][c] = 0.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(A_out, r0 + rows_per_block);
+  for (int base = r0 + wv * 16; base < r1; base += 64) {
+    const int row = base + rl;
+    const bool ok = row < r1;
+    float dy[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) dy[c] = ok ? dout[(int64_t)row * ld_do + qc * CQ + c] : 0.f;
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+      const int idx = (ok && o < K) ? nbr[(int64_t)(o < K ? o : 0) * A_out + row] : -1;   // (no break: the loop must unroll -- acc[] lives in registers)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float x = idx >= 0 ? in[(int64_t)idx * ld_in + ci] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) acc[o][ci][c] = fmaf(x, dy[c], acc[o][ci][c]);
+      }
+    }
+  }
+  // sum the 16 row slots of the wave (lanes with equal qc): xor 4, 8, 16, 32
+#pragma unroll
+  for (int o = 0; o < 27; ++o)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        float v = acc[o][ci][c];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (rl == 0) red[wv][o][ci][qc * CQ + c] = v;
+      }
+  __syncthreads();
+  float* __restrict__ sl = slabs + (int64_t)blockIdx.x * K * CIN * COUT;
+  for (int e = tid; e < K * CIN * COUT; e += 256) {
+    const int o = e / (CIN * COUT), r = e - o * (CIN * COUT);
+    const int ci = r / COUT, c = r - ci * COUT;
+    sl[e] = ((red[0][o][ci][c] + red[1][o][ci][c]) + red[2][o][ci][c]) + red[3][o][ci][c];
+  }
+}
+
 static void wgrad_plan(int K, int A_out, int cin, int cout, int* mu, int* mblocks, int* nchunks, int* rows_per_chunk) {
   const int mt = (cin + 15) / 16;
   int m = 1;
@@ -1535,7 +1653,18 @@ static void wgrad_plan(int K, int A_out, int cin, int cout, int* mu, int* mblock
   *rows_per_chunk = rpc;
 }
 
+static inline bool stem_wgrad_shape(int K, int cin, int cout) { return K <= 27 && ((cin == 1 && (cout == 16 || cout == 32)) || (cin == 2 && cout == 16)); }   // (register budget: 27 x cin x cout / 4 accumulators per thread)
+static inline int stem_wgrad_blocks(int A_out, int* rows_per_block) {
+  int nb = (int)cdiv64(A_out, 256);
+  if (nb > 512) nb = 512;
+  *rows_per_block = (int)cdiv64(cdiv64(A_out, nb), 64) * 64;
+  return (int)cdiv64(A_out, *rows_per_block);
+}
 MOPA_API size_t mopa_spconv_wgrad_workspace_bytes(int32_t K, int32_t num_out, int32_t cin, int32_t cout) {
+  if (stem_wgrad_shape(K, cin, cout)) {
+    int rpb;
+    return align_up((size_t)stem_wgrad_blocks(num_out, &rpb) * K * cin * cout * sizeof(float), 256);
+  }
   int mu, mb, nc, rpc;
   wgrad_plan(K, num_out, cin, cout, &mu, &mb, &nc, &rpc);
   return align_up((size_t)nc * K * cin * cout * sizeof(float), 256);
@@ -1574,6 +1703,20 @@ MOPA_API int mopa_spconv_bwd_weight(const int32_t* nbr, int32_t K, int32_t num_o
   if (K <= 0 || num_out <= 0 || cin <= 0 || cout <= 0 || cout > 112 || ld_in < cin || ld_dout < cout) return MOPA_ERR_ARG;
   if (ws_bytes < mopa_spconv_wgrad_workspace_bytes(K, num_out, cin, cout)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  static const int stem_on = getenv("MOPA_SPCONV_STEM") ? atoi(getenv("MOPA_SPCONV_STEM")) : 1;   // A/B switch (must match the workspace query)
+  if (stem_wgrad_shape(K, cin, cout) && stem_on) {
+    int rpb;
+    const int nb = stem_wgrad_blocks(num_out, &rpb);
+    float* sl = (float*)ws;
+#define STEM_WG(CI, CO) k_spconv_stem_wgrad<CI, CO><<<nb, 256, 0, st>>>(nbr, K, num_out, rpb, in, ld_in, dout, ld_dout, sl)
+    if (cin == 1 && cout == 16) STEM_WG(1, 16); else if (cin == 1) STEM_WG(1, 32); else STEM_WG(2, 16);
+#undef STEM_WG
+    MOPA_CHECK_LAUNCH();
+    const int64_t n = (int64_t)K * cin * cout;
+    k_reduce_slabs<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(sl, nb, n, dweight, accumulate);
+    MOPA_CHECK_LAUNCH();
+    return MOPA_OK;
+  }
   int mu, mb, nc, rpc;
   wgrad_plan(K, num_out, cin, cout, &mu, &mb, &nc, &rpc);
   dim3 grid(K, nc, mb);

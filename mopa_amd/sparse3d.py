@@ -380,7 +380,7 @@ def spconv_launch(nbr: torch.Tensor, x: View, wk: torch.Tensor, out: View, w_fli
         gs, go, gi, gout = rb
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,
              int(w_flip) | 2, out.p, out.ld, 0, 0, stream())
-    elif rb is not None and (A_out + 63) // 64 < (1500 if K == 27 else 200):
+    elif rb is not None and cin > 4 and (A_out + 63) // 64 < (1500 if K == 27 else 200):   # (<= 4 input channels: the stem kernel inside mopa_spconv_fwd)
         gs, go, gi, gout = rb
         ws = _ws(query("mopa_spconv_grouped_workspace_bytes", K, A_out, cout), wk.device)
         call("mopa_spconv_fwd_grouped", ptr(gs), ptr(go), ptr(gi), ptr(gout), K, A_out, x.p, x.ld, cin, ptr(wk), cout,

@@ -7,7 +7,7 @@ Usage (repo root, after `gpurun -- bash profiles/make_final.sh`): python profile
 import collections, csv, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.abspath(__file__))
 F = os.path.join(R, "..", "gpurun_out", "final")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r4"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
 TITLE = {"3d": "Net3DSeg-only training step (bs 8, 1x MI355X) -- BASELINE configs[1]",
          "joint": "joint 2D+3D xMUDA step (bs 8+8, 1x MI355X) -- BASELINE configs[2]",
          "kitti": "A2D2->SemanticKITTI-shape joint step (bs 2+2, 120,000-pt scans, 10 classes, 1x MI355X) -- BASELINE configs[4] per GPU",
@@ -16,8 +16,11 @@ CMD = {"3d": "python bench.py --workload 3d --steps 50 --warmup 5", "joint": "py
        "kitti": "python bench.py --workload kitti --steps 10 --warmup 3",
        "mopa": "python bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline"}
 STEPS = {"3d": 57, "joint": 37, "kitti": 25, "mopa": 15}   # steps traced by make_final.sh (setup + warm-up + timed + host-input steps)
-FAMILY = {"sparse_conv": ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk"),
+FAMILY = {"sparse_conv": ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run"),
           "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv")}
+# kernels whose TIME belongs to a family's launches without being launches of their own: the ordered per-row sum behind every
+# offset-major convolution with a slab (csrc/sprun.hip: one k_spconv_run + one k_run_reduce = one convolution)
+FAMILY_EXTRA = {"sparse_conv": ("k_run_reduce",)}
 
 
 def git(*a):
@@ -54,7 +57,7 @@ for w in ("3d", "joint", "kitti", "mopa"):
     fam[w] = {}
     for name, kernels in FAMILY.items():
         calls = sum(agg[k][0] for k in kernels if k in agg)
-        ns = sum(agg[k][1] for k in kernels if k in agg)
+        ns = sum(agg[k][1] for k in kernels if k in agg) + sum(agg[k][1] for k in FAMILY_EXTRA.get(name, ()) if k in agg)
         if calls:
             fam[w][name] = {"calls": calls, "avg_us": round(ns / calls / 1e3, 3), "calls_per_step": round(calls / STEPS[w], 2)}
 json.dump(fam, open(os.path.join(R, f"{RND}_rocprof_family.json"), "w"), indent=1)

@@ -8,9 +8,16 @@ mode, m, num_planes, residual = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]),
 reps = int(os.environ.get("REPS", "1")); in_ch = int(os.environ.get("INCH", "1"))
 torch.manual_seed(0)
 c = T._cloud(int(os.environ.get("SEED", "7")), n=int(os.environ.get("NPTS", "6000")), size=120 if num_planes == 7 else 48)
-model = T._build_3d(num_planes, in_ch, block_reps=reps, residual=residual, m=m); model.train(True)
+model = T._build_3d(num_planes, in_ch, block_reps=reps, residual=residual, m=m); model.train(os.environ.get('EVAL', '0') != '1')
 rng = np.random.Generator(np.random.PCG64(5))
 feats = torch.from_numpy(rng.random((c.shape[0], in_ch), dtype=np.float32) + 0.5)
+if os.environ.get("EVAL", "0") == "1" and os.environ.get("EVALFIX", "1") == "1":   # as tests/test_gpu_3d.py::_check_net3dseg: running statistics := batch statistics
+    from oracle import scn3d
+    P0 = {k: v.detach().cpu().double().clone() for k, v in scn3d.fold_state_dict(model.state_dict()).items()}
+    old, scn3d.BN_MOMENTUM = scn3d.BN_MOMENTUM, 1.0
+    scn3d.net3dseg_forward(P0, scn3d.Geometry(c, num_planes), feats.double(), training=True, num_planes=num_planes, block_reps=reps, residual_blocks=residual, m=m)
+    scn3d.BN_MOMENTUM = old
+    model.load_state_dict({k: v.float() for k, v in P0.items()})
 f_dev = feats.cuda().requires_grad_(True)
 out = model({"x": [torch.from_numpy(c), f_dev]})
 gouts = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape), dtype=np.float32)) for k, v in out.items()}

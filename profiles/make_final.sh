@@ -22,7 +22,8 @@ for W in 3d joint kitti mopa; do
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$W -o run -- python3 bench.py $A --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
   N=37; [ $W = 3d ] && N=57; [ $W = kitti ] && N=25; [ $W = mopa ] && N=15   # joint: 2 setup + 5 warm-up + 20 timed + 2 + 8 steps of the host-inputs measurement (kitti: 2 + 3 + 10 + 2 + 8)
   python3 profiles/summarize.py $O/trace_$W/run_kernel_stats.csv $N > $O/stats_$W.md
-  python3 profiles/traffic.py $O/pmc_fetch_$W/run_counter_collection.csv $O/pmc_write_$W/run_counter_collection.csv > $O/traffic_$W.json
+  NETS=2; [ $W = 3d ] && NETS=1
+  python3 profiles/traffic.py $O/pmc_fetch_$W/run_counter_collection.csv $O/pmc_write_$W/run_counter_collection.csv $NETS > $O/traffic_$W.json
   cp $O/trace_$W/run_kernel_stats.csv $O/stats_$W.csv
 done
 tail -c 600 $O/bench_3d.json; echo; tail -c 300 $O/bench_joint.json; echo; head -12 $O/stats_3d.md
