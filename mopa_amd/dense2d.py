@@ -972,12 +972,25 @@ class Graph2D:
             _REC_EVENTS = tuple(e.cuda_event for e in self.events)
         try:
             # thread-local error mode: other threads (RCCL's watchdog polls events) must not invalidate the recording
-            with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode="thread_local"):
-                _lib.RECORDER = rec
-                try:
+            if rec is None:
+                with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode="thread_local"):
                     out = fn()
-                finally:
-                    _lib.RECORDER = None
+            else:
+                # the same capture WITHOUT torch.cuda.graph's gc.collect() + empty_cache(): emptying the caching allocator here hands
+                # the eager pool's 20 GB back to the driver, and the next eager pass (a bracketed bench step, a second forward while
+                # the recorded activations are busy) hipMallocs them again -- 95 segments in the middle of a training loop; on a box
+                # with slow allocations that was 280 instead of 355 scans/s for the whole first process
+                cur = torch.cuda.current_stream()
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    g.capture_begin(pool=pool, capture_error_mode="thread_local")
+                    _lib.RECORDER = rec
+                    try:
+                        out = fn()
+                    finally:
+                        _lib.RECORDER = None
+                        g.capture_end()
+                cur.wait_stream(self.side)
         finally:
             _CAPTURE = None
         if rec is not None:
