@@ -1251,8 +1251,7 @@ MOPA_API int mopa_spconv_fwd_grouped(const int32_t* grp_start, const int32_t* gr
       }
 #undef PP
     }
-    static const int k8_t1_min = getenv("MOPA_SPCONV_K8_T1_MIN_TILES") ? atoi(getenv("MOPA_SPCONV_K8_T1_MIN_TILES")) : 800;   // tuning only
-    if (K != 27 && cdiv64(num_out, 64) > k8_t1_min) {   // long down/up tables: 17-28 us vs 20-34 on the dense-table kernel
+    if (K != 27 && cdiv64(num_out, 64) > 800) {   // long down/up tables: 17-28 us vs 20-34 on the dense-table kernel
 #define T1(N, KU) return launch_t4<N, KU, 2, 1>(grp_start, grp_o, grp_in, grp_out, K, num_out, in, ld_in, cin, weight, cout, w_flip, out, ld_out, st)
       if (pntw == 1) { if (nkc == 1) T1(1, 1); if (nkc == 2) T1(1, 2); if (nkc == 3) T1(1, 3); T1(1, 4); }
       if (pntw == 2) { if (nkc == 1) T1(2, 1); if (nkc == 2) T1(2, 2); if (nkc == 3) T1(2, 3); T1(2, 4); }
@@ -1635,12 +1634,8 @@ static void wgrad_plan(int K, int A_out, int cin, int cout, int* mu, int* mblock
   // waves -- every wave pays a table scan, a ring fill and a K*Cin*Cout-element slab, so the 8-offset tables (one rule per 8
   // scanned entries) were 1.4-2x slower at the old 16384 than at 512, the 27-offset tables 5-15 % -- while the simple kernel of
   // the unaligned shapes hides its dependent ballot / gather chain by wave count only (16384).
-  static const int force27 = getenv("MOPA_WGRAD_WAVES") ? atoi(getenv("MOPA_WGRAD_WAVES")) : 0;      // tuning only
-  static const int force8 = getenv("MOPA_WGRAD_WAVES_K8") ? atoi(getenv("MOPA_WGRAD_WAVES_K8")) : 0;
   const bool pipelined = cin % 16 == 0 && cout % 16 == 0;
-  int waves = !pipelined ? 16384 : K != 27 ? 512 : cout <= 16 ? 4096 : A_out < 4096 ? 512 : 2048;
-  if (K == 27 && force27) waves = force27;
-  if (K != 27 && force8) waves = force8;
+  const int waves = !pipelined ? 16384 : K != 27 ? 512 : cout <= 16 ? 4096 : A_out < 4096 ? 512 : 2048;
   int64_t nc = cdiv64(waves, per);
   const int64_t max_rows = cdiv64(A_out, 256);
   const int64_t max_slab = (32ll << 20) / ((int64_t)K * cin * cout * 4) + 1;

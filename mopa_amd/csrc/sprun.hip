@@ -377,9 +377,7 @@ static int launch_run(const int* hdr, const int* run_in, const int* run_out, int
   if (ncu <= 0) return MOPA_ERR_LAUNCH;
   const size_t lds = (size_t)cin * NT * 16 * sizeof(float);
   int per_cu = (int)((160 * 1024) / lds);
-  static const int cap_force = getenv("MOPA_SPCONV_RUN_PER_CU") ? atoi(getenv("MOPA_SPCONV_RUN_PER_CU")) : 0;   // tuning only
-  const int cap = cap_force ? cap_force : 4;
-  if (per_cu > cap) per_cu = cap;
+  if (per_cu > 4) per_cu = 4;   // (2, 3, 6 per CU and 64-rule row sets per wave measured within 3 %: profiles/r5_spconv_run.md)
   if (per_cu < 1) per_cu = 1;
   const int64_t items_bound = slots_bound / (64 * RG);
   int64_t gx = (int64_t)ncu * per_cu;
@@ -429,12 +427,11 @@ MOPA_API int mopa_spconv_fwd_run(const int32_t* runs, int32_t K, int32_t num_out
   }
   // items of 128 slots (two row groups per wave) unless the table is so short that they would leave CUs idle: the rule count is
   // not known on the host (no synchronisation), ~9 rules per row on the deep 27-offset tables, rows_in <= 8 rows_out otherwise
-  static const int rg_force = getenv("MOPA_SPCONV_RUN_RG") ? atoi(getenv("MOPA_SPCONV_RUN_RG")) : 0;   // tuning only
   const int64_t rules_est = K == 27 ? (int64_t)9 * num_out : one_rule_per_row ? num_out : (int64_t)5 * num_out / 2;
-  const int rg = rg_force ? rg_force : rules_est / 128 < 400 ? 1 : 2;
+  const int rg = rules_est / 128 < 400 ? 1 : 2;
   int rc;
 #define RUN_L(N, G) rc = launch_run<N, G>(hdr, run_in, run_out, K, cap, in, ld_in, cin, weight_run, cout, w_flip & 1, dst, ld_dst, one_rule_per_row != 0, st)
-#define RUN_N(N) if (rg == 1) RUN_L(N, 1); else if (rg == 4 && N <= 5) RUN_L(N, 4); else RUN_L(N, 2);
+#define RUN_N(N) if (rg == 1) RUN_L(N, 1); else RUN_L(N, 2);
   switch (nt) {
     case 1: RUN_N(1); break;
     case 2: RUN_N(2); break;

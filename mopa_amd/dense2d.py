@@ -95,7 +95,7 @@ class _CaptureMiss(RuntimeError):
 _CAPTURE = None   # raw handle of the stream that will replay the graph being recorded (None: not recording)
 _relayout_cache = {}
 _refreshed = {}   # stream -> WEIGHTS_EPOCH of the last batched refresh
-BATCHED_REFRESH = os.environ.get("MOPA_BATCHED_REFRESH", "1") != "0"   # A/B switch: one launch for all stale weight forms
+BATCHED_REFRESH = True   # one launch for all stale weight forms (tests flip the attribute to compare with the one-form kernels)
 
 
 def _refresh_stale_forms(st):
@@ -191,10 +191,11 @@ def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: int = 0):
 
 
 # F(4x4) layers whose 36 GEMMs and output transform run as ONE kernel (mopa_wino4_gemm_output: M is never materialised): needs
-# 64-aligned input channels and at least two full rounds of its 64-tile x 32-channel blocks (2 per CU): the 304x480 layers and
+# 64-aligned input channels and ~1.4 rounds of its 64-tile x 32-channel blocks (700; round 4 said 1024 from the one bench shape,
+# profiles/r5_algo_table.md has 4 / 8 / 16 images at both resolutions: 750-block grids win by 10-20 %): the 304x480 layers and
 # the 128-output-channel layers at 152x240 (measured in csrc/wino2d.hip; -0.55 ms per 8-image forward + backward).  Smaller
 # grids stay on the batched GEMM + output transform.  MOPA_WINO4_FUSED=0 switches it off.
-WINO4_FUSED_MIN_BLOCKS = int(os.environ.get("MOPA_WINO4_FUSED_MIN_BLOCKS", "1024")) if os.environ.get("MOPA_WINO4_FUSED", "1") != "0" else 1 << 62
+WINO4_FUSED_MIN_BLOCKS = int(os.environ.get("MOPA_WINO4_FUSED_MIN_BLOCKS", "700")) if os.environ.get("MOPA_WINO4_FUSED", "1") != "0" else 1 << 62
 
 
 def wino4_fused(cin, cout, B, H, W):
@@ -206,9 +207,10 @@ def wino4_fused(cin, cout, B, H, W):
 
 
 # F(4x4) layers that run as ONE kernel (mopa_wino4_conv: input transform, 36 GEMMs and output transform; neither V nor M reaches
-# HBM): 64-aligned channels on both sides and at least MOPA_WINO4_DIRECT_MIN_TILES tiles.  MOPA_WINO4_DIRECT=0 switches it off.
+# HBM): 64-aligned channels on both sides and at least MOPA_WINO4_DIRECT_MIN_TILES tiles (twice that for 128 output channels).
+# MOPA_WINO4_DIRECT=0 switches it off.
 WINO4_DIRECT = os.environ.get("MOPA_WINO4_DIRECT", "1") != "0"
-WINO4_DIRECT_MIN_TILES = int(os.environ.get("MOPA_WINO4_DIRECT_MIN_TILES", "16384"))
+WINO4_DIRECT_MIN_TILES = int(os.environ.get("MOPA_WINO4_DIRECT_MIN_TILES", "4096"))   # (round 4: 16384, tuned at 16 x 302 x 480 only)
 WINO4_DIRECT_MAX_CIN = int(os.environ.get("MOPA_WINO4_DIRECT_MAX_CIN", "128"))
 # Roles: "dgrad" (backward-data), "fwd_eval" (a forward pass that keeps nothing), "fwd" (the forward pass of a training step: it wants
 # V again for the weight gradient, the kernel stores it as a by-product and only a READ of V is saved -- measured neutral in the joint
@@ -218,8 +220,11 @@ WINO4_DIRECT_ROLES = tuple(r for r in os.environ.get("MOPA_WINO4_DIRECT_ROLES", 
 
 def wino4_direct(cin, cout, B, H, W, role="fwd"):
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    return (WINO4_DIRECT and role in WINO4_DIRECT_ROLES and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN
-            and T >= WINO4_DIRECT_MIN_TILES)
+    # tiles from which the one-kernel form wins (profiles/r5_algo_table.md: 4 / 8 / 16 images at 225 x 400 and 302 x 480): 64 output
+    # channels -- the input transform is done once -- from ~4,000 tiles, 128 output channels from ~8,000
+    # (more than 128 output channels repeat the input transform per 64 of them: 128 -> 256 loses to the fused form by 10 %)
+    return (WINO4_DIRECT and role in WINO4_DIRECT_ROLES and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN and cout <= 128
+            and T >= (WINO4_DIRECT_MIN_TILES if cout <= 64 else 2 * WINO4_DIRECT_MIN_TILES))
 
 
 def wino4_layout(cin, cout, B, H, W, role="fwd"):

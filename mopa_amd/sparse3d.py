@@ -24,7 +24,7 @@ from ._lib import GradSink, call, ptr, query, stream, workspace
 BN_EPS = 1e-4       # SCN BatchNormalization eps (Appendix A.6)
 BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
 LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
-BATCHED_REPACK = os.environ.get("MOPA_BATCHED_REPACK", "1") != "0"   # A/B switch: one launch for all stale weight forms
+BATCHED_REPACK = True   # one launch for all stale weight forms (the single-form path stays for never-built forms; tests flip the attribute)
 RUN_PATH = os.environ.get("MOPA_SPCONV_RUN", "1") != "0"             # the offset-major convolution (csrc/sprun.hip); 0 = round-4 kernels only
 RUN_MAX_ROWS = int(os.environ.get("MOPA_SPCONV_RUN_TABLE_ROWS", "220000"))   # 27-offset tables above this get no run-major rulebook
 

@@ -109,9 +109,8 @@ class Timeline:
 class DualStream:
     def __init__(self, device, order_2d_first: bool = False):
         self.device = torch.device(device)
-        # MOPA_SIDE_PRIORITY=-1: a high-priority HIP stream for the 3D branch / the geometry builds (tuning switch)
-        prio = int(os.environ.get("MOPA_SIDE_PRIORITY", "0"))
-        self.side = torch.cuda.Stream(device=self.device, priority=prio)
+        # (a high-priority side stream was measured in round 3: 325-329 scans/s either way -- the switch is gone)
+        self.side = torch.cuda.Stream(device=self.device)
         self.order_2d_first = order_2d_first
         self.timeline = None
 
