@@ -1026,7 +1026,7 @@ def main():
         sp = None
         if ks:
             sp = {"bound": "hbm", "achieved": round(ks["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_fwd / k_spconv_blk / k_spconv_run + k_run_reduce (sparse conv fwd + bwd-data)",
+                  "frac": round(ks["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_spconv_t4 / k_spconv_pipe / k_spconv_blk / k_spconv_run + k_run_reduce / k_spconv_stem (sparse conv fwd + bwd-data)",
                   "launches_per_step": ks["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(ks["avg_us"], 2),
                   "algorithmic_bytes_per_launch": round(ks["bytes_per_launch"]), "mfma_tflops": round(ks["tflops"], 2),
                   # the family is not HBM-bound on every level: from level 3 down (128 -> 64 channels and wider, few rows) a launch's
@@ -1053,7 +1053,7 @@ def main():
         t3 = _prof(f"{t3_key}_hbm_traffic.json")  # PMC passes of that workload's command (profiles/traffic.py)
         if sp and t3_key and os.path.exists(t3):
             d3 = json.load(open(t3))
-            fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run") if k in d3]
+            fam = [d3[k] for k in ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run", "k_spconv_stem") if k in d3]
             extra = [d3[k] for k in ("k_run_reduce",) if k in d3]   # (its bytes belong to the offset-major launches, it is not a launch of its own)
             if fam:
                 sp["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam + extra) / sum(f["launches"] for f in fam))
