@@ -1563,60 +1563,53 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
   }
 }
 
-// The stem's weight gradient (1-4 input channels): dW[o][ci][c] = sum_i in[nbr[o][i]][ci] * dout[i][c] -- a reduction over the rows,
-// no GEMM.  Block = 256 threads = 64 rows x 4 quarter-rows of COUT / 4 channels; every thread keeps dout's channels of its row
-// quarter in registers and walks the K offsets; per offset the 64 rows of a wave column are summed with DPP-free shuffles and the
-// block's result goes to a slab [chunk][K][cin][cout] (summed in order by k_reduce_slabs: deterministic).
-template <int CIN, int COUT>
+// The stem's weight gradient (one input channel): dW[o][c] = sum_i in[nbr[o][i]] * dout[i][c] -- a reduction over the rows, no GEMM.
+// Block = 4 waves over a row range; a lane owns one row per pass (its 16 output-gradient channels in registers, the table entries are
+// coalesced 256-byte loads) and wave w owns the offsets o = w, w + 4, ... (7 of 27): 7 x 16 accumulators per lane, summed over the 64
+// lanes once at the end; the block's result goes to a slab [block][K][cout] (summed in order by k_reduce_slabs: deterministic).
+template <int COUT>
 __global__ __launch_bounds__(256) void k_spconv_stem_wgrad(const int* __restrict__ nbr, int K, int A_out, int rows_per_block,
                                                             const float* __restrict__ in, int ld_in, const float* __restrict__ dout, int ld_do,
                                                             float* __restrict__ slabs) {
-  constexpr int CQ = COUT / 4;               // channels per thread
-  __shared__ float red[4][27][CIN][COUT];    // one partial per wave
+  constexpr int NO = 7;                      // offsets per wave (4 waves x 7 >= 27)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int qc = lane & 3, rl = lane >> 2;   // quarter of the channels, row slot (16 rows per wave and pass)
-  float acc[27][CIN][CQ];
+  float acc[NO][COUT];
 #pragma unroll
-  for (int o = 0; o < 27; ++o)
+  for (int j = 0; j < NO; ++j)
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-      for (int c = 0; c < CQ; ++c) acc[o][ci][c] = 0.f;
+    for (int c = 0; c < COUT; ++c) acc[j][c] = 0.f;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(A_out, r0 + rows_per_block);
-  for (int base = r0 + wv * 16; base < r1; base += 64) {
-    const int row = base + rl;
+  for (int base = r0; base < r1; base += 64) {
+    const int row = base + lane;
     const bool ok = row < r1;
-    float dy[CQ];
+    int idx[NO];
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) dy[c] = ok ? dout[(int64_t)row * ld_do + qc * CQ + c] : 0.f;
+    for (int j = 0; j < NO; ++j) {
+      const int o = wv + 4 * j;
+      idx[j] = (ok && o < K) ? nbr[(int64_t)(o < K ? o : 0) * A_out + row] : -1;
+    }
+    float dy[COUT];
 #pragma unroll
-    for (int o = 0; o < 27; ++o) {
-      const int idx = (ok && o < K) ? nbr[(int64_t)(o < K ? o : 0) * A_out + row] : -1;   // (no break: the loop must unroll -- acc[] lives in registers)
+    for (int c = 0; c < COUT; c += 4) {
+      const float4 v = ok ? *reinterpret_cast<const float4*>(dout + (int64_t)row * ld_do + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dy[c] = v.x; dy[c + 1] = v.y; dy[c + 2] = v.z; dy[c + 3] = v.w;
+    }
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) {
-        const float x = idx >= 0 ? in[(int64_t)idx * ld_in + ci] : 0.f;
+    for (int j = 0; j < NO; ++j) {
+      const float x = idx[j] >= 0 ? in[(int64_t)idx[j] * ld_in] : 0.f;
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) acc[o][ci][c] = fmaf(x, dy[c], acc[o][ci][c]);
-      }
+      for (int c = 0; c < COUT; ++c) acc[j][c] = fmaf(x, dy[c], acc[j][c]);
     }
   }
-  // sum the 16 row slots of the wave (lanes with equal qc): xor 4, 8, 16, 32
+  float* __restrict__ sl = slabs + (int64_t)blockIdx.x * K * COUT;
 #pragma unroll
-  for (int o = 0; o < 27; ++o)
+  for (int j = 0; j < NO; ++j) {
+    const int o = wv + 4 * j;
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-      for (int c = 0; c < CQ; ++c) {
-        float v = acc[o][ci][c];
-        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (rl == 0) red[wv][o][ci][qc * CQ + c] = v;
-      }
-  __syncthreads();
-  float* __restrict__ sl = slabs + (int64_t)blockIdx.x * K * CIN * COUT;
-  for (int e = tid; e < K * CIN * COUT; e += 256) {
-    const int o = e / (CIN * COUT), r = e - o * (CIN * COUT);
-    const int ci = r / COUT, c = r - ci * COUT;
-    sl[e] = ((red[0][o][ci][c] + red[1][o][ci][c]) + red[2][o][ci][c]) + red[3][o][ci][c];
+    for (int c = 0; c < COUT; ++c) {
+      const float v = wave_sum(acc[j][c]);
+      if (lane == 0 && o < K) sl[o * COUT + c] = v;
+    }
   }
 }
 
@@ -1648,7 +1641,7 @@ static void wgrad_plan(int K, int A_out, int cin, int cout, int* mu, int* mblock
   *rows_per_chunk = rpc;
 }
 
-static inline bool stem_wgrad_shape(int K, int cin, int cout) { return K <= 27 && ((cin == 1 && (cout == 16 || cout == 32)) || (cin == 2 && cout == 16)); }   // (register budget: 27 x cin x cout / 4 accumulators per thread)
+static inline bool stem_wgrad_shape(int K, int cin, int cout) { return K <= 27 && cin == 1 && cout == 16; }   // (7 x 16 accumulators per lane)
 static inline int stem_wgrad_blocks(int A_out, int* rows_per_block) {
   int nb = (int)cdiv64(A_out, 256);
   if (nb > 512) nb = 512;
@@ -1656,13 +1649,15 @@ static inline int stem_wgrad_blocks(int A_out, int* rows_per_block) {
   return (int)cdiv64(A_out, *rows_per_block);
 }
 MOPA_API size_t mopa_spconv_wgrad_workspace_bytes(int32_t K, int32_t num_out, int32_t cin, int32_t cout) {
-  if (stem_wgrad_shape(K, cin, cout)) {
+  size_t stem = 0;
+  if (stem_wgrad_shape(K, cin, cout)) {   // (the generic plan's size as well: an unaligned output gradient takes that path)
     int rpb;
-    return align_up((size_t)stem_wgrad_blocks(num_out, &rpb) * K * cin * cout * sizeof(float), 256);
+    stem = align_up((size_t)stem_wgrad_blocks(num_out, &rpb) * K * cin * cout * sizeof(float), 256);
   }
   int mu, mb, nc, rpc;
   wgrad_plan(K, num_out, cin, cout, &mu, &mb, &nc, &rpc);
-  return align_up((size_t)nc * K * cin * cout * sizeof(float), 256);
+  const size_t gen = align_up((size_t)nc * K * cin * cout * sizeof(float), 256);
+  return gen > stem ? gen : stem;
 }
 
 template <int MU>
@@ -1699,12 +1694,12 @@ MOPA_API int mopa_spconv_bwd_weight(const int32_t* nbr, int32_t K, int32_t num_o
   if (ws_bytes < mopa_spconv_wgrad_workspace_bytes(K, num_out, cin, cout)) return MOPA_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   static const int stem_on = getenv("MOPA_SPCONV_STEM") ? atoi(getenv("MOPA_SPCONV_STEM")) : 1;   // A/B switch (must match the workspace query)
-  if (stem_wgrad_shape(K, cin, cout) && stem_on) {
+  if (stem_wgrad_shape(K, cin, cout) && stem_on && ld_dout % 4 == 0 && ((uintptr_t)dout & 15) == 0) {
     int rpb;
     const int nb = stem_wgrad_blocks(num_out, &rpb);
     float* sl = (float*)ws;
-#define STEM_WG(CI, CO) k_spconv_stem_wgrad<CI, CO><<<nb, 256, 0, st>>>(nbr, K, num_out, rpb, in, ld_in, dout, ld_dout, sl)
-    if (cin == 1 && cout == 16) STEM_WG(1, 16); else if (cin == 1) STEM_WG(1, 32); else STEM_WG(2, 16);
+#define STEM_WG() k_spconv_stem_wgrad<16><<<nb, 256, 0, st>>>(nbr, K, num_out, rpb, in, ld_in, dout, ld_dout, sl)
+    STEM_WG();
 #undef STEM_WG
     MOPA_CHECK_LAUNCH();
     const int64_t n = (int64_t)K * cin * cout;
