@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_run_reduce(const int* __restrict__ pos,
 
 // Shapes the offset-major path takes (the dispatcher's rule; cin / cout are those of the convolution to run).  Measured per layer
 // against the output-stationary kernels at 8 and 16 scans (profiles/r5_spconv_run.md):
-//   * tables with one rule per output row (no slab, no reduce): always, from 32 input channels;
+//   * tables with one rule per output row (no slab, no reduce): from 32 input channels and 8,192 rows;
 //   * 27-offset tables: where the matrix pipe bounds the launch and the slab's bytes (2 x rules x cout x 4, written and read once)
 //     stay below what the fuller MFMA groups return -- cin >= 64, cout >= 48 and rows x cout <= 110,000 x cin (wins: 103k rows
 //     96 -> 48 0.78x, 49k 128 -> 64 0.71x, 98k 64 -> 64 0.97x, 39k 80 -> 160 0.86x; losses: 386k 64 -> 32 1.33x, 98k 64 -> 128 1.21x);
@@ -356,7 +356,7 @@ MOPA_API int mopa_spconv_run_wanted(int32_t K, int32_t num_out, int32_t cin, int
   if (mode == 0 || K <= 0 || K > 27 || num_out <= 0 || run_nt(cin, cout) == 0) return 0;
   if ((int64_t)num_out * 8 * 224 * 4 >= (1ll << 32)) return 0;   // 32-bit byte offsets into the input rows
   if (mode == 2) return 1;
-  if (one_rule_per_row) return cin >= 32;
+  if (one_rule_per_row) return cin >= 32 && num_out >= 8192;   // (6,789 rows: 13.5 against 11.0 us; 19,312 rows: 9.0 against 14.9)
   if (K != 27) return 0;
   return cin >= 64 && cout >= 48 && (int64_t)num_out * cout <= rows_per * cin;
 }
@@ -428,7 +428,7 @@ MOPA_API int mopa_spconv_fwd_run(const int32_t* runs, int32_t K, int32_t num_out
   // items of 128 slots (two row groups per wave) unless the table is so short that they would leave CUs idle: the rule count is
   // not known on the host (no synchronisation), ~9 rules per row on the deep 27-offset tables, rows_in <= 8 rows_out otherwise
   const int64_t rules_est = K == 27 ? (int64_t)9 * num_out : one_rule_per_row ? num_out : (int64_t)5 * num_out / 2;
-  const int rg = rules_est / 128 < 400 ? 1 : 2;
+  const int rg = rules_est / 128 < 1024 ? 1 : 2;   // (fewer than ~4 items of 128 per CU: level 5 at 8 scans 27 -> 17 us with 64-slot items)
   int rc;
 #define RUN_L(N, G) rc = launch_run<N, G>(hdr, run_in, run_out, K, cap, in, ld_in, cin, weight_run, cout, w_flip & 1, dst, ld_dst, one_rule_per_row != 0, st)
 #define RUN_N(N) if (rg == 1) RUN_L(N, 1); else RUN_L(N, 2);
