@@ -116,6 +116,7 @@ SIGNATURES = {
     "mopa_wino4_weight_t": ("i", "piiipp"),
     "mopa_wino4_weight_f": ("i", "piiipp"),
     "mopa_wino4_conv": ("i", "pipppiiiiiiipiipp"),
+    "mopa_wino4_conv_tiles32": ("i", "i"),
     "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),
     "mopa_wino4_input": ("i", "piiiiipp"),

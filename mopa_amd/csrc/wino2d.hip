@@ -12,6 +12,7 @@
 #include "weight_forms.h"
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 // U[p][r][c], p = 4*i + j.  dgrad = 0: r = input channel, c = output channel, g = w[c][r][.][.] (OIHW);
 //                           dgrad = 1: r = output channel, c = input channel, g = w[r][c] rotated by 180 degrees.
@@ -1043,11 +1044,305 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
 #endif
 }
 
+// k_wino4_conv with 32 tiles per item (round-4 review, item 2): 8 waves = (16 output channels wv) x (point half ph).  A wave multiplies
+// BOTH 16-tile halves by its 18 points' weight fragments -- 8 MFMAs per fragment instead of 4, half the weight bytes from L2 per tile
+// -- and holds 2 x 18 accumulator blocks = the 144 registers of k_wino4_conv, so two waves share a SIMD as before (one wave per SIMD
+// with all 36 points would need 288 accumulators: the compiler spills 157 registers of it).  V of both halves: 144 KB of LDS.
+template <bool BN, bool VOUT>
+__global__ __launch_bounds__(512, 2) void k_wino4_conv32(const float* __restrict__ in, int ld_in, const float* __restrict__ Uf,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int ld_out, int B, int H,
+                                                     int W, int th, int tw, int Cin, int Cout, int accumulate,
+                                                     const float* __restrict__ stats, int imgs_per_group, int nitems,
+                                                     float* __restrict__ Vout
+#ifdef W4C_PROFILE
+                                                     , long long* prof
+#endif
+                                                     ) {
+#ifdef W4C_PROFILE
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define W4C_T(K_) { const long long n_ = __builtin_readcyclecounter(); pt[K_] += n_ - tprev; tprev = n_; }
+#else
+#define W4C_T(K_)
+#endif
+  extern __shared__ __attribute__((aligned(16))) float w4c_lds[];   // [2 tile halves][2 chunks][36][64] float4 = 144 KB; two output tiles [16][1028] floats over it
+  f32x4w* __restrict__ lds = reinterpret_cast<f32x4w*>(w4c_lds);
+  const int tid = threadIdx.x, lane = tid & 63, t = lane & 15, q = lane >> 4;
+  const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves
+  const int wv = wv8 & 3;     // transform: the wave's 8 channels of the step; multiply: its 16 output channels
+  const int ph = wv8 >> 2;    // transform / by-product: tile half; multiply / fold: point half (transform rows pi = 3 ph .. 3 ph + 2)
+  const int ny = Cout >> 6;
+  const int T = B * th * tw, tt = th * tw;
+  const int nround = Cin >> 5, nchunk = Cin >> 4, nnb = Cout >> 4;
+  const f32x4w zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t pstride = (int64_t)nchunk * nnb * 64;   // float4 elements per transform point
+  f32x4w acc[2][18];   // [tile half][point of the wave's point half]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 18; ++p) acc[h][p] = zero4;
+  const f32x2w zero2 = {0.f, 0.f};
+  f32x2w sc = {1.f, 1.f}, sh = zero2;
+  unsigned rmask = 0, cmask = 0;
+  float pf_sink = 0.f;
+  // transform phase: lane = (tile tx_ = lane / 4, channel pair pr_ = lane % 4 of the wave's 8 channels) -- four consecutive lanes read
+  // 32 contiguous bytes (with the MFMA numbering t + 16 q every lane of a load would start a segment of its own).  Channel
+  // 8 wv + 2 pr_ + e of the step = chunk wv / 2, quad qq_ = 2 (wv % 2) + pr_ / 2, half hh_ = pr_ % 2 of the float4 in slot tx_ + 16 qq_.
+  const int tx_ = lane >> 2, pr_ = lane & 3;
+  const int qq_ = ((wv & 1) << 1) + (pr_ >> 1), hh_ = pr_ & 1;
+  f32x4w bA[6], bB[6];
+  // the patch of step (IT_, R_): tile coordinates, in-image masks, BatchNorm constants, 36 loads.  PF_: touch the lines only (into
+  // L2, one step ahead: the 144 patch registers of a real prefetch do not fit beside the accumulators and the weight buffers) --
+  // a dword load per lane into one scratch register that is kept alive until the next real patch has been waited for.
+#define W4C_PATCH(IT_, R_, PF_)   /* the wave's tile half: ph */                                                                               \
+  {                                                                                                           \
+    const int tile_ = ((IT_) / ny) * 32 + ph * 16 + tx_;                                                      \
+    const bool tv_ = tile_ < T;                                                                               \
+    const int tb_ = tv_ ? tile_ / tt : 0, trt_ = tv_ ? tile_ - tb_ * tt : 0;                                  \
+    const int tty_ = trt_ / tw, ttx_ = trt_ - tty_ * tw;                                                      \
+    const int y0_ = 4 * tty_ - 1, x0_ = 4 * ttx_ - 1;                                                         \
+    const int ch0_ = ((R_) << 5) + (wv << 3) + 2 * pr_;                                                       \
+    const float* __restrict__ pin_ = in + ((int64_t)(tb_ * H + y0_) * W + x0_) * ld_in + ch0_;               \
+    const float* __restrict__ psafe_ = in + ch0_;                                                             \
+    unsigned rm_ = 0, cm_ = 0;                                                                                \
+    _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_) {                                                        \
+      rm_ |= (tv_ && (unsigned)(y0_ + a_) < (unsigned)H) ? (1u << a_) : 0u;                                   \
+      cm_ |= ((unsigned)(x0_ + a_) < (unsigned)W) ? (1u << a_) : 0u;                                          \
+    }                                                                                                         \
+    if (!(PF_)) {                                                                                             \
+      rmask = rm_; cmask = cm_;                                                                               \
+      if (BN) {                                                                                               \
+        /* imgs_per_group = images per BatchNorm group | bn_c0 << 16 (one kernel argument more costs this kernel its register budget); */ \
+        /* channels below bn_c0 pass through (see mopa_wino4_input_bn) */                                     \
+        const int bc0_ = imgs_per_group >> 16;                                                                \
+        sc = (f32x2w){1.f, 1.f}; sh = zero2;                                                                  \
+        if (ch0_ >= bc0_) {                                                                                   \
+          const float* __restrict__ sg_ = stats + (int64_t)(tb_ / (imgs_per_group & 0xffff)) * 4 * (Cin - bc0_) + ch0_ - bc0_; \
+          sc = *reinterpret_cast<const f32x2w*>(sg_);                                                         \
+          sh = *reinterpret_cast<const f32x2w*>(sg_ + Cin - bc0_);                                            \
+        }                                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int a_ = 0; a_ < 6; ++a_)                                                          \
+      _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {                                                      \
+        const bool ins_ = ((rm_ >> a_) & (cm_ >> c_) & 1u) != 0u;                                             \
+        const float* __restrict__ src_ = ins_ ? pin_ + ((int64_t)a_ * W + c_) * ld_in : psafe_;              \
+        if (PF_) { if (wv == 0 && pr_ == 0) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src_)); } /* "+": ONE register; one lane per 128-byte line */ \
+        else d[a_][c_] = *reinterpret_cast<const f32x2w*>(src_);                                              \
+      }                                                                                                       \
+  }
+#define W4C_LOADB(BQ, C_, P0_)                                                                                \
+  {                                                                                                           \
+    const f32x4w* __restrict__ ub_ = Ufw + (int64_t)((r << 1) + (C_)) * nnb * 64 + (int64_t)(ph * 18 + (P0_)) * pstride;  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) BQ[i_] = ub_[i_ * pstride];                             \
+  }
+#define W4C_MUL6(BQ, C_, P0_, I0_)                                                                            \
+  _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {   /* the same weight fragments for both tile halves: 8 MFMAs per fragment */ \
+    const f32x4w* __restrict__ la_ = lds + ((hf_ * 2 + (C_)) * 36 + ph * 18 + (P0_) + (I0_)) * 64 + lane;     \
+    f32x4w av_[6];                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) av_[i_] = la_[i_ * 64];                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                        \
+      acc[hf_][(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][0], BQ[(I0_) + i_][0], acc[hf_][(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[hf_][(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][1], BQ[(I0_) + i_][1], acc[hf_][(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[hf_][(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][2], BQ[(I0_) + i_][2], acc[hf_][(P0_) + (I0_) + i_], 0, 0, 0); \
+      acc[hf_][(P0_) + (I0_) + i_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[i_][3], BQ[(I0_) + i_][3], acc[hf_][(P0_) + (I0_) + i_], 0, 0, 0); \
+    }                                                                                                         \
+  }
+#define W4C_MUL(BQ, C_, P0_) W4C_MUL6(BQ, C_, P0_, 0)
+  constexpr float AT[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+  int item = blockIdx.x, r = 0;
+  while (item < nitems) {
+    const int tg = item / ny, n0 = (item - tg * ny) << 6;
+    const f32x4w* __restrict__ Ufw = reinterpret_cast<const f32x4w*>(Uf) + (int64_t)((n0 >> 4) + wv) * 64 + lane;
+    W4C_T(0)
+    // ---- transform: patch -> V chunk wv (everyone is done with the LDS of the previous step: barrier at its end)
+    f32x2w d[6][6];
+    W4C_PATCH(item, r, false);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const bool inside = ((rmask >> a) & (cmask >> c) & 1u) != 0u;
+        f32x2w v = d[a][c];
+        if (BN) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float o = fmaf(v[e], sc[e], sh[e]);
+            v[e] = o > 0.f ? o : o * 0.f;
+          }
+        }
+        d[a][c] = inside ? v : zero2;
+      }
+    asm volatile("" :: "v"(pf_sink));   // (the touch loads of the previous step were issued before this patch: they have landed)
+    W4C_T(1)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)
+      const f32x2w d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+      w4_bt6(d0, d1, d2, d3, d4, d5, d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
+    }
+    {
+      f32x2w* __restrict__ lw = reinterpret_cast<f32x2w*>(w4c_lds) + (((ph * 2 + (wv >> 1)) * 36) * 64 + tx_ + 16 * qq_) * 2 + hh_;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {   // (.) B
+        f32x2w v0, v1, v2, v3, v4, v5;
+        w4_bt6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5], v0, v1, v2, v3, v4, v5);
+        lw[(a * 6 + 0) * 128] = v0;
+        lw[(a * 6 + 1) * 128] = v1;
+        lw[(a * 6 + 2) * 128] = v2;
+        lw[(a * 6 + 3) * 128] = v3;
+        lw[(a * 6 + 4) * 128] = v4;
+        lw[(a * 6 + 5) * 128] = v5;
+      }
+    }
+    W4C_LOADB(bA, 0, 0);
+    W4C_LOADB(bB, 0, 6);
+    const bool last_round = r + 1 == nround;
+    const int nitem = last_round ? item + (int)gridDim.x : item, nr = last_round ? 0 : r + 1;
+    W4C_T(2)
+    __syncthreads();   // V is complete
+    W4C_T(3)
+    if (VOUT && n0 == 0) {
+      // training forward: V[36][T][Cin] goes to HBM as a by-product (the weight gradient multiplies it again) -- written once, not read
+      // by this layer.  A point is 16 tiles x 32 channels = two 1-KiB wave stores of whole 128-byte (tile, channel block) rows.
+      const int c8 = lane & 7, vt = lane >> 3;   // float4 c8 of the step's 32 channels = chunk c8 / 4, quad c8 % 4
+      // (running pointers, a rolled loop: this block must not cost the multiplication its registers)
+      const f32x4w* __restrict__ lp = lds + ((ph * 2 + (c8 >> 2)) * 36 + wv) * 64 + vt + 16 * (c8 & 3);
+      float* __restrict__ vp = Vout + ((int64_t)wv * T + (tg << 5) + (ph << 4) + vt) * Cin + (r << 5) + 4 * c8;
+      const int64_t vstep = (int64_t)4 * T * Cin;
+      const bool ok0 = (tg << 5) + (ph << 4) + vt < T, ok1 = (tg << 5) + (ph << 4) + vt + 8 < T;
+#pragma unroll 1
+      for (int k = 0; k < 9; ++k, lp += 4 * 64, vp += vstep) {
+        const f32x4w v0 = lp[0], v1 = lp[8];
+        if (ok0) *reinterpret_cast<f32x4w*>(vp) = v0;
+        if (ok1) *reinterpret_cast<f32x4w*>(vp + 8 * Cin) = v1;
+      }
+    }
+    // six units of (6 points x 2 tile halves x 4 MFMAs): the weight fragments of the unit after next are loaded behind each
+    W4C_MUL(bA, 0, 0);   W4C_LOADB(bA, 0, 12);
+    W4C_MUL(bB, 0, 6);   W4C_LOADB(bB, 1, 0);
+    W4C_MUL(bA, 0, 12);  W4C_LOADB(bA, 1, 6);
+    W4C_MUL(bB, 1, 0);   W4C_LOADB(bB, 1, 12);
+    W4C_MUL(bA, 1, 6);
+    W4C_MUL(bB, 1, 12);
+    W4C_T(4)
+    __syncthreads();   // everyone is done reading V
+    W4C_T(5)
+    // touch the next step's patch: it comes from L2 instead of HBM when the loop comes round
+    if (nitem < nitems) W4C_PATCH(nitem, nr, true);
+    if (last_round) {
+      // ---- output transform: lane holds M[point][tile 4 q + i][channel n0 + 16 wv + t], i = 0..3, for the transform rows pi = 3 ph ..
+      // 3 ph + 2 of both tile halves.  Y = A^T M A is linear in the rows: each wave folds its three rows in registers and the two
+      // partial sums meet in the LDS tiles -- wave (wv, ph) writes tile half ph and keeps its share of the other half in the (dead)
+      // accumulators; after a barrier it adds that share to tile half 1 - ph, which wave (wv, 1 - ph) wrote.
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float o[4][16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          float srow[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) srow[i][c] = 0.f;
+#pragma unroll
+          for (int pj = 0; pj < 6; ++pj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (AT[pj][c] != 0.f) srow[i][c] = fmaf(AT[pj][c], acc[hf][pl * 6 + pj][i], srow[i][c]);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const float ca = ph ? AT[3 + pl][a] : AT[pl][a];   // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[i][a * 4 + c] = fmaf(ca, srow[i][c], o[i][a * 4 + c]);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 18; ++p) acc[hf][p] = zero4;
+        if (hf == ph) {
+          // [tile half][tile 16][pixel 16][channel 64] with 4 floats between tiles (the four lane groups q write tiles 4 apart)
+          float* __restrict__ ot = w4c_lds + hf * (16 * 1028) + (wv << 4) + t;
+          const float bvv = bias ? bias[n0 + (wv << 4) + t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ot[(4 * q + i) * 1028 + e * 64] = o[i][e] + bvv;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[hf][i * 4 + (e >> 2)][e & 3] = o[i][e];
+        }
+      }
+      __syncthreads();   // each tile half holds one point half (+ bias)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        if (hf != ph) {
+          float* __restrict__ ot = w4c_lds + hf * (16 * 1028) + (wv << 4) + t;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ot[(4 * q + i) * 1028 + e * 64] += acc[hf][i * 4 + (e >> 2)][e & 3];
+#pragma unroll
+          for (int p = 0; p < 16; ++p) acc[hf][p] = zero4;
+        }
+      __syncthreads();
+      // whole pixel rows: thread = (pixel wv * 4 + q of the tile, channel quad t) of tile half ph; one tile per iteration, its coordinates
+      // are uniform and stepped, not divided
+      {
+        int otile = (tg << 5) + (ph << 4);
+        int ob = otile / tt, ort = otile - ob * tt;
+        int oty = ort / tw, otx = ort - oty * tw;
+        const f32x4w* __restrict__ sp = reinterpret_cast<const f32x4w*>(w4c_lds + ph * (16 * 1028) + (wv * 4 + q) * 64 + 4 * t);
+#pragma unroll 4
+        for (int k = 0; k < 16 && otile < T; ++k, ++otile) {
+          const int y = 4 * oty + wv, x = 4 * otx + q;
+          if (y < H && x < W) {
+            f32x4w v = sp[k * 257];   // (1028 floats per tile)
+            f32x4w* gp = reinterpret_cast<f32x4w*>(out + ((int64_t)(ob * H + y) * W + x) * ld_out + n0 + 4 * t);
+            if (accumulate) v += *gp;
+            *gp = v;
+          }
+          if (++otx == tw) { otx = 0; if (++oty == th) { oty = 0; ++ob; } }
+        }
+      }
+      __syncthreads();   // the tiles have been read: the next step may write V over them
+    }
+    W4C_T(6)
+    item = nitem; r = nr;
+  }
+#undef W4C_PATCH
+#undef W4C_LOADB
+#undef W4C_MUL
+#undef W4C_MUL6
+#ifdef W4C_PROFILE
+  if (blockIdx.x == 100 && tid == 0)
+    for (int k = 0; k < 8; ++k) prof[k] = pt[k];
+#endif
+}
+
 // B-operand fragments of k_wino4_conv from the OIHW weight (weight_forms.h: transpose = 2); dgrad as in mopa_wino4_weight.
 MOPA_API int mopa_wino4_weight_f(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* Uf, void* stream) {
   if (O <= 0 || I <= 0 || O % 16 || I % 16) return MOPA_ERR_ARG;
   k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, Uf, 2);
   MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// Which kernel mopa_wino4_conv launches: -1 = by shape (the default), 0 = k_wino4_conv (16 tiles per item), 1 = k_wino4_conv32 (32 tiles);
+// the environment variable MOPA_WINO4_CONV32 gives the initial value (tests and profiles/ set it).
+static std::atomic<int>& w4c_tiles32_mode() {
+  static std::atomic<int> mode([] { const char* e = getenv("MOPA_WINO4_CONV32"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }());
+  return mode;
+}
+MOPA_API int mopa_wino4_conv_tiles32(int32_t mode) {
+  w4c_tiles32_mode().store(mode < 0 ? -1 : mode != 0 ? 1 : 0, std::memory_order_relaxed);
   return MOPA_OK;
 }
 
@@ -1067,32 +1362,42 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
   if (stats && (n_groups < 1 || B % n_groups || B / n_groups > 0xffff || bn_c0 < 0 || bn_c0 >= Cin || (bn_c0 & 1))) return MOPA_ERR_ARG;
   const int th = (H + 3) / 4, tw = (W + 3) / 4;
   const int64_t T = (int64_t)B * th * tw;
-  const int64_t nitems = cdiv64(T, 16) * (Cout / 64);
-  if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
-  const size_t ldsb = (size_t)2 * 36 * 64 * 16;   // 72 KB: two workgroups per CU
   const int ncu = mopa_cu_count();   // of the current device
   const int dev = mopa_device_index();
   if (ncu <= 0 || dev < 0) return MOPA_ERR_LAUNCH;
-  const int v = (stats ? 1 : 0) | (V ? 2 : 0);
+  // k_wino4_conv32 (32 tiles per item, one 8-wave workgroup per CU: half the weight bytes per tile, but the CU's transform and
+  // multiply phases no longer overlap) instead of k_wino4_conv (16 tiles, two 4-wave workgroups per CU) where it measured faster:
+  // from 8 items per CU on (profiles/r5_wino4_conv32.md; 16 x 304 x 480: 64->128 1487 -> 1393 us, 128->64 1477 -> 1320 us).
+  // mopa_wino4_conv_tiles32 / MOPA_WINO4_CONV32 = 0 / 1: never / always.
+  const int conv32_mode = w4c_tiles32_mode().load(std::memory_order_relaxed);
+  const bool conv32 = conv32_mode >= 0 ? conv32_mode != 0 : cdiv64(T, 32) * (Cout / 64) >= 8 * (int64_t)ncu;
+  const int64_t nitems = cdiv64(T, conv32 ? 32 : 16) * (Cout / 64);
+  if (T >= (1 << 30) || nitems >= (1ll << 31)) return MOPA_ERR_ARG;
+  const size_t ldsb = (size_t)(conv32 ? 4 : 2) * 36 * 64 * 16;   // 72 KB: two workgroups per CU; 144 KB: one
+  const int v = (stats ? 1 : 0) | (V ? 2 : 0), va = v | (conv32 ? 4 : 0);
   typedef void (*kern_t)(const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, int,
                          int, float*
 #ifdef W4C_PROFILE
                          , long long*
 #endif
                          );
-  static const kern_t kerns[4] = {k_wino4_conv<false, false>, k_wino4_conv<true, false>, k_wino4_conv<false, true>, k_wino4_conv<true, true>};
-  static std::atomic<bool> attr[64][4];   // per device and variant: the attribute belongs to the device's code object
-  if (!attr[dev][v].load(std::memory_order_acquire)) {
+  static const kern_t kerns16[4] = {k_wino4_conv<false, false>, k_wino4_conv<true, false>, k_wino4_conv<false, true>, k_wino4_conv<true, true>};
+  static const kern_t kerns32[4] = {k_wino4_conv32<false, false>, k_wino4_conv32<true, false>, k_wino4_conv32<false, true>,
+                                    k_wino4_conv32<true, true>};
+  const kern_t* kerns = conv32 ? kerns32 : kerns16;
+  const int per_cu = conv32 ? 1 : 2, nthr = conv32 ? 512 : 256;
+  static std::atomic<bool> attr[64][8];   // per device and variant: the attribute belongs to the device's code object
+  if (!attr[dev][va].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
       return MOPA_ERR_LAUNCH;
-    attr[dev][v].store(true, std::memory_order_release);
+    attr[dev][va].store(true, std::memory_order_release);
   }
-  const unsigned nblk = (unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu);   // persistent: two workgroups per CU
+  const unsigned nblk = (unsigned)(nitems < per_cu * ncu ? nitems : per_cu * ncu);   // persistent
   const int ipg = stats ? (B / n_groups) | (bn_c0 << 16) : 1;
 #ifdef W4C_PROFILE
   static long long* prof = nullptr;
   if (!prof) hipMallocManaged(&prof, 128);
-  kerns[v]<<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
+  kerns[v]<<<nblk, nthr, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
                                                   (int)nitems, V, prof);
   hipStreamSynchronize((hipStream_t)stream);
   {
@@ -1102,7 +1407,7 @@ MOPA_API int mopa_wino4_conv(const float* in, int32_t ld_in, const float* Uf, co
            prof[0] / n_, prof[1] / n_, prof[2] / n_, prof[3] / n_, prof[4] / n_, prof[5] / n_, prof[6] / n_, n_);
   }
 #else
-  kerns[v]<<<nblk, 256, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
+  kerns[v]<<<nblk, nthr, ldsb, (hipStream_t)stream>>>(in, ld_in, Uf, bias, out, ld_out, B, H, W, th, tw, Cin, Cout, accumulate, stats, ipg,
                                                   (int)nitems, V);
 #endif
   MOPA_CHECK_LAUNCH();

@@ -865,8 +865,11 @@ def test_deferred_batchnorm_gives_the_bits_of_the_materialised_one(groups, monke
 @pytest.mark.parametrize("cin,cout,H,W,acc,dgrad,G", [(64, 64, 37, 51, False, False, 0), (128, 64, 21, 30, True, False, 0),
                                                       (64, 128, 16, 24, False, True, 0), (64, 64, 19, 22, False, False, 2),
                                                       (128, 128, 9, 13, True, True, 1)])
-def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, G, monkeypatch):
-    """mopa_wino4_conv (input transform, 36 GEMMs, output transform of F(4x4) in one kernel; V and M never written) through
+@pytest.mark.parametrize("tiles32", [0, 1])
+def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, G, tiles32, monkeypatch, request):
+    """mopa_wino4_conv (input transform, 36 GEMMs, output transform of F(4x4) in one kernel; V and M never written) -- both of its
+    kernels: k_wino4_conv (16 tiles per work item) and k_wino4_conv32 (32 tiles, the two point halves of the output transform summed
+    through LDS), forced with mopa_wino4_conv_tiles32 (by default the shape decides: 32 tiles from 8 items per CU on) -- through
     dense2d.wino_conv, forced on for small shapes: against an fp64 conv3x3 (padding 1; dgrad: the transposed convolution's weight form)
     and against the two-kernel path; ragged tiles, a tile group beyond T, the input as a column slice of a wider buffer, bias,
     accumulation, and (G > 0) a deferred BatchNorm + ReLU applied on the way in for G image groups."""
@@ -874,6 +877,8 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
     from mopa_amd import dense2d
     from mopa_amd._lib import call, ptr, stream
     from mopa_amd.dense2d import bn_fwd_groups
+    call("mopa_wino4_conv_tiles32", tiles32)
+    request.addfinalizer(lambda: call("mopa_wino4_conv_tiles32", -1))
     rng = np.random.Generator(np.random.PCG64(900 + cin + W))
     B = 2 if G != 1 else 3
     wide = torch.from_numpy(rng.standard_normal((B * H * W, cin + 64)).astype(np.float32)).cuda()
@@ -917,6 +922,32 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
         _close(out, ref.float().numpy(), rtol=1e-4, atol=3e-5)
         outs.append(out)
     _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
+
+
+def test_one_kernel_convolution_picks_32_tiles_per_item_on_the_long_layers(request):
+    """mopa_wino4_conv by shape: the decoder's full-resolution layer (64 -> 128 backward-data at 4 x 304 x 480: 1140 tile groups x 2 = 2280
+    work items of 32 tiles >= 8 per CU) runs k_wino4_conv32 -- the bits of the forced 32-tile kernel -- and agrees with the 16-tile kernel
+    to fp32 round-off (the two point halves are summed in a different order); a short layer (64 -> 64 at 1 x 64 x 64) keeps the 16-tile
+    kernel's bits."""
+    from mopa_amd._lib import call, ptr, stream
+    request.addfinalizer(lambda: call("mopa_wino4_conv_tiles32", -1))
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (B, H, W, cin, cout, want32) in ((4, 304, 480, 64, 128, True), (1, 64, 64, 64, 64, False)):
+        x = torch.randn(B * H * W, cin, device="cuda", generator=g)
+        w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05
+        U = torch.empty(36, cin, cout, device="cuda")
+        call("mopa_wino4_weight_f", ptr(w), cout, cin, 0, ptr(U), stream())
+        outs = {}
+        for mode in (-1, 0, 1):
+            call("mopa_wino4_conv_tiles32", mode)
+            o = torch.empty(B * H * W, cout, device="cuda")
+            call("mopa_wino4_conv", ptr(x), cin, ptr(U), None, ptr(o), cout, B, H, W, cin, cout, 0, None, 1, 0, None, stream())
+            outs[mode] = o
+        torch.cuda.synchronize()
+        assert torch.equal(outs[-1], outs[1 if want32 else 0])
+        assert not torch.equal(outs[0], outs[1])
+        scale = float(outs[0].abs().max())
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
 
 
 def test_one_kernel_convolution_network_level(monkeypatch):
@@ -999,8 +1030,8 @@ def test_stem_batchnorm_backward_inside_the_stem_weight_gradient(groups, trainin
     assert float(gb["net_2d.conv1.weight"].abs().max()) > 0
 
 
-@pytest.mark.parametrize("G,one_kernel", [(1, False), (2, False), (2, True)])
-def test_join_buffer_with_the_up_convolution_batchnorm_applied_on_the_way_in(G, one_kernel, monkeypatch):
+@pytest.mark.parametrize("G,one_kernel", [(1, False), (2, False), (2, True), (2, 32)])
+def test_join_buffer_with_the_up_convolution_batchnorm_applied_on_the_way_in(G, one_kernel, monkeypatch, request):
     """bn_c0: a decoder join buffer [skip (already relu(batchnorm(.)): non-negative, with exact zeros) | raw up-convolution]; the
     BatchNorm of the second half is statistics only and the consumer normalises channels [c0, C) while it reads -- mopa_wino4_input_bn
     and, in one kernel with the convolution, mopa_wino4_conv -- against the buffer whose second half was written out by the apply pass:
@@ -1008,6 +1039,9 @@ def test_join_buffer_with_the_up_convolution_batchnorm_applied_on_the_way_in(G, 
     from mopa_amd import dense2d
     from mopa_amd._lib import call, ptr, stream
     from mopa_amd.dense2d import Img, bn_fwd_groups
+    if one_kernel:   # (True: k_wino4_conv, 32: k_wino4_conv32)
+        call("mopa_wino4_conv_tiles32", int(one_kernel == 32))
+        request.addfinalizer(lambda: call("mopa_wino4_conv_tiles32", -1))
     rng = np.random.Generator(np.random.PCG64(77 + G))
     B, H, W, cj = 2 * G, 14, 19, 64
     raw = torch.from_numpy(rng.standard_normal((B * H * W, 2 * cj)).astype(np.float32)).cuda()
