@@ -55,6 +55,9 @@ SIGNATURES = {
     "mopa_spconv_run_form": ("i", "ii"),
     "mopa_spconv_run_workspace_bytes": ("z", "iii"),
     "mopa_spconv_fwd_run": ("i", "piipiipiipiipzp"),
+    "mopa_spconv_wgrad_run_wanted": ("i", "iiiii"),
+    "mopa_spconv_wgrad_run_workspace_bytes": ("z", "iiiii"),
+    "mopa_spconv_bwd_weight_run": ("i", "piiiipiipiipipzp"),
     # ---- native executor of the 3D layer program (scn_exec.hip)
     "mopa_scn_workspace_bytes": ("z", "pipii"),
     "mopa_scn_forward": ("i", "pippppppzp"),

@@ -114,6 +114,35 @@ static inline int wanted_ntw(const Table& t, int cin, int cout, int ld_in) {
   return mopa_spconv_grouped_wants_packed(t.K, t.rows_out, cin, cout);
 }
 
+// The weight gradient of a convolution of `ckind` at level l: on the run lists where sprun.hip's dispatcher wants them -- the
+// table's own run-major rulebook, or (stride-2 convolution: its forward table has none) the deconvolution table's with the two index
+// lists swapped -- else on the dense table.  Mirrors mopa_amd/sparse3d.py::spconv_bwd_weight_of.
+struct WgradPlan { Table t; int run; int swap; };
+static inline WgradPlan wgrad_plan_of(const int64_t* geom, int ckind, int l, int cin, int cout) {
+  WgradPlan w;
+  w.t = table_of(geom, ckind, l, false);
+  w.run = 0; w.swap = 0;
+  if (ckind == C_NIN) return w;
+  if (w.t.runs) {
+    w.run = mopa_spconv_wgrad_run_wanted(w.t.K, w.t.rows_out, cin, cout, w.t.one);
+    return w;
+  }
+  if (ckind == C_DOWN) {
+    const Table r = table_of(geom, ckind, l, true);   // the deconvolution table: the same (coarse, fine, offset) triples
+    if (r.runs && r.one && mopa_spconv_wgrad_run_wanted(r.K, r.rows_out, cin, cout, 1)) { w.t = r; w.run = 1; w.swap = 1; }
+  }
+  return w;
+}
+static inline size_t wgrad_workspace(const WgradPlan& w, int cin, int cout) {
+  return w.run ? mopa_spconv_wgrad_run_workspace_bytes(w.t.K, w.t.rows_out, cin, cout, w.t.one)
+               : mopa_spconv_wgrad_workspace_bytes(w.t.K, w.t.rows_out, cin, cout);
+}
+static inline int run_wgrad(const WgradPlan& w, const View& x, const View& dy, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (w.run)
+    return mopa_spconv_bwd_weight_run(w.t.runs, w.t.K, w.t.rows_out, w.t.one, w.swap, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, dw, accumulate, ws, ws_bytes, st);
+  return mopa_spconv_bwd_weight(w.t.nbr, w.t.K, w.t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, dw, accumulate, ws, ws_bytes, st);
+}
+
 // Make the weight form of (op, pass) valid for `ntw` at `epoch`; returns the pointer the kernel reads.  pass 0: forward
 // (ntw 0 = the parameter itself), pass 1: backward-data (the convolution to run is the per-offset transpose).
 static const float* form_ptr(const int64_t* params, int64_t* forms, int op, int pass, int ntw) {
@@ -200,8 +229,7 @@ MOPA_API size_t mopa_scn_workspace_bytes(const int32_t* prog_host, int32_t n_ops
         if (t.runs && !t.one && mopa_spconv_run_wanted(t.K, t.rows_out, cin, cout, 0))
           need = max_sz(need, mopa_spconv_run_workspace_bytes(t.K, t.rows_out, cout));
       }
-      const Table t = table_of(geom_host, o[OP_CKIND], l, false);
-      need = max_sz(need, mopa_spconv_wgrad_workspace_bytes(t.K, t.rows_out, o[OP_SC], o[OP_DC]));
+      need = max_sz(need, wgrad_workspace(wgrad_plan_of(geom_host, o[OP_CKIND], l, o[OP_SC], o[OP_DC]), o[OP_SC], o[OP_DC]));
     }
   }
   need = max_sz(need, mopa_output_layer_heads_bwd_workspace_bytes((int)geom_host[G_NPTS], M, num_classes));
@@ -314,12 +342,12 @@ MOPA_API int mopa_scn_backward(const int32_t* prog_host, int32_t n_ops, const in
       continue;
     }
     const int ck = o[OP_CKIND], l = o[OP_LSRC] < o[OP_LDST] ? o[OP_LSRC] : o[OP_LDST];
-    const Table t = table_of(geom_host, ck, l, false);
+    const WgradPlan wg = wgrad_plan_of(geom_host, ck, l, x.C, dy.C);
     if (side) {   // dy is complete at this point of `stream`; nothing later in the pass writes it or the layer's input again
       if (hipEventRecord(ev_ready, st) != hipSuccess || hipStreamWaitEvent(wst, ev_ready, 0) != hipSuccess) return MOPA_ERR_LAUNCH;
-      rc = mopa_spconv_bwd_weight(t.nbr, t.K, t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, (float*)g[0], (int)g[2], ws2, ws2_bytes, wst);
+      rc = run_wgrad(wg, x, dy, (float*)g[0], (int)g[2], ws2, ws2_bytes, wst);
     } else {
-      rc = mopa_spconv_bwd_weight(t.nbr, t.K, t.rows_out, x.p, x.ld, x.C, dy.p, dy.ld, dy.C, (float*)g[0], (int)g[2], ws, ws_bytes, st);
+      rc = run_wgrad(wg, x, dy, (float*)g[0], (int)g[2], ws, ws_bytes, st);
     }
     if (rc) break;
     if (pl[PL_SKIPDX]) continue;

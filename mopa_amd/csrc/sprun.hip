@@ -451,3 +451,381 @@ MOPA_API int mopa_spconv_fwd_run(const int32_t* runs, int32_t K, int32_t num_out
   }
   return MOPA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the run lists: dW[o] = sum over the slots s of offset o's run of in[a(s)]^T dout[b(s)] -- one GEMM per offset
+// with the slots as its K dimension, (a, b) = (run_in, run_out) or, for the stride-2 convolution's gradient taken on its
+// deconvolution table, (run_out, run_in).  spconv.hip's k_spconv_wgrad2 walks the dense table (27 x rows entries, one rule per 1-10
+// entries), one wave per (offset, row chunk, 64-channel block of Cin) loading both operands straight into the MFMA layout: every
+// output-gradient row is gathered once per Cin block and the wave's 16 MFMAs per 4 rules wait on a dependent index -> gather chain.
+// Here a block of eight waves owns a PIECE of S consecutive slots of one offset (pieces are equal in rules, not in table rows: the
+// centre offset of a submanifold table has 10x the rules of a corner), stages 32 slots x (Cin + Cout) floats at a time into LDS
+// -- whole rows, float4 gathers, the next tile's rows in flight in registers, the tile after next's indices behind them -- and
+// multiplies the full Cin x Cout tile from there (wave (w, kh): Cin blocks [w MU, w MU + MU) x all Cout blocks over half kh of the
+// tile's k-steps; the halves are added through LDS at the end).  Pieces write slabs;
+// k_wgrad_run_reduce adds the slabs of an offset in piece order (deterministic) into dW[o].
+// Semantics: autograd of scn.SubmanifoldConvolution / Convolution / Deconvolution weights (mopa/models/scn_unet.py:27-28); oracle:
+// oracle/scn3d.py::sparse_conv_bwd.
+#ifndef WGR_TS
+#define WGR_TS 32
+#endif
+#ifndef WGR_PROBE
+#define WGR_PROBE 0   // timing probes (profiles/): 1 = staging only, 2 = no gathers (zero rows), 3 = neither
+#endif
+#define WGR_PROBE_NOCOMPUTE ((WGR_PROBE & 1) != 0)
+#define WGR_PROBE_NOGATHER ((WGR_PROBE & 2) != 0)
+// N consecutive floats from LDS as ONE access where the width allows (16-byte / 8-byte aligned by construction: the strides, the wave's
+// base and r N are multiples of 4 / 2): scalar reads of a row-of-4 layout collide four ways on the banks, ds_read_b128 does not
+template <int N>
+__device__ __forceinline__ void wgr_read(const float* __restrict__ p, float (&v)[N]) {
+  typedef float f32x2r __attribute__((ext_vector_type(2)));
+  if constexpr (N == 4) {
+    const f32x4r t = *reinterpret_cast<const f32x4r*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else if constexpr (N == 2) {
+    const f32x2r t = *reinterpret_cast<const f32x2r*>(p);
+    v[0] = t[0]; v[1] = t[1];
+  } else if constexpr (N == 6) {
+    const f32x2r t0 = *reinterpret_cast<const f32x2r*>(p), t1 = *reinterpret_cast<const f32x2r*>(p + 2), t2 = *reinterpret_cast<const f32x2r*>(p + 4);
+    v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1]; v[4] = t2[0]; v[5] = t2[1];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[i];
+  }
+}
+template <int MU, int NT, bool FULL>
+__device__ __forceinline__ void wgr_tile(f32x4r (&acc)[MU][NT], const float* __restrict__ pa, const float* __restrict__ pb, int sA, int sB, int mu_w) {
+#pragma unroll
+  for (int kk = 0; kk < WGR_TS / 8; ++kk) {   // (the wave's half of the tile's k-steps: pa / pb point at its first slot)
+    float a[MU], b[NT];
+    if constexpr (FULL) {
+      wgr_read<MU>(pa + kk * 4 * sA, a);
+    } else {
+#pragma unroll
+      for (int u = 0; u < MU; ++u) a[u] = u < mu_w ? pa[kk * 4 * sA + u] : 0.f;
+    }
+    wgr_read<NT>(pb + kk * 4 * sB, b);
+#pragma unroll
+    for (int u = 0; u < MU; ++u)
+      if (FULL || u < mu_w) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[t], acc[u][t], 0, 0, 0);
+      }
+  }
+}
+template <int MU, int NT>
+__global__ __launch_bounds__(512) void k_wgrad_run(const int* __restrict__ hdr, const int* __restrict__ idxA, const int* __restrict__ idxB, int K,
+                                                   int S, const float* __restrict__ Am, int ldA, int cin, const float* __restrict__ Bm, int ldB,
+                                                   int cout, int sA, int sB, float* __restrict__ slabs) {
+  constexpr int NA = (MU * WGR_TS + 31) / 32, NB = (NT * WGR_TS + 127) / 128;   // float4 gathers per thread (of 512) and tile
+  extern __shared__ float4 wgr_smem4[];
+  float* __restrict__ smem = reinterpret_cast<float*>(wgr_smem4);
+  __shared__ int s_rng[2];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = w8 & 3, kh = w8 >> 2;   // wave (w, kh): Cin blocks [w MU, w MU + MU), the k-steps of half kh of every tile
+  // piece blockIdx.x: pieces are numbered offset by offset (the K counts and starts are loaded side by side: a serial walk over the
+  // header costs every block -- the empty ones of the bound-sized grid too -- K dependent L2 round trips)
+  __shared__ int s_cnt[32], s_start[32];
+  if (tid < 32) { s_cnt[tid] = tid < K ? hdr[32 + tid] : 0; s_start[tid] = tid < K ? hdr[tid] : 0; }
+  __syncthreads();
+  if (tid == 0) {
+    int b = blockIdx.x, beg = 0, end = 0;
+    for (int o = 0; o < K; ++o) {
+      const int n = s_cnt[o], np = (n + S - 1) / S;
+      if (b < np) { beg = s_start[o] + b * S; end = min(s_start[o] + n, beg + S); break; }
+      b -= np;
+    }
+    s_rng[0] = beg; s_rng[1] = end;
+  }
+  __syncthreads();
+  const int beg = s_rng[0], end = s_rng[1];
+  if (end <= beg) return;   // (the grid is sized from the bound on the slots)
+  float* __restrict__ tA = smem;                        // [2][WGR_TS][sA]
+  float* __restrict__ tB = smem + 2 * WGR_TS * sA;      // [2][WGR_TS][sB]
+  const int c4A = cin >> 2, c4B = cout >> 2;
+  // staging map: float4 f = tid + 256 i of a tile -> (slot, float4 column), the same for every tile.  Every load and store below is
+  // UNCONDITIONAL (indices clamped, values selected, the float4s past the tile's end written to a per-thread dummy slot behind the
+  // tiles): a per-lane conditional load compiles to a branch around it and an s_waitcnt vmcnt(0) in front of every later use -- the
+  // first version of this kernel ran its gathers, its MFMAs and its LDS stores strictly one after the other (121 us = 48 + 45 + 22
+  // for the three parts alone, profiles/r5_wgrad_run.md).
+  float* __restrict__ dummy = smem + 2 * WGR_TS * (sA + sB) + tid * 4;
+  int slotA[NA], colA[NA], offA[NA], slotB[NB], colB[NB], offB[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int f = tid + 512 * i;
+    const bool ok = f < WGR_TS * c4A;
+    slotA[i] = ok ? f / c4A : WGR_TS + 1;   // (a slot past every piece's end: its index reads as -1, its row as zeros)
+    colA[i] = ok ? (f % c4A) << 2 : 0;
+    offA[i] = ok ? slotA[i] * sA + colA[i] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int f = tid + 512 * i;
+    const bool ok = f < WGR_TS * c4B;
+    slotB[i] = ok ? f / c4B : WGR_TS + 1;
+    colB[i] = ok ? (f % c4B) << 2 : 0;
+    offB[i] = ok ? slotB[i] * sB + colB[i] : -1;
+  }
+  int ia[2][NA], ib[2][NB];      // index registers of two tiles (the loads of one are issued IN FRONT of the row gathers that use the other's: waiting for them then leaves those gathers in flight)
+  f32x4r ra[2][NA], rb[2][NB];   // two tiles of rows in flight
+  unsigned vmask[2];             // which of them are rules (bit i: ra[i], bit 16 + i: rb[i])
+  unsigned imask[2] = {0, 0};    // which of the index registers lie inside the piece
+  const f32x4r zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int last = end - 1;
+#define WGR_IDX(T_, IS_)   /* raw entries + which of them count: combined when the rows are issued (an OR here would wait for the loads) */ \
+  {                                                                                                   \
+    const int s0_ = beg + (T_) * WGR_TS;                                                              \
+    unsigned m_ = 0;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                  \
+      const int s_ = s0_ + slotA[i];                                                                  \
+      ia[IS_][i] = idxA[min(s_, last)];                                                               \
+      m_ |= (slotA[i] <= WGR_TS && s_ < end) ? (1u << i) : 0u;                                        \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
+      const int s_ = s0_ + slotB[i];                                                                  \
+      ib[IS_][i] = idxB[min(s_, last)];                                                               \
+      m_ |= (slotB[i] <= WGR_TS && s_ < end) ? (1u << (16 + i)) : 0u;                                 \
+    }                                                                                                 \
+    imask[IS_] = m_;                                                                                  \
+  }
+#define WGR_ROWS(SET_, IS_)   /* (a padding slot's row: row 0 is loaded, dropped when the set is stored -- a select here would wait for the load) */ \
+  {                                                                                                   \
+    unsigned m_ = 0;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                  \
+      ra[SET_][i] = *reinterpret_cast<const f32x4r*>(Am + (int64_t)max(ia[IS_][i], 0) * ldA + colA[i]);  \
+      m_ |= (ia[IS_][i] >= 0 && ((imask[IS_] >> i) & 1u) && !WGR_PROBE_NOGATHER) ? (1u << i) : 0u;              \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
+      rb[SET_][i] = *reinterpret_cast<const f32x4r*>(Bm + (int64_t)max(ib[IS_][i], 0) * ldB + colB[i]);  \
+      m_ |= (ib[IS_][i] >= 0 && ((imask[IS_] >> (16 + i)) & 1u) && !WGR_PROBE_NOGATHER) ? (1u << (16 + i)) : 0u; \
+    }                                                                                                 \
+    vmask[SET_] = m_;                                                                                 \
+  }
+#define WGR_STORE(SET_)   /* rows of register set SET_ -> LDS buffer SET_ */                          \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                    \
+      *reinterpret_cast<f32x4r*>(offA[i] >= 0 ? tA + (SET_) * WGR_TS * sA + offA[i] : dummy) = ((vmask[SET_] >> i) & 1u) ? ra[SET_][i] : zero4; \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                    \
+      *reinterpret_cast<f32x4r*>(offB[i] >= 0 ? tB + (SET_) * WGR_TS * sB + offB[i] : dummy) = ((vmask[SET_] >> (16 + i)) & 1u) ? rb[SET_][i] : zero4; \
+  }
+  const int cinb = cin >> 4;
+  const int mu_w = min(MU, max(cinb - w * MU, 0));   // Cin blocks of this wave (wave-uniform)
+  const int base_w = w * MU * 16;
+  f32x4r acc[MU][NT];
+#pragma unroll
+  for (int u = 0; u < MU; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[u][t] = zero4;
+  const int ntile = (end - beg + WGR_TS - 1) / WGR_TS;
+  // pipeline: LDS buffer t & 1 holds tile t, register set (t + 1) & 1 the rows of tile t + 1 (in flight), the index registers tile t + 2
+  WGR_IDX(0, 0);
+  WGR_IDX(1, 1);   // (tiles past the piece's end: every index -1, zero rows -- issued all the same, the loop body has no branch)
+  WGR_ROWS(0, 0);
+  WGR_IDX(2, 0);
+  WGR_ROWS(1, 1);
+  WGR_STORE(0);
+  __syncthreads();
+#define WGR_STEP(T_, CUR_)   /* CUR_ = T_ & 1 (static: the register sets are indexed at compile time) */ \
+  {                                                                                                   \
+    WGR_IDX((T_) + 3, (CUR_) ^ 1);                  /* in front of the gathers: see ia */                    \
+    WGR_ROWS(CUR_, CUR_);                           /* rows of tile T_ + 2 into the set tile T_ left */     \
+    if (WGR_PROBE_NOCOMPUTE) {}                                                                       \
+    else if (mu_w == MU)                                                                              \
+      wgr_tile<MU, NT, true>(acc, tA + ((CUR_) * WGR_TS + kh * (WGR_TS / 2) + q) * sA + base_w + r * MU, tB + ((CUR_) * WGR_TS + kh * (WGR_TS / 2) + q) * sB + r * NT, sA, sB, MU); \
+    else if (mu_w > 0)                                                                                \
+      wgr_tile<MU, NT, false>(acc, tA + ((CUR_) * WGR_TS + kh * (WGR_TS / 2) + q) * sA + base_w + r * mu_w, tB + ((CUR_) * WGR_TS + kh * (WGR_TS / 2) + q) * sB + r * NT, sA, sB, mu_w); \
+    __builtin_amdgcn_sched_barrier(0);              /* (nothing of the next step -- its address arithmetic waits for this step's index loads -- moves up here) */ \
+    WGR_STORE((CUR_) ^ 1);                          /* tile T_ + 1: issued a whole tile ago */              \
+    __syncthreads();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  // lane (r, q): A[m = r][k = q] = in-row of slot 4 kk + q, channel base_w + r mu_w + u (block u); B[k = q][n = r] = its NT
+  // consecutive output-gradient channels r NT + t.  A wave with all MU blocks takes the branch-free body (every LDS read of the
+  // tile can be scheduled ahead of the MFMAs); the last wave of a Cin that is not a multiple of 64 MU / 4 the guarded one.
+  for (int tile = 0; tile < ntile; tile += 2) {
+    WGR_STEP(tile, 0);
+    if (tile + 1 < ntile) WGR_STEP(tile + 1, 1);
+  }
+#undef WGR_STEP
+#undef WGR_IDX
+#undef WGR_ROWS
+#undef WGR_STORE
+  // the two k-halves meet in LDS (the tiles are dead: the last step ended with a barrier): waves (w, 1) write, waves (w, 0) add
+  // [block (u, t)][element j][lane] floats per wave w: 16 MU NT lanes-rows of 256 bytes
+  {
+    float* __restrict__ cmb = smem + w * (MU * NT * 4 * 64) + lane;
+    if (kh == 1) {
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cmb[((u * NT + t) * 4 + j) * 64] = acc[u][t][j];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int u = 0; u < MU; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[u][t][j] += cmb[((u * NT + t) * 4 + j) * 64];
+  }
+  // D[m = 4 q + j][n = r] of block (u, t) = dW[channel base_w + (4 q + j) mu_w + u][r NT + t]
+  float* __restrict__ sl = slabs + (int64_t)blockIdx.x * cin * cout;
+#pragma unroll
+  for (int u = 0; u < MU; ++u)
+    if (u < mu_w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = base_w + (4 * q + j) * mu_w + u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sl[(int64_t)ci * cout + r * NT + t] = acc[u][t][j];
+      }
+    }
+}
+
+// dW[o][e] (+)= the slabs of offset o's pieces, in piece order: block = 64 elements (16 float4 lanes: 256-byte runs) x 16 piece-lanes
+// that sum strided pieces, then a fixed-order combine (as k_reduce_slabs: deterministic)
+__global__ __launch_bounds__(256) void k_wgrad_run_reduce(const int* __restrict__ hdr, int K, int S, const float* __restrict__ slabs, int n_e,
+                                                          float* __restrict__ dw, int accumulate) {
+  __shared__ f32x4r red[16][17];
+  __shared__ int s_p[2];
+  __shared__ int s_np[32];
+  const int o = blockIdx.y;
+  if (threadIdx.x < 32) s_np[threadIdx.x] = (int)threadIdx.x < K ? (hdr[32 + threadIdx.x] + S - 1) / S : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int p0 = 0;
+    for (int k = 0; k < o; ++k) p0 += s_np[k];
+    s_p[0] = p0; s_p[1] = s_np[o];
+  }
+  __syncthreads();
+  const int p0 = s_p[0], np = s_p[1];
+  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int i = (blockIdx.x * 16 + el) * 4;   // (n_e = cin cout is a multiple of 256)
+  f32x4r s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n_e) {
+    const f32x4r* __restrict__ sp = reinterpret_cast<const f32x4r*>(slabs + (int64_t)p0 * n_e + i);
+    const int64_t step = (int64_t)n_e >> 2;
+#pragma unroll 4
+    for (int c = cl; c < np; c += 16) s += sp[c * step];
+  }
+  red[cl][el] = s;
+  __syncthreads();
+  if (cl == 0 && i < n_e) {
+    float* __restrict__ d = dw + (int64_t)o * n_e + i;   // (a parameter's gradient inside a flat buffer: 4-byte aligned is all that is promised)
+    f32x4r t = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) t = (f32x4r){d[0], d[1], d[2], d[3]};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][el];
+    d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
+  }
+}
+
+static inline int wgr_stride(int c, int n16) {   // smallest row stride >= c with stride % 64 == 16 n16 % 64: the MFMA-layout reads of the four slots of a k-step fall into different banks
+  const int want = (16 * n16) & 63;
+  int s = (c + 3) & ~3;
+  while ((s & 63) != want) s += 4;
+  return s;
+}
+struct WgrPlan { int mu, nt, S, sA, sB; int64_t npieces; size_t lds; };
+static inline bool wgr_plan(int K, int64_t num_out, int cin, int cout, int one_rule_per_row, WgrPlan* p) {
+  if (K <= 0 || K > 27 || cin < 16 || cin > 256 || cin % 16 || cout < 16 || cout > 112 || cout % 16) return false;
+  const int cinb = cin / 16;
+  p->mu = (cinb + 3) / 4;
+  p->nt = cout / 16;
+  p->sA = wgr_stride(cin, p->mu);
+  p->sB = wgr_stride(cout, p->nt);
+  p->lds = (size_t)2 * WGR_TS * (p->sA + p->sB) * sizeof(float) + 512 * 16;   // two tiles of each operand + the dummy slots
+  const size_t cmb = (size_t)4 * p->mu * p->nt * 4 * 64 * sizeof(float);         // (the k-halves' combine buffer lies over the tiles)
+  if (p->lds < cmb) p->lds = cmb;
+  // piece size: ~3 pieces per CU at the expected rule count (unknown on the host: ~9 rules per row on the 27-offset tables, exactly one
+  // per row on the deconvolution tables), at least 128 slots, and no more slab than 128 MiB at the BOUND on the slots
+  const int ncu = mopa_cu_count() > 0 ? mopa_cu_count() : 256;
+  const int64_t rules_est = one_rule_per_row ? num_out : K == 27 ? 9 * num_out : 5 * num_out / 2;
+  int64_t S = (rules_est / (3 * ncu) + WGR_TS - 1) / WGR_TS * WGR_TS;
+  if (S < 128) S = 128;
+  if (S > 2048) S = 2048;
+  static const int s_env = getenv("MOPA_WGR_S") ? atoi(getenv("MOPA_WGR_S")) : 0;   // tuning probe
+  if (s_env > 0) S = s_env;
+  const int64_t bound = one_rule_per_row ? num_out + (int64_t)K * RUN_PAD : run_cap(K, num_out);   // slots that can hold a rule
+  const int64_t per = (int64_t)cin * cout * sizeof(float);
+  while ((bound / S + K) * per > (128ll << 20)) S += WGR_TS;
+  p->S = (int)S;
+  p->npieces = bound / S + K;
+  return true;
+}
+// Which weight gradients take the run lists (profiles/r5_wgrad_run.md: us per launch of both kernels at 8 and 16 scans, every layer
+// shape): the 27-offset layers from 48 input channels on (below, the old kernel's one-wave-per-(offset, chunk) walk is as fast: the
+// GEMM is small against the table scan either way) up to 192 (224: 94 KB of LDS tiles, one block per CU) -- unless more than 30 % of
+// the four Cin wave slots are empty (Cin = 80: blocks 2, 2, 1, 0) on a short level; the 8-offset tables (one rule per fine row) from
+// 40,000 rows and 48 channels on.  MOPA_SPCONV_WGRAD_RUN=0: never, 2: whenever the shape is supported.
+MOPA_API int mopa_spconv_wgrad_run_wanted(int32_t K, int32_t num_out, int32_t cin, int32_t cout, int32_t one_rule_per_row) {
+  static const int mode = getenv("MOPA_SPCONV_WGRAD_RUN") ? atoi(getenv("MOPA_SPCONV_WGRAD_RUN")) : 1;
+  WgrPlan p;
+  if (!mode || !wgr_plan(K, num_out, cin, cout, one_rule_per_row, &p)) return 0;
+  if (mode == 2) return 1;
+  if (one_rule_per_row) return num_out >= 40000 && (cin >= 48 || cout >= 48);
+  if (K != 27 || cin < 48 || cin > 192) return 0;
+  const int slots = 4 * p.mu, used = cin / 16;
+  return 10 * (slots - used) <= 3 * slots || num_out >= 30000;
+}
+MOPA_API size_t mopa_spconv_wgrad_run_workspace_bytes(int32_t K, int32_t num_out, int32_t cin, int32_t cout, int32_t one_rule_per_row) {
+  WgrPlan p;
+  if (!wgr_plan(K, num_out, cin, cout, one_rule_per_row, &p)) return 0;
+  return align_up((size_t)p.npieces * cin * cout * sizeof(float), 256);
+}
+
+template <int MU>
+static int launch_wgrad_run(const WgrPlan& p, const int* hdr, const int* ia, const int* ib, int K, const float* A, int ldA, int cin, const float* B,
+                            int ldB, int cout, float* slabs, hipStream_t st) {
+  typedef void (*kern_t)(const int*, const int*, const int*, int, int, const float*, int, int, const float*, int, int, int, int, float*);
+  static const kern_t kerns[7] = {k_wgrad_run<MU, 1>, k_wgrad_run<MU, 2>, k_wgrad_run<MU, 3>, k_wgrad_run<MU, 4>,
+                                  k_wgrad_run<MU, 5>, k_wgrad_run<MU, 6>, k_wgrad_run<MU, 7>};
+  static std::atomic<bool> attr[64][7];
+  const int dev = mopa_device_index();
+  if (dev < 0) return MOPA_ERR_LAUNCH;
+  const kern_t k = kerns[p.nt - 1];
+  if (p.lds > 64 * 1024 && !attr[dev][p.nt - 1].load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return MOPA_ERR_LAUNCH;
+    attr[dev][p.nt - 1].store(true, std::memory_order_release);
+  }
+  k<<<(unsigned)p.npieces, 512, p.lds, st>>>(hdr, ia, ib, K, p.S, A, ldA, cin, B, ldB, cout, p.sA, p.sB, slabs);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
+// dweight[K][cin][cout] (+= if accumulate) from in[*, cin] and dout[*, cout] over the rules of the table the run-major rulebook `runs` was
+// built from (num_out = its output rows).  swap == 0: `in` rows are the rules' input rows and `dout` rows their output rows; swap == 1
+// (the stride-2 convolution's gradient on its deconvolution table: one_rule_per_row): the other way round.  ws >=
+// mopa_spconv_wgrad_run_workspace_bytes.  Rows 16-byte aligned (ld % 4 == 0).
+MOPA_API int mopa_spconv_bwd_weight_run(const int32_t* runs, int32_t K, int32_t num_out, int32_t one_rule_per_row, int32_t swap, const float* in,
+                                        int32_t ld_in, int32_t cin, const float* dout, int32_t ld_dout, int32_t cout, float* dweight,
+                                        int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+  WgrPlan p;
+  if (!runs || !in || !dout || !dweight || num_out <= 0 || !wgr_plan(K, num_out, cin, cout, one_rule_per_row, &p)) return MOPA_ERR_ARG;
+  if (ld_in < cin || ld_dout < cout || (ld_in & 3) || (ld_dout & 3) || (((uintptr_t)in | (uintptr_t)dout | (uintptr_t)ws) & 15)) return MOPA_ERR_ARG;
+  if (!ws || ws_bytes < mopa_spconv_wgrad_run_workspace_bytes(K, num_out, cin, cout, one_rule_per_row)) return MOPA_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t cap = run_cap(K, num_out);
+  const int* hdr = runs;
+  const int* run_in = runs + RUN_HDR;
+  const int* run_out = run_in + cap;
+  const int* ia = swap ? run_out : run_in;
+  const int* ib = swap ? run_in : run_out;
+  float* slabs = (float*)ws;
+  int rc;
+  switch (p.mu) {
+    case 1: rc = launch_wgrad_run<1>(p, hdr, ia, ib, K, in, ld_in, cin, dout, ld_dout, cout, slabs, st); break;
+    case 2: rc = launch_wgrad_run<2>(p, hdr, ia, ib, K, in, ld_in, cin, dout, ld_dout, cout, slabs, st); break;
+    case 3: rc = launch_wgrad_run<3>(p, hdr, ia, ib, K, in, ld_in, cin, dout, ld_dout, cout, slabs, st); break;
+    default: rc = launch_wgrad_run<4>(p, hdr, ia, ib, K, in, ld_in, cin, dout, ld_dout, cout, slabs, st); break;
+  }
+  if (rc) return rc;
+  const int n_e = cin * cout;
+  k_wgrad_run_reduce<<<dim3((unsigned)cdiv64(n_e, 64), (unsigned)K), 256, 0, st>>>(hdr, K, p.S, slabs, n_e, dweight, accumulate);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}

@@ -413,6 +413,31 @@ def spconv_bwd_weight(nbr: torch.Tensor, x: View, dout: View, dw: torch.Tensor, 
          int(accumulate), ptr(ws), ws.numel(), stream())
 
 
+def spconv_bwd_weight_of(geom, kind: str, l: int, x: View, dout: View, dw: torch.Tensor, accumulate: bool = False):
+    """The weight gradient of the convolution (kind, level l): on the run-major rulebook where csrc/sprun.hip's dispatcher wants it
+    (mopa_spconv_wgrad_run_wanted) -- the table's own, or for the stride-2 convolution the deconvolution table's with the two index
+    lists swapped -- else on the dense table.  Mirrors csrc/scn_exec.hip::wgrad_plan_of (the two paths give the same bits)."""
+    t = geom.rule_table(kind, l)
+    if kind != "nin":
+        rt, swap = (t, 0)
+        r = geom.runs(rt)
+        if r is None and kind == "down":
+            rt, swap = geom.up[l], 1
+            r = geom.runs(rt)
+            if r is not None and not r[1]:
+                r = None
+        if r is not None:
+            buf, one = r
+            K, A = rt.shape
+            if query("mopa_spconv_wgrad_run_wanted", K, A, x.C, dout.C, one):
+                assert dw.shape == (K, x.C, dout.C)
+                ws = _ws(query("mopa_spconv_wgrad_run_workspace_bytes", K, A, x.C, dout.C, one), dw.device)
+                call("mopa_spconv_bwd_weight_run", ptr(buf), K, A, one, swap, x.p, x.ld, x.C, dout.p, dout.ld, dout.C, ptr(dw),
+                     int(accumulate), ptr(ws), ws.numel(), stream())
+                return
+    spconv_bwd_weight(t, x, dout, dw, accumulate=accumulate)
+
+
 def bn_row_groups(geom, level: int):
     """Row ranges BatchNorm treats as separate batches at `level`: [(0, A)] or, for a geometry built with group_points,
     [(0, s1), (s1, A)] / [(0, s1), (s1, s2), (s2, A)] (same rule as csrc/scn_exec.hip::bn_groups)."""
@@ -1014,7 +1039,7 @@ class SCNNetFunction(torch.autograd.Function):
                 t = geom.rule_table(kind, l)
                 if kind == "nin":
                     w, dw = w.view(1, w.shape[0], w.shape[1]), dw.view(1, dw.shape[0], dw.shape[1])
-                spconv_bwd_weight(t, views[src.key], dout, dw, accumulate=wacc)
+                spconv_bwd_weight_of(geom, kind, l, views[src.key], dout, dw, accumulate=wacc)
                 if src is prog.x0 and not ctx.feats_needs_grad:
                     continue
                 dx = gview(dx_ref)

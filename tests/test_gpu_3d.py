@@ -243,6 +243,93 @@ def test_offset_major_convolution_equals_the_table_kernel_bit_for_bit(cin, cout)
         assert torch.equal(first, ov.dense())
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (48, 48), (64, 32), (80, 96), (128, 64), (160, 80), (192, 96), (224, 112)])
+def test_weight_gradient_on_the_run_lists_vs_oracle_and_the_table_kernel(cin, cout):
+    """mopa_spconv_bwd_weight_run (csrc/sprun.hip: pieces of equal rule count per filter offset, LDS-staged Cin x Cout GEMM, slabs
+    summed in piece order) against the autograd of the fp64 oracle (oracle/scn3d.py::sparse_conv) and against the dense-table kernel
+    mopa_spconv_bwd_weight: on the 27-offset table, on the deconvolution table (one rule per row) and -- lists swapped -- for the
+    stride-2 convolution whose own table has no run-major rulebook; inputs as channel slices of wider buffers, the gradient written into
+    a buffer that is only 4-byte aligned, accumulation onto a previous value, run to run the same bits (no atomics), and Cin values
+    that leave some of the block's wave slots empty (80: blocks 2, 2, 1, 0)."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd._lib import call, ptr, query, stream
+    c = _cloud(6, n=6000)
+    g, o = _geoms(c, 2, 64)
+    dev = "cuda"
+    rng = np.random.Generator(np.random.PCG64(cin * 31 + cout))
+    for name, tab_o, run_tab, one, swap, A_in in (("subm", o.nbr27[0], g.nbr27[0], 0, 0, o.num_active[0]),
+                                                  ("up", o.up[0], g.up[0], 1, 0, o.num_active[1]),
+                                                  ("down", o.ch[0], g.up[0], 1, 1, o.num_active[0])):
+        K, A_out = tab_o.shape
+        x = torch.from_numpy(rng.standard_normal((A_in, cin), dtype=np.float32))
+        gout = torch.from_numpy(rng.standard_normal((A_out, cout), dtype=np.float32))
+        wr = torch.zeros(K, cin, cout, dtype=torch.float64, requires_grad=True)
+        (scn3d.sparse_conv(x.double(), tab_o, wr) * gout.double()).sum().backward()
+        xin = torch.zeros(A_in, cin + 8, device=dev)
+        xin[:, 4:4 + cin] = x.to(dev)
+        gin = torch.zeros(A_out, cout + 8, device=dev)
+        gin[:, 4:4 + cout] = gout.to(dev)
+        xv, gv = s3.View(xin, 4, cin), s3.View(gin, 4, cout)
+        runs = g.runs(run_tab)
+        assert runs is not None and runs[1] == one
+        Kr, Ar = run_tab.shape
+        ws = torch.empty(query("mopa_spconv_wgrad_run_workspace_bytes", Kr, Ar, cin, cout, one), dtype=torch.uint8, device=dev)
+        flat = torch.full((K * cin * cout + 2,), 3.0, device=dev)
+        dw = flat[1:1 + K * cin * cout]                              # 4-byte aligned only
+        prev = torch.from_numpy(rng.standard_normal(K * cin * cout).astype(np.float32)).to(dev)
+
+        def run(acc):
+            call("mopa_spconv_bwd_weight_run", ptr(runs[0]), Kr, Ar, one, swap, xv.p, xv.ld, cin, gv.p, gv.ld, cout, dw.data_ptr(), int(acc),
+                 ptr(ws), ws.numel(), stream())
+
+        run(False)
+        got = dw.clone()
+        assert float(flat[0]) == 3.0 and float(flat[-1]) == 3.0          # neighbours untouched
+        sw = max(1.0, float(wr.grad.abs().max()))
+        np.testing.assert_allclose(got.cpu().numpy().reshape(K, cin, cout), wr.grad.float().numpy(), rtol=2e-4, atol=5e-5 * sw, err_msg=name)
+        run(False)
+        assert torch.equal(dw, got), name                                # deterministic
+        dw.copy_(prev)
+        run(True)
+        np.testing.assert_allclose((dw - prev).cpu().numpy(), got.cpu().numpy(), rtol=0, atol=2e-6 * sw + 1e-6 * float(prev.abs().max()))
+        # the dense-table kernel on the layer's own table
+        tab_g = {"subm": g.nbr27[0], "up": g.up[0], "down": g.ch[0]}[name]
+        ref = torch.empty(K, cin, cout, device=dev)
+        s3.spconv_bwd_weight(tab_g, xv, gv, ref)
+        np.testing.assert_allclose(got.cpu().numpy().reshape(K, cin, cout), ref.cpu().numpy(), rtol=0, atol=2e-5 * sw, err_msg=name)
+
+
+def test_weight_gradient_dispatch_native_executor_equals_python_walk(monkeypatch):
+    """The native executor (csrc/scn_exec.hip::wgrad_plan_of) and the Python walk (sparse3d.spconv_bwd_weight_of) choose the weight
+    gradient's kernel per layer by the same rule (mopa_spconv_wgrad_run_wanted: here the 64- to 192-channel 27-offset layers take the
+    run lists, the rest the dense table) and give the same bits for every parameter gradient."""
+    from mopa_amd import sparse3d as s3, synth
+    from mopa_amd.config import default_cfg
+    from mopa_amd.models.build import build_model_3d
+    batch = synth.make_batch(2, H=16, W=16)
+    calls = []
+    inner = s3.call
+    monkeypatch.setattr(s3, "call", lambda name, *a: (calls.append(name), inner(name, *a))[1])
+
+    def run(native):
+        monkeypatch.setattr(s3, "NATIVE", native)
+        torch.manual_seed(3)
+        m = build_model_3d(default_cfg())[0].cuda().train()
+        out = m(batch)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        (out["seg_logit"] * torch.randn(out["seg_logit"].shape, device="cuda", generator=g)).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ga = run(True)
+    n0 = calls.count("mopa_spconv_bwd_weight_run")
+    gb = run(False)
+    assert n0 == 0   # (native: one C-ABI call per pass)
+    assert calls.count("mopa_spconv_bwd_weight_run") >= 5 and calls.count("mopa_spconv_bwd_weight") >= 10
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+
+
 def test_dispatcher_sends_the_matrix_bound_layers_to_the_offset_major_kernel():
     """mopa_spconv_run_wanted: the rule written in csrc/sprun.hip (measured table: profiles/r5_spconv_run.md)."""
     from mopa_amd._lib import query

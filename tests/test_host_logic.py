@@ -289,3 +289,24 @@ def test_dispatcher_follows_the_measured_algorithm_table():
             # where BatchNorm normalises over few samples), not a speed choice; 128 -> 128 at 6,000 tiles sits between the two forms
             slack = 1.30 if r["chosen"][role] == "F2" else 1.10
             assert ratio <= slack, (r["res"], r["B"], r["layer"], role, ratio)
+
+
+def test_weight_gradient_dispatcher_follows_the_measured_table():
+    """mopa_spconv_wgrad_run_wanted (csrc/sprun.hip): the rule read off profiles/r5_wgrad_run.md -- every (table, rows, Cin, Cout) of the
+    8- and 16-scan tables where the run-list kernel measured faster than the dense-table one by 5 % or more is sent to it, the ones
+    where it measured slower are not.  (A size query: no GPU needed.)"""
+    from mopa_amd._lib import query
+    want = lambda *a: query("mopa_spconv_wgrad_run_wanted", *a)
+    # 27-offset tables: (rows, cin, cout) -> picked
+    for rows, cin, cout, pick in ((257465, 16, 16, 0), (257465, 32, 16, 0), (193135, 32, 32, 0), (193135, 64, 32, 1), (103554, 48, 48, 1),
+                                  (103554, 96, 48, 1), (49022, 64, 64, 1), (49022, 128, 64, 1), (19312, 80, 80, 0), (39360, 80, 80, 1),
+                                  (19312, 160, 80, 1), (6789, 96, 96, 1), (6789, 192, 96, 1), (2330, 112, 112, 1), (2330, 224, 112, 0),
+                                  (4782, 224, 112, 0), (99391, 128, 64, 1), (207867, 96, 48, 1)):
+        assert want(27, rows, cin, cout, 0) == pick, (rows, cin, cout)
+    # 8-offset tables (rows = fine rows of the deconvolution table; the stride-2 convolution's gradient runs on the same lists)
+    for rows, cin, cout, pick in ((257465, 32, 16, 0), (257465, 16, 32, 0), (193135, 48, 32, 1), (193135, 32, 48, 1), (103554, 64, 48, 1),
+                                  (49022, 80, 64, 1), (49022, 64, 80, 1), (19312, 96, 80, 0), (39360, 96, 80, 0), (6789, 112, 96, 0),
+                                  (515277, 32, 16, 0), (388842, 48, 32, 1)):
+        assert want(8, rows, cin, cout, 1) == pick, (rows, cin, cout)
+    assert want(27, 49022, 20, 64, 0) == 0 and want(27, 49022, 64, 120, 0) == 0 and want(27, 49022, 272, 64, 0) == 0   # unsupported shapes
+    assert query("mopa_spconv_wgrad_run_workspace_bytes", 27, 49022, 128, 64, 0) >= 27 * 128 * 64 * 4
