@@ -21,6 +21,7 @@
 #include "common.h"
 #include "sprun_pack.h"
 #include <atomic>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -741,13 +742,17 @@ static inline bool wgr_plan(int K, int64_t num_out, int cin, int cout, int one_r
   p->lds = (size_t)2 * WGR_TS * (p->sA + p->sB) * sizeof(float) + 512 * 16;   // two tiles of each operand + the dummy slots
   const size_t cmb = (size_t)4 * p->mu * p->nt * 4 * 64 * sizeof(float);         // (the k-halves' combine buffer lies over the tiles)
   if (p->lds < cmb) p->lds = cmb;
-  // piece size: ~3 pieces per CU at the expected rule count (unknown on the host: ~9 rules per row on the 27-offset tables, exactly one
-  // per row on the deconvolution tables), at least 128 slots, and no more slab than 128 MiB at the BOUND on the slots
+  // piece size S (slots): a piece's time grows with its steps (S / 32, strictly serial) and the kernel's fixed costs with the number of
+  // pieces (prologue, slab, reduce, the tail of the last round), so the measured optimum follows sqrt(rules) -- 128 at 21 k expected rules,
+  // 512-672 at 125-350 k, 1024 from 900 k on (profiles/r5_wgrad_run.md, "piece size") -- with the rule count estimated on the host (~9 per
+  // row on the 27-offset tables); the 8-offset tables (one rule per row, small slabs): three pieces per CU, from 128 slots.  And no
+  // more slab than 128 MiB at the BOUND on the slots.
   const int ncu = mopa_cu_count() > 0 ? mopa_cu_count() : 256;
   const int64_t rules_est = one_rule_per_row ? num_out : K == 27 ? 9 * num_out : 5 * num_out / 2;
-  int64_t S = (rules_est / (3 * ncu) + WGR_TS - 1) / WGR_TS * WGR_TS;
+  int64_t S = one_rule_per_row ? rules_est / (3 * ncu) : (int64_t)(1.2 * sqrt((double)rules_est));
+  S = (S + WGR_TS - 1) / WGR_TS * WGR_TS;
   if (S < 128) S = 128;
-  if (S > 2048) S = 2048;
+  if (S > 1024) S = 1024;
   static const int s_env = getenv("MOPA_WGR_S") ? atoi(getenv("MOPA_WGR_S")) : 0;   // tuning probe
   if (s_env > 0) S = s_env;
   const int64_t bound = one_rule_per_row ? num_out + (int64_t)K * RUN_PAD : run_cap(K, num_out);   // slots that can hold a rule
