@@ -1112,14 +1112,14 @@ def main():
         tj = {}
         if joint and os.path.exists(tpath):                                      # of this same command (profiles/traffic.py)
             tj = json.load(open(tpath))
-            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv") if k in tj]
+            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32") if k in tj]
             if fam:
                 traffic = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": f"{os.path.relpath(tpath, ROOT)} at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out + k_wino4_conv (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
+                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out + k_wino4_conv / k_wino4_conv32 (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
