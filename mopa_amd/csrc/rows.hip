@@ -275,7 +275,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
       sc[j] = stats[cq * 4 + j]; sh[j] = stats[C + cq * 4 + j];
       mu[j] = stats[2 * C + cq * 4 + j]; is[j] = stats[3 * C + cq * 4 + j];
     }
-    for (int row = rbeg + rl; row < rend; row += RL) {
+    // four rows of loads in flight per thread (the sums take the rows in the same order as a rolled loop: same bits)
+    int row = rbeg + rl;
+    for (; row + 3 * RL < rend; row += 4 * RL) {
+      float4 xv[4], gv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const float4*>(x + (int64_t)(row + u * RL) * ldx + cq * 4);
+        gv[u] = *reinterpret_cast<const float4*>(dy + (int64_t)(row + u * RL) * ld_dy + cq * 4);
+        yv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ymask) yv[u] = *reinterpret_cast<const float4*>(ymask + (int64_t)(row + u * RL) * ld_ym + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, ys[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dz = bn_dz(gs[j], xs[j], sc[j], sh[j], leak, act, ymask ? ys : nullptr, j);
+          s[j] += dz;
+          ss[j] += dz * ((xs[j] - mu[j]) * is[j]);
+        }
+      }
+    }
+    for (; row < rend; row += RL) {
       const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + cq * 4);
       const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)row * ld_dy + cq * 4);
       float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """F(4x4) conv: input transform + fused GEMM/output kernel (or batched GEMM + output transform) vs the ONE-kernel convolution
 (mopa_wino4_conv), per layer shape of the joint step (B = 16 by default); checks that the two agree.
-Usage: python profiles/bench_wino_direct.py [B]"""
+Usage: python profiles/bench_wino_direct.py [B]     (WANT_V=1: both paths keep V -- the training forward role)"""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())
@@ -41,7 +41,7 @@ for name, cin, cout, H, W in shapes:
         call(("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f")[lay], ptr(w), cout, cin, 0, ptr(U), stream())
         o = torch.zeros(B * H * W, cout, device="cuda")
         # want_v=False: the backward-data role (the default use of the one-kernel path) keeps no V
-        res.append(timed(lambda: dense2d.wino_conv(ptr(x), cin, B, H, W, cin, cout, U, bias, ptr(o), cout, F=4, want_v=not direct)))
+        res.append(timed(lambda: dense2d.wino_conv(ptr(x), cin, B, H, W, cin, cout, U, bias, ptr(o), cout, F=4, want_v=(not direct) or os.environ.get("WANT_V", "0") != "0")))
         outs.append(o)
     err = float((outs[0] - outs[1]).abs().max()) / float(outs[0].abs().max())
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
