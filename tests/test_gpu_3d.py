@@ -299,6 +299,36 @@ def test_weight_gradient_on_the_run_lists_vs_oracle_and_the_table_kernel(cin, co
         np.testing.assert_allclose(got.cpu().numpy().reshape(K, cin, cout), ref.cpu().numpy(), rtol=0, atol=2e-5 * sw, err_msg=name)
 
 
+@pytest.mark.parametrize("n,batch", [(7, 1), (60, 2), (700, 3)])
+def test_weight_gradient_on_the_run_lists_tiny_geometries(n, batch):
+    """mopa_spconv_bwd_weight_run where pieces, tiles and filter offsets are mostly empty: 7 / 60 / 700 points (fewer rows than one
+    32-slot tile; offsets without a single rule; runs that are all padding), 64 -> 48 and 80 -> 16 channels, every table kind -- against
+    the dense-table kernel."""
+    from mopa_amd import sparse3d as s3
+    from mopa_amd._lib import call, ptr, query, stream
+    c = _cloud(9 + n, n=n, size=24, batch=batch)
+    g, o = _geoms(c, 2, 32)
+    dev = "cuda"
+    rng = np.random.Generator(np.random.PCG64(n))
+    for cin, cout in ((64, 48), (80, 16)):
+        for name, tab_g, run_tab, one, swap, A_in in (("subm", g.nbr27[0], g.nbr27[0], 0, 0, o.num_active[0]),
+                                                      ("up", g.up[0], g.up[0], 1, 0, o.num_active[1]),
+                                                      ("down", g.ch[0], g.up[0], 1, 1, o.num_active[0])):
+            K, A_out = tab_g.shape
+            x = torch.from_numpy(rng.standard_normal((A_in, cin), dtype=np.float32)).to(dev)
+            gout = torch.from_numpy(rng.standard_normal((A_out, cout), dtype=np.float32)).to(dev)
+            xv, gv = s3.View(x), s3.View(gout)
+            ref = torch.empty(K, cin, cout, device=dev)
+            s3.spconv_bwd_weight(tab_g, xv, gv, ref)
+            runs = g.runs(run_tab)
+            Kr, Ar = run_tab.shape
+            ws = torch.empty(query("mopa_spconv_wgrad_run_workspace_bytes", Kr, Ar, cin, cout, one), dtype=torch.uint8, device=dev)
+            dw = torch.full((K, cin, cout), float("nan"), device=dev)
+            call("mopa_spconv_bwd_weight_run", ptr(runs[0]), Kr, Ar, one, swap, xv.p, xv.ld, cin, gv.p, gv.ld, cout, ptr(dw), 0, ptr(ws), ws.numel(), stream())
+            scale = max(1.0, float(ref.abs().max()))
+            np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5 * scale, err_msg=f"{name} {cin}->{cout}")
+
+
 def test_weight_gradient_dispatch_native_executor_equals_python_walk(monkeypatch):
     """The native executor (csrc/scn_exec.hip::wgrad_plan_of) and the Python walk (sparse3d.spconv_bwd_weight_of) choose the weight
     gradient's kernel per layer by the same rule (mopa_spconv_wgrad_run_wanted: here the 64- to 192-channel 27-offset layers take the
