@@ -162,6 +162,8 @@ SIGNATURES = {
     "mopa_adam_flat": ("i", "pppplffffffffp"),
 }
 
+from ._host_args import HOST_PARAMS  # noqa: E402  (generated: which arguments of an entry point are host pointers)
+
 _lib = None
 
 
@@ -219,11 +221,14 @@ class CommandList:
     """A recorded sequence of this library's entry points (+ event hand-overs between two streams) that mopa_exec_replay
     (csrc/exec2d.hip) walks in ONE call: `words` = [op, nargs, args...]* as int64; integers and pointers as they are, float / double
     as the bits of a double.  The stream arguments (always the last one) are kept as slots: `main` / `side` word indices that
-    replay() patches with the streams of the replaying pass.  Host arrays passed by pointer (HOST_ARGS: the 25-int geometry of the
-    implicit-GEMM calls, pointer tables) are copied into `blob`, which lives as long as the list."""
+    replay() patches with the streams of the replaying pass.  Host arrays passed by pointer are copied into `blob`, which lives
+    as long as the list: WHICH arguments are host pointers comes from the header's `_host` suffix (mopa_amd/_host_args.py,
+    generated by csrc/gen_header.py), how many bytes they hold from HOST_BYTES below -- an entry point with a host pointer of
+    unknown size is refused (a raw host address recorded verbatim would dangle at replay; the caller then runs the pass eagerly)."""
 
-    HOST_ARGS = {"mopa_conv2d_igemm": {4: 100}, "mopa_conv2d_igemm_batched": {3: 100}, "mopa_conv2d_bwd_weight": {3: 100},
-                 "mopa_add_i64_many": {0: 512}}
+    # bytes behind a host-pointer parameter, by parameter name: (args, position) -> size
+    HOST_BYTES = {"geom_host": lambda args, j: 100,                       # ConvGeom: 25 x int32 (csrc/conv2d.hip)
+                  "ptrs_host": lambda args, j: 8 * int(args[j + 1])}      # mopa_add_i64_many(ptrs_host, n, ...)
     _ids = {}
 
     def __init__(self, main_stream: int):
@@ -250,12 +255,15 @@ class CommandList:
         sig = SIGNATURES[name][1]
         if fid < 0 or not sig.endswith("p") or len(sig) != len(args):
             raise RuntimeError(f"CommandList: {name} cannot be recorded")
-        host = self.HOST_ARGS.get(name, {})
+        host = HOST_PARAMS.get(name, {})
+        for j, pname in host.items():
+            if pname not in self.HOST_BYTES:
+                raise RuntimeError(f"CommandList: {name} takes the host pointer `{pname}` of unknown size and cannot be recorded")
         base = len(self.words)
         self.words += [fid, len(args)]
         for j, (t, a) in enumerate(zip(sig, args)):
             if j in host:
-                n = host[j]
+                n = self.HOST_BYTES[host[j]](args, j)
                 self.fix.append((base + 2 + j, len(self.blob)))
                 self.blob += ctypes.string_at(a, n)
                 self.blob += b"\0" * ((-len(self.blob)) % 16)
@@ -309,10 +317,12 @@ WEIGHTS_EPOCH = [0]
 
 
 def query(name: str, *args) -> int:
-    """Pure size / plan queries (workspace bytes, kernel plans): memoised, the answers depend on the arguments only."""
+    """Pure size / plan queries (workspace bytes, kernel plans): memoised per DEVICE -- some plans follow the current device's CU
+    count (csrc/common.h::mopa_cu_count: 16- or 32-tile one-kernel convolution, the run-list weight gradient's piece size and
+    with it its workspace), so in a process that drives different GPU models the answer for one device is not the other's."""
     if "p" in SIGNATURES[name][1]:   # takes a pointer (e.g. a geometry block): the address says nothing about the content
         return int(getattr(_lib or load(), name)(*args))
-    key = (name, args)
+    key = (name, args, _raw_device() if (_raw_device is not None and torch.cuda.is_initialized()) else -1)
     v = _query_cache.get(key)
     if v is None:
         v = _query_cache[key] = int(getattr(_lib or load(), name)(*args))

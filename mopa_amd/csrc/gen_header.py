@@ -131,8 +131,37 @@ def gen_exec_table():
     print("wrote exec_table.inc", len(fns), "entry points")
 
 
+def gen_host_args():
+    """mopa_amd/_host_args.py: for every entry point, the positions and names of its HOST-pointer parameters (names ending in
+    `_host`).  The command-list recorder (mopa_amd/_lib.py::CommandList) copies those it knows the size of into its own blob and
+    refuses to record an entry point with any other one -- a recorded raw host address would dangle at replay."""
+    table = {}
+    for fname, _ in SECTIONS:
+        for sig in protos(os.path.join(HERE, fname)):
+            m = re.match(r"(\w[\w\s\*]*?)\s*(mopa_\w+)\((.*)\);$", sig)
+            name, params = m.group(2), m.group(3)
+            host = {}
+            for j, prm in enumerate(params.split(",")):
+                prm = re.sub(r"/\*.*?\*/", "", prm).strip()
+                pname = re.split(r"[\s\*]+", prm)[-1]
+                if pname.endswith("_host") and "*" in prm:
+                    host[j] = pname
+            if host:
+                table[name] = host
+    out = os.path.join(HERE, "..", "_host_args.py")
+    with open(out, "w") as f:
+        f.write('"""GENERATED by csrc/gen_header.py::gen_host_args from the MOPA_API prototypes; do not edit by hand.\n'
+                'entry point -> {argument position: name} of its host-pointer parameters (names ending in _host)."""\n')
+        f.write("HOST_PARAMS = {\n")
+        for n in sorted(table):
+            f.write(f"    {n!r}: {table[n]!r},\n")
+        f.write("}\n")
+    print("wrote _host_args.py", len(table), "entry points with host pointers")
+
+
 def main():
     gen_exec_table()
+    gen_host_args()
     parts = [HEAD]
     for fname, doc in SECTIONS:
         parts.append(f"\n/* ---- {fname}\n * {doc}\n */")

@@ -191,36 +191,68 @@ MOPA_API int mopa_softmax_bwd(const float* probs, const float* dprobs, int64_t n
 // Per (image b, id m): n = #pixels, mu = mean_n P, V = sum_{n,c} (P - mu)^2.
 //   loss_m = V / (n C) - [min_entropy] sum_c mu_c log2(mu_c + 1e-30) / log2(Knorm)     (Knorm = probs.shape[1], B.2)
 //   loss   = mean_b ( mean_{m valid in b} loss_m )   (an image without valid ids adds 0 but counts, loss.py:278-281)
-// Two segmented-reduction passes (means, then centred squares) keep fp32 accurate; block-level LDS float
-// atomics + per-block slabs + an ordered slab reduction.
+// Two segmented-reduction passes (means, then centred squares) keep fp32 accurate.  The per-id sums are ORDERED: a wave
+// takes 64 consecutive pixels (lane = pixel), walks the distinct ids among them (leader = the first lane not yet served)
+// and sums the matching lanes with the fixed xor-butterfly of wave_sum -- wavefront shuffles, no float atomics -- into
+// a wave-private LDS accumulator that a single lane per channel read-add-writes; the waves of a block take their
+// 64-pixel groups in a fixed order and their accumulators are added in wave order; per-block slabs + an ordered slab
+// reduction.  Same bits run to run (tests/test_gpu_losses.py::test_mask_cons_loss_is_bit_reproducible).  SAM masks are
+// spatially coherent: a group of 64 row-adjacent pixels holds 1-3 ids, so the leader loop is short.
 #define MAXID 256
 #define MC_PIX_PER_BLOCK 4096
+
+static inline int mc_waves(int W) {   // waves per block: the wave-private accumulators have to fit 64 KB of LDS
+  const int nw = 65536 / (MAXID * W * (int)sizeof(float));
+  return nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
+}
 
 __global__ __launch_bounds__(256) void k_mc_pass(const float* __restrict__ probs, const int* __restrict__ masks, int HW, int C,
                                                   const float* __restrict__ mu /*null in pass 1: [B][MAXID][C]*/,
                                                   float* __restrict__ slabs /*[B][nblk][MAXID][W]*/, int nblk, int W) {
-  extern __shared__ float acc[];  // [MAXID][W]   pass1: W=C+1 (sums, count) ; pass2: W=1 (centred squares)
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < MAXID * W; i += 256) acc[i] = 0.f;
+  extern __shared__ float acc[];  // [waves][MAXID][W]   pass1: W=C+1 (sums, count) ; pass2: W=1 (centred squares)
+  const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nw * MAXID * W; i += nthr) acc[i] = 0.f;
   __syncthreads();
+  float* mine = acc + wv * MAXID * W;
   const int p0 = blockIdx.x * MC_PIX_PER_BLOCK, p1 = min(HW, p0 + MC_PIX_PER_BLOCK);
-  for (int pix = p0 + threadIdx.x; pix < p1; pix += 256) {
-    const int id = masks[(int64_t)b * HW + pix];
-    if (id < 0 || id >= MAXID) continue;
-    const float* pr = probs + ((int64_t)b * HW + pix) * C;
-    if (!mu) {
-      for (int c = 0; c < C; ++c) atomicAdd(&acc[id * W + c], pr[c]);
-      atomicAdd(&acc[id * W + C], 1.f);
-    } else {
+  for (int g0 = p0 + wv * 64; g0 < p1; g0 += nthr) {   // wave-uniform: whole groups of 64 pixels
+    const int pix = g0 + lane;
+    int id = pix < p1 ? masks[(int64_t)b * HW + pix] : -1;
+    if (id >= MAXID) id = -1;
+    const float* pr = probs + ((int64_t)b * HW + (pix < p1 ? pix : p0)) * C;
+    float v2 = 0.f;
+    if (mu && id >= 0) {
       const float* m = mu + ((int64_t)b * MAXID + id) * C;
-      float v = 0.f;
-      for (int c = 0; c < C; ++c) { const float d = pr[c] - m[c]; v = fmaf(d, d, v); }
-      atomicAdd(&acc[id], v);
+      for (int c = 0; c < C; ++c) { const float d = pr[c] - m[c]; v2 = fmaf(d, d, v2); }
+    }
+    unsigned long long todo = __ballot(id >= 0);
+    while (todo) {
+      const int lid = __shfl(id, __ffsll((long long)todo) - 1, 64);
+      const bool hit = id == lid;
+      const unsigned long long mb = __ballot(hit);
+      todo &= ~mb;
+      if (!mu) {
+        float keep = 0.f;   // lane c ends up with channel c's sum, lane C with the pixel count
+        for (int c = 0; c < C; ++c) {
+          const float s = wave_sum(hit ? pr[c] : 0.f);
+          if (lane == c) keep = s;
+        }
+        if (lane == C) keep = (float)__popcll(mb);
+        if (lane <= C) mine[lid * W + lane] += keep;
+      } else {
+        const float s = wave_sum(hit ? v2 : 0.f);
+        if (lane == 0) mine[lid] += s;
+      }
     }
   }
   __syncthreads();
   float* dst = slabs + ((int64_t)b * nblk + blockIdx.x) * MAXID * W;
-  for (int i = threadIdx.x; i < MAXID * W; i += 256) dst[i] = acc[i];
+  for (int i = threadIdx.x; i < MAXID * W; i += nthr) {
+    float s = acc[i];
+    for (int w = 1; w < nw; ++w) s += acc[w * MAXID * W + i];
+    dst[i] = s;
+  }
 }
 
 // tab[b][id] = {n, V} ; mu[b][id][c]
@@ -317,10 +349,11 @@ MOPA_API int mopa_mask_cons_fwd(const float* probs, const int32_t* masks, int32_
   float* cnt = mu + (size_t)B * MAXID * C;
   float* nvalid = cnt + (size_t)B * MAXID;
   dim3 grid(nblk, B);
-  k_mc_pass<<<grid, 256, (size_t)MAXID * (C + 1) * sizeof(float), st>>>(probs, masks, HW, C, nullptr, slabs1, nblk, C + 1);
+  const int nw1 = mc_waves(C + 1), nw2 = mc_waves(1);
+  k_mc_pass<<<grid, 64 * nw1, (size_t)nw1 * MAXID * (C + 1) * sizeof(float), st>>>(probs, masks, HW, C, nullptr, slabs1, nblk, C + 1);
   k_mc_means<<<dim3(4, B), 256, 0, st>>>(slabs1, nblk, C, mu, cnt);
   k_mc_divide<<<stream_grid((int64_t)B * MAXID * C, 256), 256, 0, st>>>(mu, cnt, B, C);
-  k_mc_pass<<<grid, 256, (size_t)MAXID * sizeof(float), st>>>(probs, masks, HW, C, mu, slabs2, nblk, 1);
+  k_mc_pass<<<grid, 64 * nw2, (size_t)nw2 * MAXID * sizeof(float), st>>>(probs, masks, HW, C, mu, slabs2, nblk, 1);
   k_mc_finalize<<<1, 256, 0, st>>>(slabs2, nblk, mu, cnt, B, C, log2f((float)k_norm), min_entropy, nvalid, loss);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;

@@ -359,6 +359,9 @@ MOPA_API int mopa_spconv_run_wanted(int32_t K, int32_t num_out, int32_t cin, int
   if (mode == 2) return 1;
   if (one_rule_per_row) return cin >= 32 && num_out >= 8192;   // (6,789 rows: 13.5 against 11.0 us; 19,312 rows: 9.0 against 14.9)
   if (K != 27) return 0;
+  // the slab is sized from the bound K x rows slots (no host round trip), ~3 x the rules in practice: refuse layers whose bound
+  // exceeds 1 GiB (the measured wins all sit below 0.8 GiB) -- they stay on the output-stationary kernels
+  if (run_cap(K, num_out) * (int64_t)cout * (int64_t)sizeof(float) > (1ll << 30)) return 0;
   return cin >= 64 && cout >= 48 && (int64_t)num_out * cout <= rows_per * cin;
 }
 

@@ -229,9 +229,13 @@ MOPA_API int mopa_vgi_compact_cells(const uint8_t* cand2d, int32_t X, int32_t Y,
 // ---------------------------------------------------------------- road height of a chosen cell
 // out[0] = sum of z over the points of the LOWEST ground voxel of column (cell_x, cell_y), out[1] = their count
 // (mixmatch_ss.py:431-444: argmin over the ground voxels of the cell, then the mean z of that voxel's points).
-__global__ void k_vgi_road(const float* __restrict__ pts, int stride, int n, float vs, const int* __restrict__ first,
-                           const unsigned char* __restrict__ g_mask, int col, int zlo, int vx, int vy, double* __restrict__ out) {
+// ONE block: every thread sums its points in index order, the waves' fixed xor-butterflies and an ordered sum over the
+// waves follow -- the same bits run to run (no floating-point atomics; a cloud is at most a few hundred thousand points).
+__global__ __launch_bounds__(1024) void k_vgi_road(const float* __restrict__ pts, int stride, int n, float vs, const int* __restrict__ first,
+                                                    const unsigned char* __restrict__ g_mask, int col, int zlo, int vx, int vy,
+                                                    double* __restrict__ out) {
   __shared__ int s_vz;
+  __shared__ double ws[16], wc[16];
   if (threadIdx.x == 0) {
     int vz = INT_MAX;
     const int* f = first + (int64_t)col * VGI_ZR;
@@ -242,7 +246,7 @@ __global__ void k_vgi_road(const float* __restrict__ pts, int stride, int n, flo
   __syncthreads();
   const int vz = s_vz;
   double s = 0.0, c = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float* p = pts + (int64_t)i * stride;
     if ((int)floorf(__fdiv_rn(p[0], vs)) == vx && (int)floorf(__fdiv_rn(p[1], vs)) == vy && (int)floorf(__fdiv_rn(p[2], vs)) == vz) {
       s += (double)p[2];
@@ -251,16 +255,21 @@ __global__ void k_vgi_road(const float* __restrict__ pts, int stride, int n, flo
   }
   s = wave_sum_d(s);
   c = wave_sum_d(c);
-  if ((threadIdx.x & 63) == 0 && c > 0.0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
+  if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += ws[w]; tc += wc[w]; }
+    out[0] = ts;
+    out[1] = tc;
+  }
 }
 MOPA_API int mopa_vgi_road_height(const float* points, int32_t stride, int32_t n, float voxel_size, const int32_t* first,
                                   const uint8_t* g_mask, int32_t ox, int32_t oy, int32_t X, int32_t Y, int32_t zlo, int32_t cell_x,
                                   int32_t cell_y, double* out /*[2]*/, void* stream) {
   const int cx = cell_x - ox, cy = cell_y - oy;
   if (n <= 0 || cx < 0 || cx >= X || cy < 0 || cy >= Y) return MOPA_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, 2 * sizeof(double), st) != hipSuccess) return MOPA_ERR_LAUNCH;
-  k_vgi_road<<<stream_grid(n, 256), 256, 0, st>>>(points, stride, n, voxel_size, first, g_mask, cx * Y + cy, zlo, cell_x, cell_y, out);
+  k_vgi_road<<<1, 1024, 0, (hipStream_t)stream>>>(points, stride, n, voxel_size, first, g_mask, cx * Y + cy, zlo, cell_x, cell_y, out);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

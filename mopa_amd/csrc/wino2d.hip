@@ -912,7 +912,10 @@ __global__ __launch_bounds__(256, 2) void k_wino4_conv(const float* __restrict__
         }
         d[a][c] = inside ? v : zero2;
       }
-    asm volatile("" :: "v"(pf_sink));   // (the touch loads of the previous step were issued before this patch: they have landed)
+    // the touch loads of the previous step were issued before this patch's loads, which have just been consumed: in-order vmcnt says
+    // they have landed; the explicit wait makes that hold whatever the compiler's wait-count pass (blind to VMEM issued from inline
+    // asm) emitted above -- it is free here, nothing younger is in flight
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf_sink));
     W4C_T(1)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)
@@ -1172,7 +1175,10 @@ __global__ __launch_bounds__(512, 2) void k_wino4_conv32(const float* __restrict
         }
         d[a][c] = inside ? v : zero2;
       }
-    asm volatile("" :: "v"(pf_sink));   // (the touch loads of the previous step were issued before this patch: they have landed)
+    // the touch loads of the previous step were issued before this patch's loads, which have just been consumed: in-order vmcnt says
+    // they have landed; the explicit wait makes that hold whatever the compiler's wait-count pass (blind to VMEM issued from inline
+    // asm) emitted above -- it is free here, nothing younger is in flight
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf_sink));
     W4C_T(1)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {   // B^T d, column by column (the formulas of w4_bt)

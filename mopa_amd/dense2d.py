@@ -1121,8 +1121,11 @@ class Net2DFunction(torch.autograd.Function):
         if graph is not None and graph.fwd is None:
             try:
                 graph.record_forward(P, flat, training, drop_p)
-            except RuntimeError:   # (_CaptureMiss is one) -- this key stays eager from now on
+            except RuntimeError:   # _CaptureMiss, an entry point the recorder refuses (host pointer of unknown size), or
+                # torch.OutOfMemoryError (a RuntimeError): the recording pins a second set of this key's activations in a private
+                # pool -- when that does not fit, the key stays eager from now on and the half-built pool is released with the record
                 graph.failed, graph = True, None
+                ctx.graph_key.fwd = ctx.graph_key.bwd = None
         if graph is not None:
             graph.forward(imgc, drop_seed)
             feat, tape, J = graph.feat, graph.tape, graph.J
@@ -1168,7 +1171,8 @@ class Net2DFunction(torch.autograd.Function):
         graph = ctx.graph
         if graph is not None and ctx.generation != graph.generation:
             raise RuntimeError("Net2DSeg backward: the activations of this forward pass were overwritten by a later graph replay "
-                               "(a second backward through the same pass after another forward?); set MOPA_GRAPH_2D=0")
+                               "(a second backward through the same pass after another forward?); set MOPA_NATIVE_2D=0 (and leave "
+                               "MOPA_GRAPH_2D unset) to run every pass eagerly")
         sink = GradSink(P, spec.order)   # gradients go straight into attached .grad buffers (accumulating)
 
         def cont(t):

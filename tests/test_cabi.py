@@ -113,3 +113,27 @@ def test_command_list_executor_table_and_packing():
     rec3.add("mopa_zero_rows", (10, 4, 5, 4, 2))
     with pytest.raises(RuntimeError):
         rec3.add("mopa_zero_rows", (10, 4, 5, 4, 3))                                  # a third stream
+    # host pointers: which arguments are host pointers comes from the header's `_host` suffix; the stem's fused
+    # weight gradient (arg 10 = geom_host) is copied like the other geometries, an entry point with a host table of unknown size
+    # is refused instead of recording a raw host address, and a pointer list copies exactly n entries
+    from mopa_amd._host_args import HOST_PARAMS
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    seen = 0
+    for m in re.finditer(r"\b(?:int|size_t)\s+(mopa_\w+)\s*\(([^;]*)\)\s*;", src):
+        params = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        want = {j: re.split(r"[\s\*]+", a)[-1] for j, a in enumerate(params) if "*" in a and re.split(r"[\s\*]+", a)[-1].endswith("_host")}
+        assert HOST_PARAMS.get(m.group(1), {}) == want, m.group(1)
+        seen += bool(want)
+    assert seen == len(HOST_PARAMS) >= 15
+    rec4 = _lib.CommandList(1)
+    rec4.add("mopa_stem_bwd_weight_bn", (1, 2, 64, 3, 128, 4, 5, 2, 1, 6, ctypes.addressof(geom), 0, 7, 1024, 1))
+    ptrs = (ctypes.c_int64 * 3)(11, 22, 33)
+    rec4.add("mopa_add_i64_many", (ctypes.addressof(ptrs), 3, 5, 1))
+    rec4.finish()
+    w4 = rec4.words_np
+    assert list((ctypes.c_int32 * 25).from_address(int(w4[2 + 10]))) == list(range(25)) and int(w4[2 + 10]) != ctypes.addressof(geom)
+    a0 = 2 + 15
+    assert list((ctypes.c_int64 * 3).from_address(int(w4[a0 + 2]))) == [11, 22, 33] and int(w4[a0 + 2]) != ctypes.addressof(ptrs)
+    desc = (ctypes.c_int64 * 8)()
+    with pytest.raises(RuntimeError, match="host pointer"):
+        _lib.CommandList(1).add("mopa_conv2d_weight_forms_batched", (ctypes.addressof(desc), 1, 1))

@@ -88,6 +88,33 @@ def test_mask_cons_full_size_vs_oracle():
     np.testing.assert_allclose(ld.grad.cpu().numpy(), lr.grad.float().numpy(), rtol=1e-3, atol=1e-10)
 
 
+def test_mask_cons_loss_is_bit_reproducible():
+    """The per-mask sums are ordered (wave shuffles + wave-private LDS accumulators, csrc/losses.hip::k_mc_pass): forward and
+    backward of mask_cons_loss (loss.py:241-283) at 8 x 302 x 480 give the same bits run to run -- and with random, spatially
+    INCOHERENT ids (the leader loop's worst case: up to 64 distinct ids per wave) and 11 classes as well."""
+    from mopa_amd import synth
+    from mopa_amd.common.utils.loss import mask_cons_loss, softmax_lastdim
+    rng = np.random.Generator(np.random.PCG64(11))
+    for B, C, coherent in ((8, 5, True), (2, 11, False)):
+        H, W = 302, 480
+        logits = torch.from_numpy(rng.standard_normal((B, H, W, C), dtype=np.float32)).cuda()
+        if coherent:
+            masks = [torch.from_numpy(synth.sam_mask(rng, H, W)).cuda() for _ in range(B)]
+        else:
+            masks = [torch.from_numpy(rng.integers(-1, 256, (H, W)).astype(np.int32)).cuda() for _ in range(B)]
+        runs = []
+        for _ in range(3):
+            ld = logits.clone().requires_grad_(True)
+            loss = mask_cons_loss(softmax_lastdim(ld), masks, True)
+            loss.backward()
+            runs.append((loss.detach().clone(), ld.grad.clone()))
+        for l, g in runs[1:]:
+            assert torch.equal(l, runs[0][0]) and torch.equal(g, runs[0][1])
+        # and the value is the oracle's (the incoherent case has no golden vector)
+        ref = olosses.mask_cons_loss(torch.softmax(logits.cpu().double(), 3), [m.cpu() for m in masks], True)
+        np.testing.assert_allclose(runs[0][0].item(), ref.item(), rtol=1e-5)
+
+
 def test_flat_adam_matches_torch_adam():
     from mopa_amd.optim import FlatAdam
     torch.manual_seed(0)

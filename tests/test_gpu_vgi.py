@@ -62,6 +62,28 @@ def test_ground_insertion_matches_the_reference(g8, k):
     assert torch.equal(cat_pc[:n0].cpu(), torch.from_numpy(c["ori_pc"][:, :3]).double())
 
 
+def test_road_height_is_bit_reproducible():
+    """The road height under a chosen cell (mixmatch_ss.py:431-444) is an ordered sum (one block, fixed wave order:
+    csrc/vgi.hip::k_vgi_road; it was two global double atomics per wave): the whole insertion gives the same bits run to run."""
+    from mopa_amd import vgi
+    c = _case(0)
+    m = vgi.OverlapMap(c["ori_pc"], 0.5, (25.0, 25.0), -2.0, c["front"], g_mask=c["g_mask"])
+    anchor = c["objs"][0]
+    cells, _, _ = m.ground_cells(m.free_cells(anchor[:, :3]), anchor, c["proj"], c["image_size"])
+    for cell in cells[:: max(1, len(cells) // 8)][:8]:
+        h = [m.road_height(cell) for _ in range(4)]
+        assert all(np.array_equal(np.asarray(x), np.asarray(h[0])) for x in h[1:])
+    outs = []
+    for _ in range(2):
+        np.random.seed(100)
+        cat_pc, _, _, _ = vgi.point_mixmatch(torch.from_numpy(c["ori_pc"]).cuda(), c["label"], [o.copy() for o in c["objs"]],
+                                             c["obj_labels"], insert_mode="ground", search_voxel_size=0.5, search_range=[25.0, 25.0],
+                                             search_z_min=-2.0, proj_matrix=c["proj"], image_size=c["image_size"],
+                                             g_indices=c["g_mask"], front_axis=c["front"])
+        outs.append(cat_pc)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_range_image_culling_and_post_process_bit_exact(g8, k):
     from mopa_amd import vgi
