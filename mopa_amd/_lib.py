@@ -130,6 +130,10 @@ SIGNATURES = {
     "mopa_wino4_dout": ("i", "piiiiipp"),
     "mopa_wino4_wgrad_workspace_bytes": ("z", "iii"),
     "mopa_wino4_bwd_weight": ("i", "ppiiipipzp"),
+    # ---- F(4x4) weight gradient in one kernel (wino4wg.hip)
+    "mopa_wino4_wgrad_fused_ok": ("i", "iiiii"),
+    "mopa_wino4_wgrad_fused_workspace_bytes": ("z", "iiiii"),
+    "mopa_wino4_wgrad_fused": ("i", "pipiipiiiiiipipzp"),
     "mopa_conv2d_wgrad_workspace_bytes": ("z", "p"),
     "mopa_conv2d_bwd_weight": ("i", "ppppipzp"),
     "mopa_conv2d_relayout_weight": ("i", "ppiiiiiiip"),

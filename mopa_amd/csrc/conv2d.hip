@@ -1051,6 +1051,13 @@ __global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slab
   }
 }
 
+// (for wino4wg.hip: the slab sum + G^T dU G epilogue of an F(4x4) weight gradient whose slabs another kernel produced)
+int wino4_dw_launch(const float* slabs, int nsplit, int Cin, int Cout, float* dweight, int flags, hipStream_t st) {
+  const int64_t n = (int64_t)Cin * Cout;
+  k_wino4_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, nsplit, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
+  return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
+}
+
 static void wino_wgrad_split(int np, int64_t T, int Cin, int Cout, int* nsplit, int* m_per_split) {
   const int64_t tiles = (int64_t)np * (Cin / 64) * (Cout / 64);
   int64_t ns = cdiv64(2048, tiles);   // (768 ... 2048 target blocks: same joint step within 0.5 %)
@@ -1063,6 +1070,7 @@ static void wino_wgrad_split(int np, int64_t T, int Cin, int Cout, int* nsplit, 
 }
 
 static size_t wino_wgrad_ws(int np, int32_t T, int32_t Cin, int32_t Cout) {
+  if (T <= 0 || Cin < 64 || Cout < 64 || Cin % 64 || Cout % 64) return 0;   // (shapes wino_bwd_weight refuses)
   int ns, mps;
   wino_wgrad_split(np, T, Cin, Cout, &ns, &mps);
   return align_up((size_t)ns * np * Cin * Cout * sizeof(float), 256);

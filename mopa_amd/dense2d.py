@@ -322,11 +322,31 @@ def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
             and WINOGRAD_WGRAD)
 
 
-def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2):
+# F(4x4) layers whose weight gradient runs as ONE kernel from x and dY (mopa_wino4_wgrad_fused, csrc/wino4wg.hip: neither V nor dM in
+# HBM) -- the 64 / 128-channel layers with many tiles, where the two-operand form is bound by the 2 x 2.25 x activations it moves.  The
+# training forward pass of such a layer keeps no V (it may then run as the one-kernel convolution).  MOPA_WINO4_WGRAD_FUSED=0 = off.
+WINO4_WGRAD_FUSED = os.environ.get("MOPA_WINO4_WGRAD_FUSED", "1") != "0"
+WINO4_WGRAD_FUSED_MIN_TILES = int(os.environ.get("MOPA_WINO4_WGRAD_FUSED_MIN_TILES", "8192"))
+
+
+def wino4_wgrad_fused(cin, cout, B, H, W):
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    return (WINO4_WGRAD_FUSED and cin % 32 == 0 and cout % 64 == 0 and cin <= 128 and cout <= 128 and T >= WINO4_WGRAD_FUSED_MIN_TILES
+            and bool(query("mopa_wino4_wgrad_fused_ok", B, H, W, cin, cout)))
+
+
+def wino_wgrad(x: Img, dout: Img, cin, cout, dw, V=None, accumulate=False, F=2, fused=None):
     """dw (OIHW, [cout][cin][3][3]) (+)= weight gradient of conv3x3(x) given dout, through V = B^T x B (kept from the forward
-    pass when the caller has it), dM = A dout A^T."""
+    pass when the caller has it), dM = A dout A^T -- or, for the layers wino4_wgrad_fused names (fused=None: ask it), in one kernel
+    from x and dout."""
     dev = dw.device
     B, H, W = x.B, x.H, x.W
+    if F == 4 and V is None and (wino4_wgrad_fused(cin, cout, B, H, W) if fused is None else fused):
+        bn = getattr(x, "bn", None)
+        ws = _ws(query("mopa_wino4_wgrad_fused_workspace_bytes", B, H, W, cin, cout), dev)
+        call("mopa_wino4_wgrad_fused", x.p, x.ld, ptr(bn[0]) if bn is not None else None, bn[1] if bn is not None else 1,
+             bn[2] if bn is not None else 0, dout.p, dout.ld, B, H, W, cin, cout, ptr(dw), int(accumulate) | 2, ptr(ws), ws.numel(), stream())
+        return
     T, NP = B * ((H + F - 1) // F) * ((W + F - 1) // F), (F + 2) ** 2
     sfx = "" if F == 2 else "4"
     dM = torch.empty(NP * T * cout, dtype=torch.float32, device=dev)
@@ -446,17 +466,23 @@ class ConvOp:
     def forward(self, x: Img, out: Img, keep_v: bool = False):
         """-> the transformed input V when the Winograd path ran and the weight gradient will want it again (training)."""
         F = wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "fwd")
-        drole = "fwd" if keep_v else "fwd_eval"
+        a = (self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W)
+        # does the weight gradient of this pass want V again?  Not when it runs in one kernel from x and dY (wino4_wgrad_fused): the
+        # training forward pass then keeps nothing, like a forward pass without gradients
+        v_wanted = (keep_v and F == 4 and wino_tile(*a, "wgrad") == 4 and wino_wgrad_eligible(*a)
+                    and not wino4_wgrad_fused(self.I, self.O, x.B, x.H, x.W))
+        drole = "fwd" if v_wanted or (keep_v and F != 4) else "fwd_eval"
         lazy = getattr(x, "bn", None)
         if lazy is not None and not self.takes_lazy(x.B, x.H, x.W, keep_v):
             raise RuntimeError("ConvOp.forward: this layer cannot consume a deferred BatchNorm (ask takes_lazy first)")
         if F:
             V = wino_conv(x.p, x.ld, x.B, x.H, x.W, self.I, self.O,
                           wino_weight_cached(self.w, False, F, wino4_layout(self.I, self.O, x.B, x.H, x.W, drole) if F == 4 else 0), self.b, out.p,
-                          out.ld, F=F, bn_in=lazy, role=drole, want_v=keep_v and F == 4 and wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad") == 4
-                          and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W))
-            same = F == wino_tile(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W, "wgrad")   # V serves the weight gradient
-            return V if V is not None and keep_v and same and wino_wgrad_eligible(self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W) else None
+                          out.ld, F=F, bn_in=lazy, role=drole, want_v=v_wanted)
+            if F == 4 and not v_wanted:
+                return None
+            same = F == wino_tile(*a, "wgrad")   # V serves the weight gradient
+            return V if V is not None and keep_v and same and wino_wgrad_eligible(*a) else None
         wl = relayout_cached(self.w, (self.k, self.k, self.I, self.O), self.O, self.I, self.k, self.k, 0)
         igemm(x.p, wl, self.b, out.p, self._fwd_geom(x, out))
 

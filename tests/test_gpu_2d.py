@@ -924,6 +924,63 @@ def test_wino4_one_kernel_convolution_vs_fp64_conv(cin, cout, H, W, acc, dgrad, 
     _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,acc,G,c0", [(64, 64, 2, 37, 51, False, 0, 0), (128, 64, 3, 40, 64, True, 0, 0),
+                                                    (64, 128, 2, 33, 32, False, 0, 0), (64, 64, 2, 36, 44, False, 2, 0),
+                                                    (128, 64, 4, 32, 40, True, 2, 64), (32, 64, 1, 64, 64, False, 0, 0),
+                                                    (96, 128, 2, 21, 27, False, 1, 32)])
+def test_wino4_one_kernel_weight_gradient_vs_fp64(cin, cout, B, H, W, acc, G, c0):
+    """mopa_wino4_wgrad_fused (csrc/wino4wg.hip: the F(4x4) weight gradient from x and dY in one kernel, neither V nor dM in HBM)
+    against torch autograd's fp64 conv2d weight gradient (the reference's arithmetic behind resnet34_unet.py:97-110) and against the
+    two-operand form (mopa_wino4_input[_bn] + mopa_wino4_dout + mopa_wino4_bwd_weight): ragged tiles (H, W not multiples of 4), a tile
+    range that ends inside a chunk, both operands as column slices of wider buffers, accumulation into an existing OIHW gradient, and
+    (G > 0) a deferred BatchNorm + ReLU applied on the way in for G image groups, with (c0 > 0) the lower channels passing through."""
+    import torch.nn.functional as F
+    from mopa_amd import dense2d
+    from mopa_amd._lib import call, ptr, query, stream
+    from mopa_amd.dense2d import bn_fwd_groups
+    rng = np.random.Generator(np.random.PCG64(77 + cin + W))
+    wide = torch.from_numpy(rng.standard_normal((B * H * W, cin + 32)).astype(np.float32)).cuda()
+    if c0:
+        wide[:, 32:32 + c0].abs_()                                   # the pass-through half of a join buffer is non-negative already
+    xin = dense2d.Img(wide, B, H, W, 32, cin)
+    x = wide[:, 32:].contiguous()
+    stats = None
+    if G:
+        cn = cin - c0
+        P = {"bn.weight": torch.linspace(0.5, 1.5, cn).cuda(), "bn.bias": torch.linspace(-1, 1, cn).cuda(),
+             "bn.running_mean": torch.zeros(cn, device="cuda"), "bn.running_var": torch.ones(cn, device="cuda")}
+        stats = torch.empty(G, 4, cn, device="cuda")
+        y = dense2d.new_img(B, H, W, cn, "cuda")
+        bn_fwd_groups(dense2d.Img(wide, B, H, W, 32 + c0, cn), y, P, "bn", 1, None, True, stats, G)
+        x = torch.cat([x[:, :c0], y.t], 1).contiguous()              # what the convolution saw
+    dwide = torch.from_numpy(rng.standard_normal((B * H * W, cout + 64)).astype(np.float32)).cuda()
+    dy = dwide[:, 64:].contiguous()
+    prev = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)).cuda()
+    xr = x.reshape(B, H, W, cin).permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
+    wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, None, padding=1).backward(dy.reshape(B, H, W, cout).permute(0, 3, 1, 2).double().cpu())
+    ref = wr.grad + (prev.double().cpu() if acc else 0)
+    assert query("mopa_wino4_wgrad_fused_ok", B, H, W, cin, cout) == 1
+    ws = torch.empty(query("mopa_wino4_wgrad_fused_workspace_bytes", B, H, W, cin, cout), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):   # twice: deterministic
+        dw = prev.clone() if acc else torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+        call("mopa_wino4_wgrad_fused", xin.p, xin.ld, ptr(stats), max(G, 1), c0, ptr(dwide, 64), dwide.shape[1], B, H, W, cin, cout,
+             ptr(dw), int(acc) | 2, ptr(ws), ws.numel(), stream())
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    scale = float(ref.abs().max())
+    err = float((outs[0].double().cpu() - ref).abs().max()) / scale
+    assert err < 2e-5, err
+    if cin % 64:
+        return
+    # the two-operand form on the same inputs
+    dw2 = prev.clone() if acc else torch.empty(cout, cin, 3, 3, device="cuda")
+    dense2d.wino_wgrad(dense2d.LazyImg(xin, stats, G, c0) if G else xin, dense2d.Img(dwide, B, H, W, 64, cout), cin, cout, dw2,
+                       accumulate=acc, F=4, fused=False)
+    assert float((outs[0] - dw2).abs().max()) / scale < 2e-5
+
+
 def test_one_kernel_convolution_picks_32_tiles_per_item_on_the_long_layers(request):
     """mopa_wino4_conv by shape: the decoder's full-resolution layer (64 -> 128 backward-data at 4 x 304 x 480: 1140 tile groups x 2 = 2280
     work items of 32 tiles >= 8 per CU) runs k_wino4_conv32 -- the bits of the forced 32-tile kernel -- and agrees with the 16-tile kernel
