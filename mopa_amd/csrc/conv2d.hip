@@ -824,16 +824,20 @@ static bool stem_wgrad_mfma(const ConvGeom& g) {
   return env_mfma && g.Cin == 16 && g.TW == 2 && g.TH == 7 && g.Cout == 64;
 }
 
-// dw[i] (+)= sum_c slabs[c][i]: 16 chunk-lanes per element + fixed-order LDS reduction.
+// dw[i] (+)= sum_c slabs[c][i]: block = EW consecutive elements x 256 / EW slab lanes + fixed-order LDS reduction.  EW = 64 reads whole
+// 256-byte runs of a slab row (16: 64-byte pieces -- 1 TB/s; the reduction of the 256- and 512-channel layers' slabs took 60 us a call);
+// the narrower forms keep >= 512 blocks on the small gradients (reduce_ew).
+template <int EW>
 __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
                                                         int accumulate, int oihw, int taps, int Cin, int Cout) {
-  __shared__ float red[16][17];
-  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + el;
+  constexpr int NL = 256 / EW;
+  __shared__ float red[NL][EW + 1];
+  const int el = threadIdx.x % EW, cl = threadIdx.x / EW;
+  const int64_t i = (int64_t)blockIdx.x * EW + el;
   float s = 0.f;
   if (i < n)
 #pragma unroll 8
-    for (int c = cl; c < nsplit; c += 16) s += slabs[(int64_t)c * n + i];
+    for (int c = cl; c < nsplit; c += NL) s += slabs[(int64_t)c * n + i];
   red[cl][el] = s;
   __syncthreads();
   if (cl == 0 && i < n) {
@@ -846,9 +850,18 @@ __global__ __launch_bounds__(256) void k_reduce_slabs2(const float* __restrict__
     }
     float t = accumulate ? dw[o] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][el];
+    for (int k = 0; k < NL; ++k) t += red[k][el];
     dw[o] = t;
   }
+}
+static inline int reduce_ew(int64_t n) { return n >= 64 * 512 ? 64 : n >= 32 * 512 ? 32 : 16; }
+static void reduce_slabs2_launch(const float* slabs, int ns, int64_t n, float* dw, int accumulate, int oihw, int taps, int Cin, int Cout,
+                                 hipStream_t st) {
+  const int ew = reduce_ew(n);
+  const unsigned nb = (unsigned)cdiv64(n, ew);
+  if (ew == 64) k_reduce_slabs2<64><<<nb, 256, 0, st>>>(slabs, ns, n, dw, accumulate, oihw, taps, Cin, Cout);
+  else if (ew == 32) k_reduce_slabs2<32><<<nb, 256, 0, st>>>(slabs, ns, n, dw, accumulate, oihw, taps, Cin, Cout);
+  else k_reduce_slabs2<16><<<nb, 256, 0, st>>>(slabs, ns, n, dw, accumulate, oihw, taps, Cin, Cout);
 }
 
 static int wgrad_ntap(const ConvGeom& g) {
@@ -936,7 +949,7 @@ MOPA_API int mopa_conv2d_bwd_weight(const float* in, const float* dy, float* dwe
     k_conv2d_wgrad<16, 1><<<grid, 256, 0, st>>>(in, dy, slabs, g, mps);
   }
   const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
-  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout);
+  reduce_slabs2_launch(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout, st);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -963,7 +976,7 @@ MOPA_API int mopa_stem_bwd_weight_bn(const float* in, const float* dy, int32_t l
   StemBn bn{xbn, stats, coef, ld_x, ld_dy, g.B / n_groups, n_groups, training};
   k_stem_wgrad_mfma<true><<<ns, 256, 0, st>>>(in, dy, slabs, g, mps, bn);
   const int64_t n = (int64_t)g.TH * g.TW * g.Cin * g.Cout;
-  k_reduce_slabs2<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout);
+  reduce_slabs2_launch(slabs, ns, n, dweight, accumulate, oihw, g.TH * g.TW, g.Cin, g.Cout, st);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
@@ -1009,15 +1022,19 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ slabs
   }
 }
 
-// F(4x4,3x3): 36 points, dW = G^T dU G with the 6x3 G.  block = 16 elements x 16 threads, thread (e, q) sums points q, q+16, q+32.
+// F(4x4,3x3): 36 points, dW = G^T dU G with the 6x3 G.  block = EW consecutive elements x 256 / EW point lanes: thread (e, q) sums points
+// q, q + 256 / EW, ... over the slabs in split order, then the first EW threads transform.  EW as in k_reduce_slabs2 (whole 256-byte runs
+// of a slab row on the 256- / 512-channel layers: this kernel averaged 52 us a call with 64-byte pieces).
+template <int EW>
 __global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slabs, int nsplit, int64_t n, float* __restrict__ dw,
                                                    int accumulate, int oihw, int Cin, int Cout) {
-  __shared__ float red[36][17];
-  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  constexpr int NQ = 256 / EW;
+  __shared__ float red[36][EW + 1];
+  const int e = threadIdx.x % EW, q = threadIdx.x / EW;
+  const int64_t i = (int64_t)blockIdx.x * EW + e;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int p = q + 16 * j;
+  for (int k = 0; k < (36 + NQ - 1) / NQ; ++k) {
+    const int p = q + k * NQ;
     if (p < 36) {
       float s = 0.f;
       if (i < n) {
@@ -1054,7 +1071,11 @@ __global__ __launch_bounds__(256) void k_wino4_dw(const float* __restrict__ slab
 // (for wino4wg.hip: the slab sum + G^T dU G epilogue of an F(4x4) weight gradient whose slabs another kernel produced)
 int wino4_dw_launch(const float* slabs, int nsplit, int Cin, int Cout, float* dweight, int flags, hipStream_t st) {
   const int64_t n = (int64_t)Cin * Cout;
-  k_wino4_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, nsplit, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
+  const int ew = reduce_ew(n), acc = flags & 1, oihw = (flags >> 1) & 1;
+  const unsigned nb = (unsigned)cdiv64(n, ew);
+  if (ew == 64) k_wino4_dw<64><<<nb, 256, 0, st>>>(slabs, nsplit, n, dweight, acc, oihw, Cin, Cout);
+  else if (ew == 32) k_wino4_dw<32><<<nb, 256, 0, st>>>(slabs, nsplit, n, dweight, acc, oihw, Cin, Cout);
+  else k_wino4_dw<16><<<nb, 256, 0, st>>>(slabs, nsplit, n, dweight, acc, oihw, Cin, Cout);
   return hipGetLastError() == hipSuccess ? MOPA_OK : MOPA_ERR_LAUNCH;
 }
 
@@ -1094,7 +1115,7 @@ static int wino_bwd_weight(int np, const float* V, const float* dM, int32_t T, i
   k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(V, dM, slabs, g, mps, (int64_t)T * Cin, (int64_t)T * Cout);
   const int64_t n = (int64_t)Cin * Cout;
   if (np == 16) k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
-  else k_wino4_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
+  else return wino4_dw_launch(slabs, ns, Cin, Cout, dweight, flags, st);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }
