@@ -134,6 +134,7 @@ class Conv2dTimer:
 
     def __init__(self):
         self.records = []
+        self.wgrad_records = []
         self.enabled = False
 
     def install(self):
@@ -173,7 +174,28 @@ class Conv2dTimer:
         dense2d.igemm_batched = wrapped_b
         inner_call = dense2d.call
 
+        WGRAD = ("mopa_conv2d_bwd_weight", "mopa_stem_bwd_weight_bn", "mopa_wino4_bwd_weight", "mopa_wino_bwd_weight", "mopa_wino4_wgrad_fused")
+
         def wrapped_call(name, *a):   # the fused F(4x4) GEMM + output-transform kernel belongs to the same family
+            if timer.enabled and name in WGRAD:
+                # the weight-gradient family (roofline_wgrad): one entry point = one weight gradient = its MFMA kernel + the ordered
+                # slab reduction (k_conv2d_wgrad_mfma / k_wino4_wgrad / k_stem_wgrad_mfma + k_reduce_slabs2 / k_wino4_dw), flops as
+                # executed; the brackets sit on the stream the call runs on (the weight-gradient stream: torch's current stream there)
+                import ctypes
+                if name in ("mopa_conv2d_bwd_weight", "mopa_stem_bwd_weight_bn"):
+                    g = (ctypes.c_int32 * 25).from_address(int(a[3] if name == "mopa_conv2d_bwd_weight" else a[10]))
+                    fl = 2 * g[0] * g[3] * g[4] * g[15] * g[16] * g[21] * g[22]
+                elif name == "mopa_wino4_wgrad_fused":
+                    B_, H_, W_, ci_, co_ = a[7], a[8], a[9], a[10], a[11]
+                    fl = 2 * 36 * B_ * ((H_ + 3) // 4) * ((W_ + 3) // 4) * ci_ * co_
+                else:
+                    fl = 2 * (36 if name == "mopa_wino4_bwd_weight" else 16) * a[2] * a[3] * a[4]
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = inner_call(name, *a)
+                e.record()
+                timer.wgrad_records.append((s, e, 0, fl, fl))
+                return r
             if not timer.enabled or name not in ("mopa_wino4_gemm_output", "mopa_wino4_conv"):
                 return inner_call(name, *a)
             one = name == "mopa_wino4_conv"   # the one-kernel convolution: input transform + GEMMs + output transform (no V)
@@ -191,6 +213,25 @@ class Conv2dTimer:
 
     summary = ConvTimer.summary
 
+    def wgrad_summary(self):
+        keep, self.records = self.records, self.wgrad_records
+        try:
+            return ConvTimer.summary(self)
+        finally:
+            self.records = keep
+
+
+def gradient_error_vs_fp64():
+    """config.gradient_error_vs_fp64: what Winograd F(4x4) in all three passes costs in gradient accuracy at the bench shape -- the
+    committed output of profiles/f4_gradient_noise.py (max |g - fp64| / max |fp64| per parameter tensor; median / p90 / max over the
+    tensors), beside the exact-product kernels' own fp32-vs-fp64 noise.  Not measured in this run."""
+    path = os.path.join(ROOT, "profiles", "r6_f4_gradient_noise.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    d["source"] = os.path.relpath(path, ROOT)
+    return d
+
 
 def f4_roles():
     from mopa_amd import dense2d
@@ -198,9 +239,13 @@ def f4_roles():
 
 
 def one_kernel_roles():
-    """Passes whose eligible F(4x4) layers run as one kernel (mopa_wino4_conv: no V / M in HBM)."""
+    """Passes whose eligible F(4x4) layers run as one kernel (mopa_wino4_conv: no V / M in HBM; "fwd": the training forward pass of
+    the layers whose weight gradient runs from x and dY -- mopa_wino4_wgrad_fused -- and so needs no V; "wgrad": that kernel)."""
     from mopa_amd import dense2d
-    return tuple(dense2d.WINO4_DIRECT_ROLES) if dense2d.WINO4_DIRECT else ()
+    r = tuple(dense2d.WINO4_DIRECT_ROLES) if dense2d.WINO4_DIRECT else ()
+    if dense2d.WINO4_WGRAD_FUSED:
+        r += (("fwd",) if dense2d.WINO4_DIRECT and "fwd_eval" in r else ()) + ("wgrad",)
+    return r
 
 
 def dense2d_streams():
@@ -1039,11 +1084,11 @@ def main():
         # files carry the commit they were taken at (profiles/collect_final.py), the line says so
         wl_key = "3d" if not joint else ("kitti" if kitti else "mopa" if mopa else "joint")
         def _prof(name):   # committed profile summaries: this round's if present, else the previous round's
-            for rnd in ("r5", "r4", "r3"):
+            for rnd in ("r6", "r5", "r4", "r3"):
                 q = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
                 if os.path.exists(q):
                     return q
-            return os.path.join(ROOT, "profiles", f"r5_{name}")
+            return os.path.join(ROOT, "profiles", f"r6_{name}")
 
         fam_path = _prof("rocprof_family.json")
         famj = json.load(open(fam_path)) if os.path.exists(fam_path) else {}
@@ -1138,6 +1183,27 @@ def main():
             if rd:   # the same flops over rocprofv3's kernel durations of this command (no launch gaps): the two figures bracket the truth
                 roof["frac_rocprof"] = round(roof["algorithmic_flops_per_launch"] / (rd["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4)
                 roof["avg_launch_us_rocprof"], roof["rocprof_commit"] = rd["avg_us"], famj.get("commit")
+        roof_wgrad = None
+        kw = timer2d.wgrad_summary() if joint else None
+        if kw:
+            roof_wgrad = {"bound": "mfma", "achieved": round(kw["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(kw["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": None,
+                          "kernel": "weight gradients of the 2D network: k_conv2d_wgrad_mfma (direct and transform-domain batches) / k_wino4_wgrad "
+                                    "(one-kernel F(4x4): x and dY in) / k_stem_wgrad_mfma + their ordered slab reductions (k_reduce_slabs2, "
+                                    "k_wino4_dw), one bracket per weight gradient, flops as executed (36 T Cin Cout 2 for an F(4x4) layer)",
+                          "launches_per_step": kw["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps,
+                          "avg_launch_us": round(kw["avg_us"], 2),
+                          "algorithmic_flops_per_launch": round(kw["tflops"] * 1e12 * kw["avg_us"] * 1e-6),
+                          "stream_configuration": "the weight-gradient stream beside the backward-data chain (as timed for `value`)"
+                          if dense2d_streams() else "the main stream",
+                          "note": "the transforms that feed the two-operand form (k_wino4_dout, the V kept or recomputed) are not in the brackets"}
+            rw = famj.get(wl_key, {}).get("wgrad_mfma")
+            if rw and not _fresh(rw, roof_wgrad["launches_per_step"]):
+                roof_wgrad["rocprof_note"] = f"{os.path.relpath(fam_path, ROOT)} was taken with another launch count per step: not used"
+                rw = None
+            if rw:
+                roof_wgrad["frac_rocprof"] = round(roof_wgrad["algorithmic_flops_per_launch"] / (rw["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4)
+                roof_wgrad["avg_launch_us_rocprof"], roof_wgrad["rocprof_commit"] = rw["avg_us"], famj.get("commit")
         wl = ("MoPA iteration per GPU (BASELINE configs[3] shape): "
               f"{B} source + {B} target scans, CE + cross-modal KL + pseudo-label CE + SAM-mask consistency loss + "
               "Valid Ground-based Insertion of a 500-pt object per target scan on the device (overlap test, ground cells, "
@@ -1168,6 +1234,7 @@ def main():
                        "gradient_buckets_2d_bytes": bucket_bytes,
                        "winograd_f4_roles": ",".join(f4_roles()) if joint else None,
                        "winograd_f4_one_kernel_roles": (",".join(one_kernel_roles()) or None) if joint else None,
+                       "gradient_error_vs_fp64": gradient_error_vs_fp64() if joint else None,
                        "scn_executor": "native (one C-ABI call per pass; bracketed steps walk the program from Python)" if native_default
                        else "python walk (MOPA_SCN_NATIVE=0)",
                        "net3d_pass": (None if not joint else "source + target scans as ONE sparse tensor (Net3DSeg bn_group_points: BatchNorm per domain "
@@ -1194,6 +1261,7 @@ def main():
                 f"{host_value[1]} further steps with coords / feats / labels / images handed over as HOST tensors and img_indices as "
                 "numpy arrays (the reference's collate output), uploaded on a copy stream beside the compute; not part of `value`"),
             "roofline": roof,
+            "roofline_wgrad": roof_wgrad,
             "roofline_sparse_conv": sp,
             # fabric-side bytes of ONE step, all kernels (Infinity-Cache hits included): the committed PMC passes of this workload's
             # command (profiles/make_final.sh -> traffic.py), never measured in this run -- the file and its commit say which build

@@ -7,7 +7,7 @@ Usage (repo root, after `gpurun -- bash profiles/make_final.sh`): python profile
 import collections, csv, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.abspath(__file__))
 F = os.path.join(R, "..", "gpurun_out", "final")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r6"
 TITLE = {"3d": "Net3DSeg-only training step (bs 8, 1x MI355X) -- BASELINE configs[1]",
          "joint": "joint 2D+3D xMUDA step (bs 8+8, 1x MI355X) -- BASELINE configs[2]",
          "kitti": "A2D2->SemanticKITTI-shape joint step (bs 2+2, 120,000-pt scans, 10 classes, 1x MI355X) -- BASELINE configs[4] per GPU",
@@ -17,10 +17,12 @@ CMD = {"3d": "python bench.py --workload 3d --steps 50 --warmup 5", "joint": "py
        "mopa": "python bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline"}
 STEPS = {"3d": 57, "joint": 37, "kitti": 25, "mopa": 15}   # steps traced by make_final.sh (setup + warm-up + timed + host-input steps)
 FAMILY = {"sparse_conv": ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run", "k_spconv_stem"),
-          "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32")}
+          "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32"),
+          # one launch of these = one weight gradient of the 2D network (bench.py: roofline_wgrad)
+          "wgrad_mfma": ("k_conv2d_wgrad_mfma", "k_wino4_wgrad", "k_stem_wgrad_mfma")}
 # kernels whose TIME belongs to a family's launches without being launches of their own: the ordered per-row sum behind every
 # offset-major convolution with a slab (csrc/sprun.hip: one k_spconv_run + one k_run_reduce = one convolution)
-FAMILY_EXTRA = {"sparse_conv": ("k_run_reduce",)}
+FAMILY_EXTRA = {"sparse_conv": ("k_run_reduce",), "wgrad_mfma": ("k_reduce_slabs2", "k_wino4_dw", "k_wino_dw")}
 
 
 def git(*a):

@@ -2,8 +2,9 @@
 """How much does the conv algorithm move the parameter gradients of Net2DSeg at the bench size (B images of 302x480)?
 Truth = the fp64 CPU oracle.  Configs: direct kernels only, Winograd F(2x2) (forward + backward), F(4x4) in the backward
 passes, F(4x4) in all three passes.  Prints median / 90th percentile / max of  max|g - truth| / max|truth|  over the
-parameter tensors.  Usage: python profiles/f4_gradient_noise.py [B=8]"""
-import os, sys, time
+parameter tensors, and writes them to gpurun_out/f4_gradient_noise.json (copy it to profiles/<round>_f4_gradient_noise.json: bench.py
+quotes it as config.gradient_error_vs_fp64).  Usage: python profiles/f4_gradient_noise.py [B=8]"""
+import json, os, subprocess, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.getcwd())
@@ -45,6 +46,9 @@ for k, v in P.items():
         v.requires_grad_(True)
 loss_of(net2d.net2dseg_forward(P, img.double(), idx, training=True, dropout_p=0.0)).backward()
 print(f"fp64 oracle: {time.time() - t0:.0f} s", flush=True)
+out = {"what": "max |g - g_fp64| / max |g_fp64| per parameter tensor of Net2DSeg (train mode, dropout off), median / p90 / max over the tensors; "
+               "fp64 = the CPU oracle (oracle/net2d.py)", "images": f"{B} x {H} x {W}", "points_per_image": 4000,
+       "commit": subprocess.run(("git", "rev-parse", "--short", "HEAD"), capture_output=True, text=True).stdout.strip() or None, "algorithms": {}}
 for name, roles, wg in (("direct kernels", (), False), ("F(2x2) fwd+bwd", (), True), ("F(4x4) backward", ("dgrad", "wgrad"), True),
                         ("F(4x4) fwd+bwd", ("fwd", "dgrad", "wgrad"), True)):
     g = run(roles, wg)
@@ -56,3 +60,7 @@ for name, roles, wg in (("direct kernels", (), False), ("F(2x2) fwd+bwd", (), Tr
             errs.append(float((g[k] - truth).abs().max()) / scale)
     errs = np.array(errs)
     print(f"{name:18s} median {np.median(errs):.2e}  p90 {np.percentile(errs, 90):.2e}  max {errs.max():.2e}  ({len(errs)} tensors)", flush=True)
+    out["algorithms"][name] = {"median": float(f"{np.median(errs):.3e}"), "p90": float(f"{np.percentile(errs, 90):.3e}"), "max": float(f"{errs.max():.3e}"),
+                               "tensors": len(errs), "shipped": name == "F(4x4) fwd+bwd"}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/f4_gradient_noise.json", "w"), indent=1)

@@ -85,11 +85,18 @@ def test_net2dseg_fixture_g1c_45x80_eleven_classes_index_tensor(golden_dir, trai
             _close(sd[k[4:]], v, 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("train", [True, False])
-def test_net2dseg_reference_call_shape_225x400_eleven_classes(train):
+@pytest.mark.parametrize("train,f4_roles", [(True, None), (False, None), (True, ("fwd",))])
+def test_net2dseg_reference_call_shape_225x400_eleven_classes(train, f4_roles, monkeypatch):
     """mopa/models/xmuda_arch.py:129-162 as written: B = 2, 225 x 400, 2000 points as a (2, 1000, 2) tensor, 11 classes, dual head.
     Outputs against the fp64 oracle at 1e-3 of their scale (end to end), with the fp32 oracle's own distance as the
-    yardstick; train mode also checks every parameter gradient's norm against the fp64 oracle."""
+    yardstick; train mode also checks every parameter gradient's norm against the fp64 oracle.  f4_roles = ("fwd",) (= MOPA_WINOGRAD_F4_ROLES=fwd):
+    only the forward pass uses Winograd F(4x4); backward-data and the weight gradient run the exact-product kernels (direct MFMA / F(2x2))
+    and every parameter gradient is bounded at 1 % of its norm instead of 3 % -- the non-F(4x4) weight-gradient path pinned at the
+    reference's own call shape."""
+    from mopa_amd import dense2d
+    if f4_roles is not None:
+        monkeypatch.setattr(dense2d, "F4_ROLES", tuple(f4_roles))
+    floor = 0.03 if f4_roles is None else 0.01
     B, H, W, N, C = 2, 225, 400, 2000, 11
     rng = np.random.Generator(np.random.PCG64(225400 + int(train)))
     img = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32))
@@ -133,7 +140,7 @@ def test_net2dseg_reference_call_shape_225x400_eleven_classes(train):
         # weights: ReLU masks within round-off of zero); the floor is 3 % of each tensor's norm -- the stride-1 3x3 layers run
         # F(4x4) Winograd in all three passes ("deliberate deviations": 1.4 / 2.7 / 6.7 % median / p90 / max
         # against fp64 at the 302 x 480 bench shape)
-        assert err <= max(4.0 * yard, 0.03 * tn), (k, err, yard, tn)
+        assert err <= max(4.0 * yard, floor * tn), (k, err, yard, tn)
     print("worst gradient errors (relative to the tensor's norm; HIP, fp32 oracle):", sorted(worst, reverse=True)[:5])
     sd = model.state_dict()
     for k in ("net_2d.bn1.running_mean", "net_2d.layer4.2.bn2.running_var", "net_2d.dec_conv_stage2.1.running_mean"):
