@@ -16,6 +16,7 @@
 //   (oy*IS + IY0 + ty*IDY, ox*IS + IX0 + tx*IDX), zero outside [IH][IW]; its weight slice is
 //   w[(KH0 + ty*KS) * KWF + (KW0 + tx*KS)] of shape [Cin][Cout].
 #include "common.h"
+#include "wino4.h"
 #include "weight_forms.h"
 #include <stdlib.h>
 #include <string.h>
@@ -1080,6 +1081,10 @@ int wino4_dw_launch(const float* slabs, int nsplit, int Cin, int Cout, float* dw
 }
 
 static void wino_wgrad_split(int np, int64_t T, int Cin, int Cout, int* nsplit, int* m_per_split) {
+  if (wgemm_tn_ok(np, T, Cin, Cout)) {   // the ring-buffered GEMM (wgemm.hip) has its own K ranges
+    wgemm_tn_split(np, T, Cin, Cout, nsplit, m_per_split);
+    return;
+  }
   const int64_t tiles = (int64_t)np * (Cin / 64) * (Cout / 64);
   int64_t ns = cdiv64(2048, tiles);   // (768 ... 2048 target blocks: same joint step within 0.5 %)
   const int64_t maxs = cdiv64(T, 128);
@@ -1111,8 +1116,12 @@ static int wino_bwd_weight(int np, const float* V, const float* dM, int32_t T, i
   g.Cin = Cin; g.Cout = Cout; g.ld_in = Cin; g.ld_out = Cout;
   hipStream_t st = (hipStream_t)stream;
   float* slabs = (float*)ws;
-  dim3 grid(np, (Cin / 64) * (Cout / 64), ns);
-  k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(V, dM, slabs, g, mps, (int64_t)T * Cin, (int64_t)T * Cout);
+  if (wgemm_tn_ok(np, T, Cin, Cout)) {
+    if (wgemm_tn_launch(np, V, dM, T, Cin, Cout, slabs, ns, mps, st) != MOPA_OK) return MOPA_ERR_LAUNCH;
+  } else {
+    dim3 grid(np, (Cin / 64) * (Cout / 64), ns);
+    k_conv2d_wgrad_mfma<1, 1><<<grid, 256, 0, st>>>(V, dM, slabs, g, mps, (int64_t)T * Cin, (int64_t)T * Cout);
+  }
   const int64_t n = (int64_t)Cin * Cout;
   if (np == 16) k_wino_dw<<<(unsigned)cdiv64(n, 16), 256, 0, st>>>(slabs, ns, n, dweight, flags & 1, (flags >> 1) & 1, Cin, Cout);
   else return wino4_dw_launch(slabs, ns, Cin, Cout, dweight, flags, st);

@@ -45,3 +45,8 @@ __device__ __forceinline__ void w4_gt(const float u[6], float g[3]) {   // g = G
 // conv2d.hip: slabs [nsplit][36][Cin][Cout] summed in split order, then dW = G^T dU G written (flags bit 0: accumulated) into the igemm
 // layout or (flags bit 1) torch's OIHW tensor
 int wino4_dw_launch(const float* slabs, int nsplit, int Cin, int Cout, float* dweight, int flags, hipStream_t st);
+
+// wgemm.hip: the transform-domain weight gradient dU[p] = V[p]^T dM[p] of the 128-aligned layers as a ring-buffered LDS-DMA GEMM
+bool wgemm_tn_ok(int np, int64_t T, int Cin, int Cout);
+void wgemm_tn_split(int np, int64_t T, int Cin, int Cout, int* nsplit, int* k_per_split);
+int wgemm_tn_launch(int np, const float* V, const float* dM, int T, int Cin, int Cout, float* slabs, int nsplit, int k_per_split, hipStream_t st);

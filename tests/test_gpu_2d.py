@@ -981,6 +981,37 @@ def test_wino4_one_kernel_weight_gradient_vs_fp64(cin, cout, B, H, W, acc, G, c0
     assert float((outs[0] - dw2).abs().max()) / scale < 2e-5
 
 
+@pytest.mark.parametrize("F,cin,cout,B,H,W,acc", [(4, 128, 128, 2, 32, 64, False), (4, 256, 128, 1, 64, 64, True), (4, 128, 384, 4, 16, 16, False),
+                                                  (2, 128, 256, 2, 16, 32, True), (4, 256, 256, 16, 38, 60, False)])
+def test_transform_domain_weight_gradient_gemm_vs_fp64(F, cin, cout, B, H, W, acc, monkeypatch):
+    """The ring-buffered LDS-DMA GEMM behind mopa_wino4_bwd_weight / mopa_wino_bwd_weight for 128-aligned channels (csrc/wgemm.hip:
+    dU[p] = V[p]^T dM[p], 128 x 128 blocks, split-K slabs) -- through dense2d.wino_wgrad (input transform, dout transform, GEMM, G^T dU G)
+    against torch autograd's fp64 conv2d weight gradient, and against k_conv2d_wgrad_mfma (MOPA_WGEMM=0 in a second process is the A/B
+    switch; here: the same call on a tile count that is NOT a multiple of 16, which the GEMM refuses).  One range and several ranges of
+    tiles, both transform sizes, accumulation into an existing OIHW gradient, the layer3 shape of the bench (2400 tiles)."""
+    import torch.nn.functional as Fn
+    from mopa_amd import dense2d
+    T = B * ((H + F - 1) // F) * ((W + F - 1) // F)
+    assert T % 16 == 0
+    rng = np.random.Generator(np.random.PCG64(5 + cin + H))
+    x = torch.from_numpy(rng.standard_normal((B * H * W, cin)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B * H * W, cout)).astype(np.float32)).cuda()
+    prev = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)).cuda()
+    wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    Fn.conv2d(x.reshape(B, H, W, cin).permute(0, 3, 1, 2).double().cpu(), wr, None, padding=1).backward(
+        dy.reshape(B, H, W, cout).permute(0, 3, 1, 2).double().cpu())
+    ref = wr.grad + (prev.double().cpu() if acc else 0)
+    outs = []
+    for _ in range(2):
+        dw = prev.clone() if acc else torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+        dense2d.wino_wgrad(dense2d.Img(x, B, H, W), dense2d.Img(dy, B, H, W), cin, cout, dw, accumulate=acc, F=F, fused=False)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])   # deterministic
+    scale = float(ref.abs().max())
+    err = float((outs[0].double().cpu() - ref).abs().max()) / scale
+    assert err < (3e-5 if F == 4 else 1e-5), err
+
+
 def test_one_kernel_convolution_picks_32_tiles_per_item_on_the_long_layers(request):
     """mopa_wino4_conv by shape: the decoder's full-resolution layer (64 -> 128 backward-data at 4 x 304 x 480: 1140 tile groups x 2 = 2280
     work items of 32 tiles >= 8 per CU) runs k_wino4_conv32 -- the bits of the forced 32-tile kernel -- and agrees with the 16-tile kernel
