@@ -119,6 +119,8 @@ SIGNATURES = {
     "mopa_wino4_weight_t": ("i", "piiipp"),
     "mopa_wino4_weight_f": ("i", "piiipp"),
     "mopa_wino4_conv": ("i", "pipppiiiiiiipiipp"),
+    "mopa_wino4_weight_q": ("i", "piiipp"),
+    "mopa_wino4_conv9": ("i", "pipppiiiiiiipiip"),
     "mopa_wino4_conv_tiles32": ("i", "i"),
     "mopa_conv2d_weight_forms_batched": ("i", "pip"),
     "mopa_wino4_gemm_output": ("i", "ppppiiiiiiip"),

@@ -39,6 +39,8 @@ SECTIONS = [
  * Replaces the cuDNN calls behind mopa/models/resnet34_unet.py:93 (conv1 7x7), :97-101 (layer1-4), :104-110,:115-129 (decoder)."""),
     ("wino2d.hip", """Winograd F(2x2,3x3) transforms for the stride-1 3x3 convolutions with >= 128 channels (same reference call sites as
  * conv2d.hip); the 16 point-wise GEMMs run through mopa_conv2d_igemm_batched."""),
+    ("wino4c9.hip", """The same one-kernel F(4x4) convolution as mopa_wino4_conv (wino2d.hip), nine transform points per wave on v_mfma_f32_32x32x2_f32:
+ * half the weight bytes per tile and a quarter of the weight loads per matrix instruction (same reference call sites)."""),
     ("wino4wg.hip", """Weight gradient of the stride-1 3x3 convolutions through Winograd F(4x4,3x3) in ONE kernel (x and dY in, dW out: neither
  * transformed operand reaches HBM) -- torch autograd's conv2d weight gradient of layer1's BasicBlocks and the decoder's 3x3
  * convolutions (mopa/models/resnet34_unet.py:97,104-110,176-182); mopa_wino4_bwd_weight (conv2d.hip) is the two-operand form."""),

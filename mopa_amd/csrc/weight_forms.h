@@ -65,7 +65,9 @@ __device__ __forceinline__ void wf_wino2_body(const float* __restrict__ w, int O
 
 // F(4x4,3x3): U[p][r][c], p = 6*i + j; transpose = 1: U^T[p][c][r] (k_wino4_w); transpose = 2: the B-operand fragments of
 // k_wino4_conv, U_f[p][r / 16][c / 16][lane = 16 ((r % 16) / 4) + c % 16][r % 4] -- one 1-KiB run per (point, 16 input channels,
-// 16 output channels), lane-linear, the four k steps of a lane adjacent.
+// 16 output channels), lane-linear, the four k steps of a lane adjacent; transpose = 3: the B-operand fragments of k_wino4_conv9 (wino4c9.hip),
+// U_q[p][r / 16][c / 32][(r % 16) / 8][lane = 32 (r % 2) + c % 32][(r % 8) / 2] -- two 1-KiB runs per (point, 16 input channels, 32 output
+// channels): v_mfma_f32_32x32x2_f32's lane = (k parity, column), the four k pairs of a run adjacent.
 __device__ __forceinline__ void wf_wino4_body(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ U, int transpose,
                                               int i0, int istep) {
   const int R = dgrad ? O : I, C = dgrad ? I : O;
@@ -89,7 +91,8 @@ __device__ __forceinline__ void wf_wino4_body(const float* __restrict__ w, int O
       float u[6];
       w4_g(t[a], u);
       const int64_t at = transpose == 2 ? ((((int64_t)(r >> 4) * (C >> 4) + (c >> 4)) * 64 + (((r & 15) >> 2) << 4) + (c & 15)) << 2) + (r & 3)
-                                        : (transpose ? c * R + r : i);
+                         : transpose == 3 ? (((((int64_t)(r >> 4) * (C >> 5) + (c >> 5)) * 2 + ((r & 15) >> 3)) * 64 + ((r & 1) << 5) + (c & 31)) << 2) + ((r & 7) >> 1)
+                                          : (transpose ? c * R + r : i);
 #pragma unroll
       for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * n + at] = u[b];
     }

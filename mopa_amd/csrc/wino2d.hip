@@ -398,7 +398,8 @@ MOPA_API int mopa_wino4_dout(const float* dy, int32_t ld, int32_t B, int32_t H, 
 // Every stale weight form of the 2D network in ONE launch: after an optimizer step the first use of each conv re-laid out
 // its weight with a tiny kernel of its own (igemm layouts, Winograd transforms: ~95 launches of 8-10 us per joint step, serialised
 // on the main stream between the convolutions).  desc_host [n][8] int64: source, destination, O, I, KH, KW, kind (0 = igemm
-// layout, 1 = F(2x2) transform, 2 = F(4x4) transform), arg (kind 0: mode 0-3; kinds 1, 2: bit 0 = dgrad, bits 1-2 = 1 transposed / 2 fragment layout (F(4x4) only)).
+// layout, 1 = F(2x2) transform, 2 = F(4x4) transform), arg (kind 0: mode 0-3; kinds 1, 2: bit 0 = dgrad, bits 1-2 = 1 transposed / 2 fragment layout of
+// mopa_wino4_conv / 3 fragment layout of mopa_wino4_conv9 (F(4x4) only)).
 #define WF_MAX 48
 struct WeightFormDescs { int64_t src[WF_MAX], dst[WF_MAX]; int32_t O[WF_MAX], I[WF_MAX], KH[WF_MAX], KW[WF_MAX], kind[WF_MAX], arg[WF_MAX]; };
 __global__ void k_weight_forms_batched(const WeightFormDescs d) {
@@ -420,8 +421,9 @@ MOPA_API int mopa_conv2d_weight_forms_batched(const int64_t* desc_host, int32_t 
     const int64_t O = r[2], I = r[3], KH = r[4], KW = r[5], kind = r[6], arg = r[7];
     if (!r[0] || !r[1] || O <= 0 || I <= 0 || kind < 0 || kind > 2) return MOPA_ERR_ARG;
     if (kind == 0 && (KH <= 0 || KW <= 0 || arg < 0 || arg > 3 || O * I * KH * KW >= (1ll << 31))) return MOPA_ERR_ARG;
-    if (kind != 0 && (KH != 3 || KW != 3 || arg < 0 || arg > 5 || (kind == 1 && (arg & 6))
-                      || ((arg & 4) && (O % 16 || I % 16)))) return MOPA_ERR_ARG;
+    if (kind != 0 && (KH != 3 || KW != 3 || arg < 0 || arg > 7 || (kind == 1 && (arg & 6))
+                      || ((arg & 6) == 4 && (O % 16 || I % 16))
+                      || ((arg & 6) == 6 && (((arg & 1) ? O : I) % 16 || ((arg & 1) ? I : O) % 32)))) return MOPA_ERR_ARG;   // fragment layouts 2 / 3
     d.src[e] = r[0]; d.dst[e] = r[1]; d.O[e] = (int)O; d.I[e] = (int)I; d.KH[e] = (int)KH; d.KW[e] = (int)KW; d.kind[e] = (int)kind; d.arg[e] = (int)arg;
     const int64_t ne = kind == 0 ? O * I * KH * KW : O * I;
     if (ne > nmax) nmax = ne;
@@ -1302,6 +1304,17 @@ __global__ __launch_bounds__(512, 2) void k_wino4_conv32(const float* __restrict
 MOPA_API int mopa_wino4_weight_f(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* Uf, void* stream) {
   if (O <= 0 || I <= 0 || O % 16 || I % 16) return MOPA_ERR_ARG;
   k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, Uf, 2);
+  MOPA_CHECK_LAUNCH();
+  return MOPA_OK;
+}
+
+// B-operand fragments of k_wino4_conv9 (wino4c9.hip) from the OIHW weight (weight_forms.h: transpose = 3); dgrad as in mopa_wino4_weight:
+// Uq[p][ci / 16][co / 32][(ci % 16) / 8][lane = 32 (ci % 2) + co % 32][(ci % 8) / 2].  (Here, not in wino4c9.hip: the same kernel and
+// translation unit as the other forms, so that the batched refresh rebuilds the same bits.)
+MOPA_API int mopa_wino4_weight_q(const float* weight, int32_t O, int32_t I, int32_t dgrad, float* Uq, void* stream) {
+  const int R = dgrad ? O : I, C = dgrad ? I : O;
+  if (O <= 0 || I <= 0 || R % 16 || C % 32) return MOPA_ERR_ARG;
+  k_wino4_w<<<stream_grid((int64_t)O * I, 256), 256, 0, (hipStream_t)stream>>>(weight, O, I, dgrad, Uq, 3);
   MOPA_CHECK_LAUNCH();
   return MOPA_OK;
 }

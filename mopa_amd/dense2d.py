@@ -174,14 +174,15 @@ def relayout_cached(w, shape, O, I, KH, KW, mode):
 def wino_weight_cached(w, dgrad: bool, F: int = 2, transposed: int = 0):
     """U[(F+2)^2][R][C] = G g G^T of a 3x3 OIHW weight (dgrad: rotated + transposed filter), cached per weight version.
     transposed (F = 4 only): 1 = U^T[36][C][R], the k-contiguous operand of the fused GEMM + output-transform kernel; 2 = the MFMA
-    B-operand fragments of the one-kernel convolution (mopa_wino4_conv), [36][R / 16][C / 16][64 lanes][4]."""
+    B-operand fragments of the one-kernel convolution (mopa_wino4_conv), [36][R / 16][C / 16][64 lanes][4]; 3 = those of its second
+    form (mopa_wino4_conv9), [36][R / 16][C / 32][2][64 lanes][4]."""
     O, I = w.shape[0], w.shape[1]
     transposed = int(transposed)
 
     def build():
         R, C = (O if dgrad else I), (I if dgrad else O)
         u = torch.empty((F + 2) ** 2, (C if transposed == 1 else R), (R if transposed == 1 else C), dtype=torch.float32, device=w.device)
-        name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f")[transposed]
+        name = "mopa_wino_weight" if F == 2 else ("mopa_wino4_weight", "mopa_wino4_weight_t", "mopa_wino4_weight_f", "mopa_wino4_weight_q")[transposed]
         call(name, ptr(w), O, I, int(dgrad), ptr(u), stream())
         u._mopa_wino_layout = (F, transposed)   # (layouts 0 and 2 have the same shape when R == C: wino_conv checks this tag)
         return u
@@ -227,9 +228,22 @@ def wino4_direct(cin, cout, B, H, W, role="fwd"):
             and T >= (WINO4_DIRECT_MIN_TILES if cout <= 64 else 2 * WINO4_DIRECT_MIN_TILES))
 
 
+# The one-kernel convolution's second form (mopa_wino4_conv9, csrc/wino4c9.hip: nine transform points per wave on 32x32x2 MFMAs, raw
+# patches staged by LDS-DMA): 0.75-0.94 x the first form's time on every layer shape of the table (profiles/bench_conv9.py) -- used
+# wherever the pass keeps no V (it has no V by-product) and the output channels come in blocks of 64.  MOPA_WINO4_CONV9=0 = off.
+WINO4_CONV9 = os.environ.get("MOPA_WINO4_CONV9", "1") != "0"
+
+
+def wino4_conv9(cin, cout, role):
+    return WINO4_CONV9 and role != "fwd" and cin % 16 == 0 and cout % 64 == 0
+
+
 def wino4_layout(cin, cout, B, H, W, role="fwd"):
-    """Weight form of an F(4x4) layer: 2 = fragments (one-kernel convolution), 1 = transposed (fused GEMM + output transform), 0."""
-    return 2 if wino4_direct(cin, cout, B, H, W, role) else int(wino4_fused(cin, cout, B, H, W))
+    """Weight form of an F(4x4) layer: 3 / 2 = fragments (one-kernel convolution, second / first form), 1 = transposed (fused GEMM +
+    output transform), 0."""
+    if wino4_direct(cin, cout, B, H, W, role):
+        return 3 if wino4_conv9(cin, cout, role) else 2
+    return int(wino4_fused(cin, cout, B, H, W))
 
 
 def wino_tile(cin, cout, k, s, p, B, H, W, role="fwd"):
@@ -284,6 +298,13 @@ def wino_conv(x_p, ld_in, B, H, W, cin, cout, U, bias, out_p, ld_out, accumulate
     th, tw = (H + F - 1) // F, (W + F - 1) // F
     T, NP = B * th * tw, (F + 2) ** 2
     sfx = "" if F == 2 else "4"
+    if F == 4 and wino4_direct(cin, cout, B, H, W, role) and wino4_conv9(cin, cout, role) and not want_v:
+        if tuple(U.shape) != (36, cin, cout) or getattr(U, "_mopa_wino_layout", (4, 3)) != (4, 3):
+            raise RuntimeError("wino_conv: the nine-point one-kernel F(4x4) path takes its own fragment form (wino_weight_cached(..., transposed=3))")
+        call("mopa_wino4_conv9", x_p, ld_in, ptr(U), ptr(bias) if bias is not None else None, out_p, ld_out, B, H, W, cin, cout,
+             int(accumulate), ptr(bn_in[0]) if bn_in is not None else None, bn_in[1] if bn_in is not None else 1,
+             bn_in[2] if bn_in is not None else 0, stream())
+        return None
     if F == 4 and wino4_direct(cin, cout, B, H, W, role):
         if tuple(U.shape) != (36, cin, cout) or getattr(U, "_mopa_wino_layout", (4, 2)) != (4, 2):
             raise RuntimeError("wino_conv: the one-kernel F(4x4) path takes the fragment weight form (wino_weight_cached(..., transposed=2))")

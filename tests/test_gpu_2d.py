@@ -495,15 +495,21 @@ def test_cached_weight_layouts_follow_every_kind_of_weight_update():
     assert len(calls) == 1 and float(ret) == calls[0] and opt.t == t0 + 1
 
 
-def test_batched_weight_form_refresh_gives_the_bits_of_the_single_kernels(monkeypatch):
+@pytest.mark.parametrize("one_kernel", [False, True])
+def test_batched_weight_form_refresh_gives_the_bits_of_the_single_kernels(one_kernel, monkeypatch):
     """After a weight update every stale igemm layout / Winograd transform of the network is rebuilt in ONE launch
     (mopa_conv2d_weight_forms_batched, shared device code with the one-form kernels): training steps with the batched refresh
-    on and off must give identical logits."""
+    on and off must give identical logits.  one_kernel: the one-kernel convolutions forced on at this size, so that the fragment forms
+    (layouts 2 and 3: mopa_wino4_weight_f / _q) are among the refreshed ones -- a form whose two builders differ in the last bit moves
+    ReLU masks and with them every gradient by percent (found with layout 3 built in another translation unit)."""
     from mopa_amd import dense2d, synth
     from mopa_amd.config import default_cfg
     from mopa_amd.models.build import build_model_2d
     from mopa_amd.optim import FlatAdam
     b = synth.make_batch(2, H=64, W=96)
+    if one_kernel:
+        monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 0)
+        monkeypatch.setattr(dense2d, "WINO4_WGRAD_FUSED_MIN_TILES", 0)
 
     def run(batched):
         monkeypatch.setattr(dense2d, "BATCHED_REFRESH", batched)
@@ -1012,6 +1018,74 @@ def test_transform_domain_weight_gradient_gemm_vs_fp64(F, cin, cout, B, H, W, ac
     assert err < (3e-5 if F == 4 else 1e-5), err
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,acc,dgrad,G,c0", [(64, 64, 2, 37, 51, False, False, 0, 0), (128, 64, 3, 21, 30, True, False, 0, 0),
+                                                          (64, 128, 2, 16, 24, False, True, 0, 0), (64, 64, 2, 19, 22, False, False, 2, 0),
+                                                          (128, 128, 3, 9, 13, True, True, 1, 0), (128, 128, 1, 64, 64, False, False, 0, 0),
+                                                          (128, 64, 2, 40, 36, False, False, 2, 64), (64, 64, 16, 76, 120, False, False, 0, 0)])
+def test_wino4_nine_point_one_kernel_convolution_vs_fp64_conv(cin, cout, B, H, W, acc, dgrad, G, c0, monkeypatch):
+    """mopa_wino4_conv9 (csrc/wino4c9.hip: the one-kernel F(4x4) convolution with nine transform points per wave on v_mfma_f32_32x32x2_f32,
+    raw patches staged by LDS-DMA, the four partial output transforms exchanged through LDS) through dense2d.wino_conv against an fp64
+    conv3x3 (padding 1; dgrad: the transposed convolution's weight form) and against the first form (mopa_wino4_conv): ragged tiles, tile
+    groups beyond T, the input as a column slice of a wider buffer, bias, accumulation, a deferred BatchNorm + ReLU on the way in for G
+    image groups (c0 > 0: the lower channels pass through), and a shape with many workgroups in flight
+    (the LDS-DMA ordering bug of its first version only showed under load)."""
+    import torch.nn.functional as F
+    from mopa_amd import dense2d
+    from mopa_amd._lib import call, ptr, stream
+    from mopa_amd.dense2d import bn_fwd_groups
+    rng = np.random.Generator(np.random.PCG64(9000 + cin + W))
+    wide = torch.from_numpy(rng.standard_normal((B * H * W, cin + 64)).astype(np.float32)).cuda()
+    if c0:
+        wide[:, 64:64 + c0].abs_()
+    xin = dense2d.Img(wide, B, H, W, 64, cin)
+    x = wide[:, 64:].contiguous()
+    stats = None
+    if G:
+        cn = cin - c0
+        P = {"bn.weight": torch.linspace(0.5, 1.5, cn).cuda(), "bn.bias": torch.linspace(-1, 1, cn).cuda(),
+             "bn.running_mean": torch.zeros(cn, device="cuda"), "bn.running_var": torch.ones(cn, device="cuda")}
+        stats = torch.empty(G, 4, cn, device="cuda")
+        y = dense2d.new_img(B, H, W, cn, "cuda")
+        bn_fwd_groups(dense2d.Img(wide, B, H, W, 64 + c0, cn), y, P, "bn", 1, None, True, stats, G)
+        x = torch.cat([x[:, :c0], y.t], 1).contiguous()
+    w = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3) if dgrad else (cout, cin, 3, 3)) * 0.05).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+    prev = torch.from_numpy(rng.standard_normal((B * H * W, cout)).astype(np.float32)).cuda()
+    wref = w.flip(2, 3).transpose(0, 1) if dgrad else w
+    ref = F.conv2d(x.reshape(B, H, W, cin).permute(0, 3, 1, 2).double().cpu(), wref.double().cpu(), None if acc else bias.double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    if acc:
+        ref = ref + prev.double().cpu()
+    O, I = (cin, cout) if dgrad else (cout, cin)
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT", True)
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT_ROLES", ("fwd", "fwd_eval", "dgrad"))
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT_MIN_TILES", 0)
+    monkeypatch.setattr(dense2d, "WINO4_DIRECT_MAX_CIN", 512)
+    outs = []
+    for nine in (True, False):
+        if not nine and cin % 64:
+            break
+        monkeypatch.setattr(dense2d, "WINO4_CONV9", nine)
+        assert dense2d.wino4_layout(cin, cout, B, H, W, "fwd_eval") == (3 if nine else 2)
+        U = torch.empty(36, cin, cout, device="cuda")
+        call("mopa_wino4_weight_q" if nine else "mopa_wino4_weight_f", ptr(w), O, I, int(dgrad), ptr(U), stream())
+        U._mopa_wino_layout = (4, 3 if nine else 2)
+        out = prev.clone() if acc else torch.full((B * H * W, cout), float("nan"), device="cuda")
+        V = dense2d.wino_conv(xin.p, xin.ld, B, H, W, cin, cout, U, None if acc else bias, ptr(out), cout, accumulate=acc, F=4,
+                              bn_in=(stats, G, c0) if G else None, role="fwd_eval", want_v=False)
+        assert V is None
+        _close(out, ref.float().numpy(), rtol=1e-4, atol=3e-5)
+        outs.append(out)
+    if len(outs) == 2:
+        _close(outs[0], outs[1].cpu(), rtol=1e-4, atol=2e-5)
+    o2 = prev.clone() if acc else torch.empty_like(outs[0])   # deterministic
+    U = torch.empty(36, cin, cout, device="cuda")
+    call("mopa_wino4_weight_q", ptr(w), O, I, int(dgrad), ptr(U), stream())
+    call("mopa_wino4_conv9", xin.p, xin.ld, ptr(U), None if acc else ptr(bias), ptr(o2), cout, B, H, W, cin, cout, int(acc),
+         ptr(stats), max(G, 1), c0, stream())
+    assert torch.equal(o2, outs[0])
+
+
 def test_one_kernel_convolution_picks_32_tiles_per_item_on_the_long_layers(request):
     """mopa_wino4_conv by shape: the decoder's full-resolution layer (64 -> 128 backward-data at 4 x 304 x 480: 1140 tile groups x 2 = 2280
     work items of 32 tiles >= 8 per CU) runs k_wino4_conv32 -- the bits of the forced 32-tile kernel -- and agrees with the 16-tile kernel
@@ -1067,9 +1141,11 @@ def test_one_kernel_convolution_network_level(monkeypatch):
     inner = dense2d.call
     monkeypatch.setattr(dense2d, "call", lambda name, *a: (calls.append(name), inner(name, *a))[1])
     la, ga, ba = run(False)
-    assert calls.count("mopa_wino4_conv") == 0
+    assert calls.count("mopa_wino4_conv") + calls.count("mopa_wino4_conv9") == 0
     lb, gb, bb = run(True)
-    assert calls.count("mopa_wino4_conv") >= 20, calls.count("mopa_wino4_conv")
+    # (both forms: mopa_wino4_conv where V is kept for a two-operand weight gradient, mopa_wino4_conv9 elsewhere)
+    assert calls.count("mopa_wino4_conv") + calls.count("mopa_wino4_conv9") >= 20, (calls.count("mopa_wino4_conv"), calls.count("mopa_wino4_conv9"))
+    assert calls.count("mopa_wino4_conv9") >= 8
     _close(lb, la.cpu(), rtol=1e-3, atol=2e-4)
     for k in ba:
         _close(bb[k], ba[k].cpu(), rtol=1e-4, atol=1e-5)

@@ -154,7 +154,11 @@ def test_conv_algorithm_choice(monkeypatch):
     assert d(64, 64, 16, 152, 240, "dgrad") and d(64, 128, 16, 304, 480, "dgrad") and d(128, 64, 16, 304, 480, "fwd_eval")
     assert not d(128, 64, 16, 304, 480, "fwd") and not d(128, 128, 16, 76, 120, "dgrad") and not d(256, 256, 16, 152, 240, "dgrad")
     assert not d(64, 64, 4, 152, 240, "dgrad")   # (9,120 tiles)
-    assert dense2d.wino4_layout(64, 64, 16, 152, 240, "dgrad") == 2 and dense2d.wino4_layout(64, 64, 16, 152, 240, "fwd") == 1
+    # ... in its second form (nine points per wave: fragment layout 3) wherever no V is kept and the output channels come in 64s
+    assert dense2d.wino4_layout(64, 64, 16, 152, 240, "dgrad") == 3 and dense2d.wino4_layout(64, 64, 16, 152, 240, "fwd") == 1
+    monkeypatch.setattr(dense2d, "WINO4_CONV9", False)
+    assert dense2d.wino4_layout(64, 64, 16, 152, 240, "dgrad") == 2
+    monkeypatch.setattr(dense2d, "WINO4_CONV9", True)
     # a deferred BatchNorm needs an F(4x4) consumer (and, in training, its transform-domain weight gradient)
     import torch
     op = dense2d.ConvOp(torch.empty(64, 128, 3, 3), None, 3, 1, 1)
@@ -274,7 +278,7 @@ def test_dispatcher_follows_the_measured_algorithm_table():
         F = dense2d.wino_tile(cin, cout, 3, 1, 1, B, H, W, "fwd" if role == "fwd_eval" else role)
         if F != 4:
             return {0: "direct", 2: "F2"}[F]
-        return {2: "F4 one", 1: "F4 fused", 0: "F4"}[dense2d.wino4_layout(cin, cout, B, H, W, role)]
+        return {3: "F4 one", 2: "F4 one", 1: "F4 fused", 0: "F4"}[dense2d.wino4_layout(cin, cout, B, H, W, role)]   # (3: its nine-point form)
 
     for r in rows:
         for role, picked in r["chosen"].items():
