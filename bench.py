@@ -196,9 +196,9 @@ class Conv2dTimer:
                 e.record()
                 timer.wgrad_records.append((s, e, 0, fl, fl))
                 return r
-            if not timer.enabled or name not in ("mopa_wino4_gemm_output", "mopa_wino4_conv"):
+            if not timer.enabled or name not in ("mopa_wino4_gemm_output", "mopa_wino4_conv", "mopa_wino4_conv9"):
                 return inner_call(name, *a)
-            one = name == "mopa_wino4_conv"   # the one-kernel convolution: input transform + GEMMs + output transform (no V)
+            one = name != "mopa_wino4_gemm_output"   # the one-kernel convolutions: input transform + GEMMs + output transform (no V)
             B, H, W, cin, cout = (a[6], a[7], a[8], a[9], a[10]) if one else (a[5], a[6], a[7], a[8], a[9])
             T = B * ((H + 3) // 4) * ((W + 3) // 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1157,14 +1157,14 @@ def main():
         tj = {}
         if joint and os.path.exists(tpath):                                      # of this same command (profiles/traffic.py)
             tj = json.load(open(tpath))
-            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32") if k in tj]
+            fam = [tj[k] for k in ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32", "k_wino4_conv9") if k in tj]
             if fam:
                 traffic = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam))
         if k2:  # the dominant kernel of the joint step is the dense implicit-GEMM conv: compute-bound fp32
             roof = {"bound": "mfma", "achieved": round(k2["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(k2["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": f"{os.path.relpath(tpath, ROOT)} at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes per launch)",
-                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out + k_wino4_conv / k_wino4_conv32 (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
+                    "kernel": "k_conv2d_igemm_mfma + k_wino4_gemm_out + k_wino4_conv9 / k_wino4_conv / k_wino4_conv32 (f32-operand MFMA, exact fp32 products; conv fwd + bwd-data + convT + the Winograd layers' GEMMs, flops as executed)",
                     "launches_per_step": k2["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps, "avg_launch_us": round(k2["avg_us"], 2),
                     "algorithmic_flops_per_launch": round(k2["tflops"] * 1e12 * k2["avg_us"] * 1e-6),
                     "algorithmic_bytes_per_launch": round(k2["bytes_per_launch"]),
@@ -1188,7 +1188,8 @@ def main():
         if kw:
             roof_wgrad = {"bound": "mfma", "achieved": round(kw["tflops"], 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(kw["tflops"] / F32_PEAK_TFLOPS, 4), "traffic": None,
-                          "kernel": "weight gradients of the 2D network: k_conv2d_wgrad_mfma (direct and transform-domain batches) / k_wino4_wgrad "
+                          "kernel": "weight gradients of the 2D network: k_conv2d_wgrad_mfma (direct and transform-domain batches) / k_wgemm_tn (transform-domain, "
+                                    "128-aligned channels, operands by LDS-DMA) / k_wino4_wgrad "
                                     "(one-kernel F(4x4): x and dY in) / k_stem_wgrad_mfma + their ordered slab reductions (k_reduce_slabs2, "
                                     "k_wino4_dw), one bracket per weight gradient, flops as executed (36 T Cin Cout 2 for an F(4x4) layer)",
                           "launches_per_step": kw["launches"] // max(n_ev_steps, 1), "timed_steps_bracketed": n_ev_steps,

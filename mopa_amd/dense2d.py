@@ -219,13 +219,26 @@ WINO4_DIRECT_MAX_CIN = int(os.environ.get("MOPA_WINO4_DIRECT_MAX_CIN", "128"))
 WINO4_DIRECT_ROLES = tuple(r for r in os.environ.get("MOPA_WINO4_DIRECT_ROLES", "fwd_eval,dgrad").split(",") if r)
 
 
+CUS = 256   # (MI355X; the dispatch rules below were measured there and the CPU tests must agree with the committed table)
+
+
 def wino4_direct(cin, cout, B, H, W, role="fwd"):
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    # tiles from which the one-kernel form wins (profiles/r5_algo_table.md: 4 / 8 / 16 images at 225 x 400 and 302 x 480): 64 output
-    # channels -- the input transform is done once -- from ~4,000 tiles, 128 output channels from ~8,000
+    # tiles from which the one-kernel form wins (profiles/r6_algo_table.md: 4 / 8 / 16 images at 225 x 400 and 302 x 480): 64 output
+    # channels -- the input transform is done once -- from ~4,000 tiles; 128 output channels from ~8,000 with the first form
+    # (mopa_wino4_conv) and, with the second (mopa_wino4_conv9: one 32-tile x 64-channel item per workgroup, one workgroup per CU),
+    # from 2,560 tiles WHEN its items fill their rounds of CUs to >= 0.7 (3,000 / 6,000 / 9,120 tiles: 0.77-0.78 x the two-kernel
+    # form; 2,280 / 4,560 tiles = 144 / 286 items on 256 CUs: 0.94 / 1.03 x)
     # (more than 128 output channels repeat the input transform per 64 of them: 128 -> 256 loses to the fused form by 10 %)
-    return (WINO4_DIRECT and role in WINO4_DIRECT_ROLES and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN and cout <= 128
-            and T >= (WINO4_DIRECT_MIN_TILES if cout <= 64 else 2 * WINO4_DIRECT_MIN_TILES))
+    if not (WINO4_DIRECT and role in WINO4_DIRECT_ROLES and cin % 64 == 0 and cout % 64 == 0 and cin <= WINO4_DIRECT_MAX_CIN and cout <= 128):
+        return False
+    if cout <= 64:
+        return T >= WINO4_DIRECT_MIN_TILES
+    if wino4_conv9(cin, cout, role) and T >= WINO4_DIRECT_MIN_TILES * 5 // 8:
+        items = (T + 31) // 32 * (cout // 64)
+        if items >= 0.7 * ((items + CUS - 1) // CUS * CUS):
+            return True
+    return T >= 2 * WINO4_DIRECT_MIN_TILES
 
 
 # The one-kernel convolution's second form (mopa_wino4_conv9, csrc/wino4c9.hip: nine transform points per wave on 32x32x2 MFMAs, raw
@@ -347,12 +360,16 @@ def wino_wgrad_eligible(cin, cout, k, s, p, B, H, W):
 # HBM) -- the 64 / 128-channel layers with many tiles, where the two-operand form is bound by the 2 x 2.25 x activations it moves.  The
 # training forward pass of such a layer keeps no V (it may then run as the one-kernel convolution).  MOPA_WINO4_WGRAD_FUSED=0 = off.
 WINO4_WGRAD_FUSED = os.environ.get("MOPA_WINO4_WGRAD_FUSED", "1") != "0"
-WINO4_WGRAD_FUSED_MIN_TILES = int(os.environ.get("MOPA_WINO4_WGRAD_FUSED_MIN_TILES", "8192"))
+WINO4_WGRAD_FUSED_MIN_TILES = int(os.environ.get("MOPA_WINO4_WGRAD_FUSED_MIN_TILES", "8192"))   # (64 output channels: 5/8 of it)
 
 
 def wino4_wgrad_fused(cin, cout, B, H, W):
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    return (WINO4_WGRAD_FUSED and cin % 32 == 0 and cout % 64 == 0 and cin <= 128 and cout <= 128 and T >= WINO4_WGRAD_FUSED_MIN_TILES
+    # (measured per shape at 2 / 4 / 8 / 16 images, profiles/bench_wgrad2d.py + profiles/r6_algo_table.md: the kernel itself passes the
+    #  two-operand form at ~10,000 tiles (64 -> 64) / ~18,000 (128 -> 64), but what is chosen is the PAIR forward + weight gradient: a
+    #  forward pass that keeps no V runs as mopa_wino4_conv9 -- 24-36 us faster at 6,000 tiles for 7-15 us lost here)
+    return (WINO4_WGRAD_FUSED and cin % 32 == 0 and cout % 64 == 0 and cin <= 128 and cout <= 128
+            and T >= (WINO4_WGRAD_FUSED_MIN_TILES if cout > 64 else WINO4_WGRAD_FUSED_MIN_TILES * 5 // 8)
             and bool(query("mopa_wino4_wgrad_fused_ok", B, H, W, cin, cout)))
 
 
@@ -463,6 +480,16 @@ def join_wgrad_stream(dev):
 
 
 # ------------------------------------------------------------------------------------------------ conv wrappers
+def forward_role(cin, cout, k, s, p, B, H, W, keep_v):
+    """(does the weight gradient of this forward pass want V again?, the role the forward convolution is dispatched under).  V is not
+    wanted when the weight gradient runs in one kernel from x and dY (wino4_wgrad_fused): the training forward pass then keeps nothing
+    and is dispatched like a forward pass without gradients ("fwd_eval")."""
+    a = (cin, cout, k, s, p, B, H, W)
+    F = wino_tile(*a, "fwd")
+    v_wanted = bool(keep_v and F == 4 and wino_tile(*a, "wgrad") == 4 and wino_wgrad_eligible(*a) and not wino4_wgrad_fused(cin, cout, B, H, W))
+    return v_wanted, ("fwd" if v_wanted or (keep_v and F != 4) else "fwd_eval")
+
+
 class ConvOp:
     """Conv2d(k, stride s, padding p) in NHWC through the implicit-GEMM kernels (fwd, dgrad, wgrad)."""
 
@@ -490,9 +517,7 @@ class ConvOp:
         a = (self.I, self.O, self.k, self.s, self.p, x.B, x.H, x.W)
         # does the weight gradient of this pass want V again?  Not when it runs in one kernel from x and dY (wino4_wgrad_fused): the
         # training forward pass then keeps nothing, like a forward pass without gradients
-        v_wanted = (keep_v and F == 4 and wino_tile(*a, "wgrad") == 4 and wino_wgrad_eligible(*a)
-                    and not wino4_wgrad_fused(self.I, self.O, x.B, x.H, x.W))
-        drole = "fwd" if v_wanted or (keep_v and F != 4) else "fwd_eval"
+        v_wanted, drole = forward_role(*a, keep_v)
         lazy = getattr(x, "bn", None)
         if lazy is not None and not self.takes_lazy(x.B, x.H, x.W, keep_v):
             raise RuntimeError("ConvOp.forward: this layer cannot consume a deferred BatchNorm (ask takes_lazy first)")

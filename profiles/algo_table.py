@@ -11,9 +11,12 @@ convolution is timed as
     F4         Winograd F(4x4,3x3): input transform + 36 batched GEMMs + output transform
     F4 fused   input transform + mopa_wino4_gemm_output (36 GEMMs with the output transform in the epilogue)
     F4 one     mopa_wino4_conv (input transform, GEMMs, output transform in one kernel; no V in HBM)
-and the dispatcher's choice for the roles is listed beside the fastest: `fwd` (a training forward pass: V is kept for the weight
-gradient, so the one-kernel form only saves a read -- it stays on the two-kernel forms by default), `fwd_eval` / `dgrad` (nothing is
-kept: the one-kernel form where it is eligible).  Writes profiles/r5_algo_table.md and .json (the CPU test
+    F4 one9    mopa_wino4_conv9 (round 6: the same in its second form -- nine transform points per wave on 32x32x2 MFMAs, raw patches
+               staged by LDS-DMA; csrc/wino4c9.hip)
+and the dispatcher's choice for the roles is listed beside the fastest: `fwd` (a training forward pass; since round 6 the layers whose
+weight gradient runs in one kernel from x and dY keep no V, and their training forward is dispatched like `fwd_eval` --
+dense2d.forward_role), `fwd_eval` / `dgrad` (nothing is kept: the one-kernel form where it is eligible).  Writes
+profiles/r6_algo_table.md and .json (the CPU test
 tests/test_host_logic.py::test_dispatcher_follows_the_measured_algorithm_table asserts the dispatcher still makes these choices).
 Usage: python profiles/algo_table.py"""
 import json
@@ -71,7 +74,12 @@ def choice(cin, cout, B, H, W, role):
     if F == 2:
         return "F2"
     lay = dense2d.wino4_layout(cin, cout, B, H, W, role)
-    return {2: "F4 one", 1: "F4 fused", 0: "F4"}[lay]
+    return {3: "F4 one9", 2: "F4 one", 1: "F4 fused", 0: "F4"}[lay]
+
+
+def training_fwd_choice(cin, cout, B, H, W):
+    """The training forward pass: dispatched as "fwd_eval" where the weight gradient needs no V (dense2d.forward_role)."""
+    return choice(cin, cout, B, H, W, dense2d.forward_role(cin, cout, 3, 1, 1, B, H, W, True)[1])
 
 
 def main():
@@ -106,13 +114,15 @@ def main():
                     with patched(WINO4_DIRECT=False, WINO4_FUSED_MIN_BLOCKS=0):
                         t["F4 fused"] = wino(4)
                 if cin % 64 == 0 and cout % 64 == 0 and cin <= dense2d.WINO4_DIRECT_MAX_CIN:
-                    with patched(WINO4_DIRECT=True, WINO4_DIRECT_MIN_TILES=0, WINO4_DIRECT_ROLES=("fwd_eval", "dgrad", "fwd")):
+                    with patched(WINO4_DIRECT=True, WINO4_DIRECT_MIN_TILES=0, WINO4_DIRECT_ROLES=("fwd_eval", "dgrad", "fwd"), WINO4_CONV9=False):
                         t["F4 one"] = wino(4)
+                    with patched(WINO4_DIRECT=True, WINO4_DIRECT_MIN_TILES=0, WINO4_DIRECT_ROLES=("fwd_eval", "dgrad", "fwd"), WINO4_CONV9=True):
+                        t["F4 one9"] = wino(4)
                 best = min(t, key=t.get)
                 if is_dgrad:   # (this row IS the backward-data convolution)
                     ch = {"fwd": "-", "fwd_eval": "-", "dgrad": choice(cin, cout, B, H, W, "dgrad")}
                 else:
-                    ch = {role: choice(cin, cout, B, H, W, role) for role in ("fwd", "fwd_eval")}
+                    ch = {"fwd": training_fwd_choice(cin, cout, B, H, W), "fwd_eval": choice(cin, cout, B, H, W, "fwd_eval")}
                     ch["dgrad"] = choice(cout, cin, B, H, W, "dgrad") if cin == cout else "(next row)"
                 rows.append(dict(res=f"{H0}x{W0}", B=B, layer=name, cin=cin, cout=cout, H=H, W=W, us={k: round(v, 1) for k, v in t.items()}, best=best,
                                  chosen=ch, chosen_over_best={r: round(t[c] / t[best], 3) for r, c in ch.items() if c in t}))
@@ -120,10 +130,10 @@ def main():
                 del x, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)   # (what comes back from the GPU box; copy into profiles/ afterwards)
     for d in ("gpurun_out", "profiles"):
-        json.dump(rows, open(os.path.join(ROOT, d, "r5_algo_table.json"), "w"), indent=1)
-    cols = ["direct", "F2", "F4", "F4 fused", "F4 one"]
-    md = ["# Round 5: algorithm per stride-1 3x3 layer, batch and resolution -- measured (us per forward convolution) against the dispatcher's choice",
-          "", "`python profiles/algo_table.py` on one MI355X, one stream.  **bold** = fastest; `fwd` = training forward (V kept for the weight gradient),",
+        json.dump(rows, open(os.path.join(ROOT, d, "r6_algo_table.json"), "w"), indent=1)
+    cols = ["direct", "F2", "F4", "F4 fused", "F4 one", "F4 one9"]
+    md = ["# Round 6: algorithm per stride-1 3x3 layer, batch and resolution -- measured (us per forward convolution) against the dispatcher's choice",
+          "", "`python profiles/algo_table.py` on one MI355X, one stream.  **bold** = fastest; `fwd` = training forward (V kept only where the weight gradient is the two-operand form),",
           "`fwd_eval` = a forward pass that keeps nothing; rows named `dgrad a->b` are the backward-data convolutions of the layers with cin != cout (the",
           "transposed channel counts; a symmetric layer's backward-data is its own row).",
           "`x best` = the time of the dispatcher's pick over the fastest alternative's (1.00 = it picks the fastest).", "",
@@ -136,7 +146,7 @@ def main():
     worst = max(max(r["chosen_over_best"].values()) for r in rows)
     md += ["", f"Worst pick over the {len(rows)} rows: {worst:.2f} x the fastest alternative."]
     for d in ("gpurun_out", "profiles"):
-        open(os.path.join(ROOT, d, "r5_algo_table.md"), "w").write("\n".join(md) + "\n")
+        open(os.path.join(ROOT, d, "r6_algo_table.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[-3:]))
 
 

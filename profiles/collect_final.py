@@ -17,9 +17,9 @@ CMD = {"3d": "python bench.py --workload 3d --steps 50 --warmup 5", "joint": "py
        "mopa": "python bench.py --workload mopa --steps 10 --warmup 3 --no-cpu-baseline"}
 STEPS = {"3d": 57, "joint": 37, "kitti": 25, "mopa": 15}   # steps traced by make_final.sh (setup + warm-up + timed + host-input steps)
 FAMILY = {"sparse_conv": ("k_spconv_t4", "k_spconv_pipe", "k_spconv_fwd", "k_spconv_blk", "k_spconv_run", "k_spconv_stem"),
-          "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32"),
+          "dense_mfma": ("k_conv2d_igemm_mfma", "k_wino4_gemm_out", "k_wino4_conv", "k_wino4_conv32", "k_wino4_conv9"),
           # one launch of these = one weight gradient of the 2D network (bench.py: roofline_wgrad)
-          "wgrad_mfma": ("k_conv2d_wgrad_mfma", "k_wino4_wgrad", "k_stem_wgrad_mfma")}
+          "wgrad_mfma": ("k_conv2d_wgrad_mfma", "k_wino4_wgrad", "k_stem_wgrad_mfma", "k_wgemm_tn")}
 # kernels whose TIME belongs to a family's launches without being launches of their own: the ordered per-row sum behind every
 # offset-major convolution with a slab (csrc/sprun.hip: one k_spconv_run + one k_run_reduce = one convolution)
 FAMILY_EXTRA = {"sparse_conv": ("k_run_reduce",), "wgrad_mfma": ("k_reduce_slabs2", "k_wino4_dw", "k_wino_dw")}

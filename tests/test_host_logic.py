@@ -263,34 +263,37 @@ def test_merge_domains_helpers():
 
 
 def test_dispatcher_follows_the_measured_algorithm_table():
-    """profiles/r5_algo_table.json (profiles/algo_table.py on an MI355X: every stride-1 3x3 layer shape at 4 / 8 / 16 images and at
+    """profiles/r6_algo_table.json (profiles/algo_table.py on an MI355X: every stride-1 3x3 layer shape at 4 / 8 / 16 images and at
     225 x 400 / 302 x 480, each algorithm timed) records what the dispatcher picked per role when it was taken.  The thresholds in
-    mopa_amd/dense2d.py (WINO4_DIRECT_MIN_TILES, WINO4_FUSED_MIN_BLOCKS, WINOGRAD_F4_PIXELS) are decisions read off that table:
-    changing them without re-measuring fails here.  Also: where nothing is kept (fwd_eval / backward-data) the pick is within 10 %
-    of the fastest measured alternative on every row -- except the rows the table itself flags (listed below with the reason)."""
+    mopa_amd/dense2d.py (WINO4_DIRECT_MIN_TILES, the nine-point form's fill rule, WINO4_WGRAD_FUSED_MIN_TILES, WINO4_FUSED_MIN_BLOCKS,
+    WINOGRAD_F4_PIXELS) are decisions read off that table: changing them without re-measuring fails here.  Also: where nothing is kept
+    (fwd_eval / backward-data) the pick is within 10 % of the fastest measured alternative on every row -- except the rows the table
+    itself flags (listed below with the reason)."""
     import json
     import os
     from mopa_amd import dense2d
-    rows = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r5_algo_table.json")))
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r6_algo_table.json")))
     assert len(rows) >= 48
 
     def choice(cin, cout, B, H, W, role):
         F = dense2d.wino_tile(cin, cout, 3, 1, 1, B, H, W, "fwd" if role == "fwd_eval" else role)
         if F != 4:
             return {0: "direct", 2: "F2"}[F]
-        return {3: "F4 one", 2: "F4 one", 1: "F4 fused", 0: "F4"}[dense2d.wino4_layout(cin, cout, B, H, W, role)]   # (3: its nine-point form)
+        return {3: "F4 one9", 2: "F4 one", 1: "F4 fused", 0: "F4"}[dense2d.wino4_layout(cin, cout, B, H, W, role)]
 
     for r in rows:
         for role, picked in r["chosen"].items():
             if picked in ("-", "(next row)"):
                 continue
-            assert choice(r["cin"], r["cout"], r["B"], r["H"], r["W"], role) == picked, (r["res"], r["B"], r["layer"], role)
+            # the training forward pass is dispatched as "fwd_eval" where the weight gradient needs no V (dense2d.forward_role)
+            drole = dense2d.forward_role(r["cin"], r["cout"], 3, 1, 1, r["B"], r["H"], r["W"], True)[1] if role == "fwd" else role
+            assert choice(r["cin"], r["cout"], r["B"], r["H"], r["W"], drole) == picked, (r["res"], r["B"], r["layer"], role)
         for role in ("fwd_eval", "dgrad"):
             ratio = r["chosen_over_best"].get(role)
             if ratio is None:
                 continue
             # F(2x2) on layer4 below 4,096 samples per channel is an ACCURACY rule (dense2d.F4_FWD_MIN_PIXELS: gradient noise of F(4x4)
-            # where BatchNorm normalises over few samples), not a speed choice; 128 -> 128 at 6,000 tiles sits between the two forms
+            # where BatchNorm normalises over few samples), not a speed choice
             slack = 1.30 if r["chosen"][role] == "F2" else 1.10
             assert ratio <= slack, (r["res"], r["B"], r["layer"], role, ratio)
 
