@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_run_reduce(const int* __restrict__ pos,
 // MOPA_SPCONV_RUN=0 switches the path off, =2 forces it wherever the shape is supported (tuning / tests).
 MOPA_API int mopa_spconv_run_wanted(int32_t K, int32_t num_out, int32_t cin, int32_t cout, int32_t one_rule_per_row) {
   static const int mode = getenv("MOPA_SPCONV_RUN") ? atoi(getenv("MOPA_SPCONV_RUN")) : 1;
-  static const int64_t rows_per = getenv("MOPA_SPCONV_RUN_ROWS_PER") ? atoll(getenv("MOPA_SPCONV_RUN_ROWS_PER")) : 110000;
+  const int64_t rows_per = 110000;
   if (mode == 0 || K <= 0 || K > 27 || num_out <= 0 || run_nt(cin, cout) == 0) return 0;
   if ((int64_t)num_out * 8 * 224 * 4 >= (1ll << 32)) return 0;   // 32-bit byte offsets into the input rows
   if (mode == 2) return 1;
@@ -448,8 +448,7 @@ MOPA_API int mopa_spconv_fwd_run(const int32_t* runs, int32_t K, int32_t num_out
 #undef RUN_N
 #undef RUN_L
   if (rc) return rc;
-  static const int no_reduce = getenv("MOPA_SPCONV_RUN_NOREDUCE") ? atoi(getenv("MOPA_SPCONV_RUN_NOREDUCE")) : 0;   // timing probe only (no output)
-  if (!one_rule_per_row && !no_reduce) {
+  if (!one_rule_per_row) {
     k_run_reduce<<<(unsigned)cdiv64(num_out, RED_ROWS), 256, 0, st>>>(pos, K, num_out, (const float*)ws, cout, out, ld_out);
     MOPA_CHECK_LAUNCH();
   }
@@ -756,8 +755,6 @@ static inline bool wgr_plan(int K, int64_t num_out, int cin, int cout, int one_r
   S = (S + WGR_TS - 1) / WGR_TS * WGR_TS;
   if (S < 128) S = 128;
   if (S > 1024) S = 1024;
-  static const int s_env = getenv("MOPA_WGR_S") ? atoi(getenv("MOPA_WGR_S")) : 0;   // tuning probe
-  if (s_env > 0) S = s_env;
   const int64_t bound = one_rule_per_row ? num_out + (int64_t)K * RUN_PAD : run_cap(K, num_out);   // slots that can hold a rule
   const int64_t per = (int64_t)cin * cout * sizeof(float);
   while ((bound / S + K) * per > (128ll << 20)) S += WGR_TS;

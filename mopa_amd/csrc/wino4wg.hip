@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_wino4_wgrad(const WgArgs a) {
 }
 
 static void wg_plan(int64_t T, int Cin, int Cout, int ncu, int* nsplit, int* tiles_per_split) {
-  static const int per_cu = [] { const char* e = getenv("MOPA_WINO4_WG_BLOCKS_PER_CU"); return e ? atoi(e) : 1; }();
+  const int per_cu = 1;   // (one 8-wave workgroup per CU and round: two fall into lockstep, profiles/r6_wino4_wgrad.md)
   const int by = (Cin / WG_CI) * (Cout / WG_CO);
   int64_t ns = ((int64_t)ncu * per_cu + by - 1) / by;   // ~ per_cu workgroups per CU in one round
   ns = (ns + 7) / 8 * 8;

@@ -212,7 +212,7 @@ def wino4_fused(cin, cout, B, H, W):
 # MOPA_WINO4_DIRECT=0 switches it off.
 WINO4_DIRECT = os.environ.get("MOPA_WINO4_DIRECT", "1") != "0"
 WINO4_DIRECT_MIN_TILES = int(os.environ.get("MOPA_WINO4_DIRECT_MIN_TILES", "4096"))   # (round 4: 16384, tuned at 16 x 302 x 480 only)
-WINO4_DIRECT_MAX_CIN = int(os.environ.get("MOPA_WINO4_DIRECT_MAX_CIN", "128"))
+WINO4_DIRECT_MAX_CIN = 128
 # Roles: "dgrad" (backward-data), "fwd_eval" (a forward pass that keeps nothing), "fwd" (the forward pass of a training step: it wants
 # V again for the weight gradient, the kernel stores it as a by-product and only a READ of V is saved -- measured neutral in the joint
 # step, 342 either way against 337 without the kernel, so it stays on the two-kernel path by default).
@@ -622,7 +622,6 @@ def colsum(x: View, out: torch.Tensor, accumulate=False):
     call("mopa_colsum", x.p, x.ld, x.rows, x.C, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream())
 
 
-GROUPED_BN = os.environ.get("MOPA_GROUPED_BN", "1") != "0"   # A/B switch: the BatchNorm groups of one pass in one set of launches
 # A/B switch: bn1 of a ResNet block is applied inside conv2's input transform instead of being written out (LazyImg)
 DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
 DEFER_UP_BN = os.environ.get("MOPA_DEFER_UP_BN", "1") != "0"   # ... and the decoder's up-convolution BatchNorms inside the join's consumer
@@ -719,7 +718,7 @@ def _backbone_forward(P, imgc, training, drop_p, drop_seed, seed_t, dev, groups=
             tape.append(("bn", name, x, y, stats, act, None, [None] * G))
             return y
         y = out if out is not None else new_img(x.B, x.H, x.W, x.C, dev)
-        if G > 1 and not (training and syncbn.active()) and GROUPED_BN:
+        if G > 1 and not (training and syncbn.active()):
             bn_fwd_groups(x, y, P, name, act, res, training, stats, G)     # one set of launches for all groups
             gathered = [None] * G
         else:
@@ -900,7 +899,7 @@ def _backbone_backward(P, sink, tape, J, feat, dfeat, training, drop_seed, seed_
                 continue
             dx = like(x)
             gmap[key(x)] = dx
-            if G > 1 and GROUPED_BN and all(gt is None for gt in gathered):
+            if G > 1 and all(gt is None for gt in gathered):
                 bn_bwd_groups(dy, x, dx, stats, act, y if res is not None else None, dres, acc_dres, training, dg, db, G, acc_params=pacc)
             else:
                 for g in range(G):

@@ -26,7 +26,7 @@ BN_MOMENTUM = 0.1   # SCN "momentum 0.9" == torch-style 0.1
 LEAK = 0.0          # scn.UNet leakiness=0 / BatchNormReLU
 BATCHED_REPACK = True   # one launch for all stale weight forms (the single-form path stays for never-built forms; tests flip the attribute)
 RUN_PATH = os.environ.get("MOPA_SPCONV_RUN", "1") != "0"             # the offset-major convolution (csrc/sprun.hip); 0 = round-4 kernels only
-RUN_MAX_ROWS = int(os.environ.get("MOPA_SPCONV_RUN_TABLE_ROWS", "220000"))   # 27-offset tables above this get no run-major rulebook
+RUN_MAX_ROWS = 220000   # 27-offset tables above this get no run-major rulebook
 
 
 def _ws(nbytes, device):
