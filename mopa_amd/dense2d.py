@@ -627,7 +627,8 @@ DEFER_BN = os.environ.get("MOPA_DEFER_BN", "1") != "0"
 DEFER_UP_BN = os.environ.get("MOPA_DEFER_UP_BN", "1") != "0"   # ... and the decoder's up-convolution BatchNorms inside the join's consumer
 DEFER_STEM_BN = os.environ.get("MOPA_DEFER_STEM_BN", "1") != "0"   # ... and the stem's inside its two readers (max-pool, full-resolution join)
 # A/B switch: the stem BatchNorm's backward apply inside the stem's weight gradient (mopa_stem_bwd_weight_bn: dx is never written)
-STEM_BN_FUSED_BWD = os.environ.get("MOPA_STEM_BN_FUSED_BWD", "1") != "0"
+# (the stem's weight gradient with the BatchNorm backward formed in its loader exists as an MFMA kernel only: off with MOPA_CONV2D_MFMA=0)
+STEM_BN_FUSED_BWD = os.environ.get("MOPA_STEM_BN_FUSED_BWD", "1") != "0" and os.environ.get("MOPA_CONV2D_MFMA", "1") != "0"
 
 
 def bn_fwd(x: View, y: View, P, name, act, res, training, stats):
