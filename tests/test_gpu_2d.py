@@ -873,6 +873,30 @@ def test_deferred_batchnorm_gives_the_bits_of_the_materialised_one(groups, monke
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,wide_out", [(16, 64, 2, 23, 18, False), (48, 192, 1, 32, 40, True), (32, 64, 3, 9, 70, False), (80, 256, 2, 12, 12, True)])
+def test_wino4_nine_point_convolution_channel_shapes_the_dispatcher_does_not_use(cin, cout, B, H, W, wide_out):
+    """mopa_wino4_conv9 straight through the C ABI on the channel counts its contract allows (Cin % 16 == 0, Cout % 64 == 0) but
+    dense2d.wino4_direct never sends (it wants 64-aligned inputs and at most 128 outputs): one to five 16-channel steps, several
+    64-channel output blocks per tile group, the output as a column slice of a wider buffer -- against an fp64 conv3x3."""
+    import torch.nn.functional as F
+    from mopa_amd._lib import call, ptr, stream
+    rng = np.random.Generator(np.random.PCG64(77 + cin + cout))
+    x = torch.from_numpy(rng.standard_normal((B * H * W, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+    U = torch.empty(36, cin, cout, device="cuda")
+    call("mopa_wino4_weight_q", ptr(w), cout, cin, 0, ptr(U), stream())
+    ld_out = cout + 64 if wide_out else cout
+    out = torch.full((B * H * W, ld_out), float("nan"), device="cuda")
+    call("mopa_wino4_conv9", ptr(x), cin, ptr(U), ptr(bias), ptr(out, 64 if wide_out else 0), ld_out, B, H, W, cin, cout, 0, None, 1, 0, stream())
+    ref = F.conv2d(x.reshape(B, H, W, cin).permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), bias.double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    got = out[:, 64:] if wide_out else out
+    _close(got, ref.float().numpy(), rtol=1e-4, atol=3e-5)
+    if wide_out:
+        assert bool(torch.isnan(out[:, :64]).all())   # nothing outside the slice is written
+
+
 @pytest.mark.parametrize("cin,cout,H,W,acc,dgrad,G", [(64, 64, 37, 51, False, False, 0), (128, 64, 21, 30, True, False, 0),
                                                       (64, 128, 16, 24, False, True, 0), (64, 64, 19, 22, False, False, 2),
                                                       (128, 128, 9, 13, True, True, 1)])
