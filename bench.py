@@ -1198,6 +1198,15 @@ def main():
                           "stream_configuration": "the weight-gradient stream beside the backward-data chain (as timed for `value`)"
                           if dense2d_streams() else "the main stream",
                           "note": "the transforms that feed the two-operand form (k_wino4_dout, the V kept or recomputed) are not in the brackets"}
+            # HBM bytes per weight gradient from the same committed PMC passes: the MFMA kernels + their slab reductions, per MFMA launch
+            wmain = [tj[k] for k in ("k_conv2d_wgrad_mfma", "k_wino4_wgrad", "k_stem_wgrad_mfma", "k_wgemm_tn") if k in tj]
+            wextra = [tj[k] for k in ("k_reduce_slabs2", "k_wino4_dw", "k_wino_dw") if k in tj]
+            if wmain:
+                roof_wgrad["traffic"] = int(sum(f["hbm_bytes_per_launch"] * f["launches"] for f in wmain + wextra) / sum(f["launches"] for f in wmain))
+                roof_wgrad["traffic_source"] = (f"{os.path.relpath(tpath, ROOT)} at commit {tj.get('_commit', '?')} (PMC passes of this command; HBM bytes of the "
+                                                "MFMA kernels and their slab reductions per weight gradient)")
+                roof_wgrad["algorithmic_bytes_per_launch_note"] = ("not priced: a weight gradient reads its layer's input and output gradient once "
+                                                                   "(x + dY; V + dM = 2.25 x that for the two-operand transform-domain form) and writes 36 Cin Cout floats per split")
             rw = famj.get(wl_key, {}).get("wgrad_mfma")
             if rw and not _fresh(rw, roof_wgrad["launches_per_step"]):
                 roof_wgrad["rocprof_note"] = f"{os.path.relpath(fam_path, ROOT)} was taken with another launch count per step: not used"
